@@ -1,0 +1,158 @@
+"""TEST INFRASTRUCTURE ONLY (build container) -- golden-vector generator.
+
+Imports the reference's own Python (``/root/reference/src/models/simclr.py``) on CPU through
+the metadata stub in ``ref_stub.py``, loads the procedural state_dict (``procedural.py``) into
+``SimCLRSkinV32('resnet50', None, 128, 0.1)``, runs the reference's training step exactly as
+``tools/backbone_train.py:98-127`` composes it (style 0, fp32 and fp64, no AMP) and writes small
+fixtures to ``tests/golden/``.  The reference never travels: only inputs' seeds and expected
+outputs are stored.
+
+    python -m oracle.gen_golden            # from /root/repo
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("SM3_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+sys.path.insert(0, ROOT)
+from oracle import procedural, ref_stub  # noqa: E402
+
+
+def _import_reference():
+    ref_stub.install()
+    sys.path.insert(0, REF)
+    from src.models.simclr import SimCLRSkinV32  # the reference's class
+    return SimCLRSkinV32
+
+
+def _subsample(t, n=256):
+    flat = t.detach().reshape(-1)
+    step = max(1, flat.numel() // n)
+    return flat[::step][:n].double().numpy()
+
+
+def run_case(SimCLRSkinV32, batch, size, seed, dtype, style, lr, tag):
+    torch.manual_seed(0)
+    model = SimCLRSkinV32("resnet50", None, 128, 0.1)
+    state = procedural.make_state_dict(seed=seed)
+    assert list(state.keys()) == list(model.state_dict().keys()), "state_dict key order differs"
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    model = model.to(dtype)
+    model.train()
+    derm_np, clinic_np = procedural.make_pair_batch(batch, size, seed)
+    derm = [torch.from_numpy(a).to(dtype) for a in derm_np]
+    clinic = [torch.from_numpy(a).to(dtype) for a in clinic_np]
+
+    criterion = torch.nn.CrossEntropyLoss()
+    optimizer = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=5e-2, eps=1e-5)
+
+    # intermediate taps (forward hooks on the reference modules; first derm view only)
+    taps = {}
+    enc = model.derm_backbone.encoder
+    calls = {"n": 0}
+
+    def mk(name):
+        def hook(_m, _i, o):
+            if name not in taps:
+                taps[name] = o.detach().clone()
+        return hook
+
+    hooks = [enc.conv1.register_forward_hook(mk("conv1")), enc.maxpool.register_forward_hook(mk("maxpool"))]
+    for li in range(1, 5):
+        layer = getattr(enc, f"layer{li}")
+        for b in range(len(layer)):
+            hooks.append(layer[b].register_forward_hook(mk(f"layer{li}.{b}")))
+
+    outputs = model(derm, clinic, style)
+    for h in hooks:
+        h.remove()
+    w = 0.25 if style == 2 else 0.5
+    cross_loss = sum(w * criterion(*o) for o in outputs[2])
+    derm_loss = criterion(*outputs[0])
+    clinic_loss = criterion(*outputs[1])
+    loss = derm_loss + clinic_loss + cross_loss
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+
+    out = {
+        "meta": np.array([batch, size, seed, style], dtype=np.int64),
+        "lr": np.array(lr),
+        "loss": np.array(loss.item()),
+        "loss_terms": np.array([derm_loss.item(), clinic_loss.item()] + [criterion(*o).item() for o in outputs[2]]),
+        "derm_logits": outputs[0][0].detach().double().numpy(),
+        "clinic_logits": outputs[1][0].detach().double().numpy(),
+    }
+    for i, o in enumerate(outputs[2]):
+        out[f"cross_logits_{i}"] = o[0].detach().double().numpy()
+        assert int(o[1].abs().sum()) == 0 and o[1].dtype == torch.long
+
+    for name, t in taps.items():
+        out["tap_sub." + name] = _subsample(t)
+        out["tap_stat." + name] = np.array([t.double().mean().item(), t.double().abs().mean().item(),
+                                             t.double().pow(2).sum().sqrt().item()])
+        out["tap_shape." + name] = np.array(t.shape, dtype=np.int64)
+
+    names = [k for k, _ in model.named_parameters()]
+    out["grad_norm"] = np.array([p.grad.double().norm().item() for _, p in model.named_parameters()])
+    out["grad_sum"] = np.array([p.grad.double().sum().item() for _, p in model.named_parameters()])
+    for k in ("derm_backbone.encoder.conv1.weight", "derm_backbone.encoder.bn1.weight",
+              "derm_backbone.encoder.bn1.bias", "clinic_backbone.encoder.layer4.2.bn3.weight",
+              "derm_backbone.encoder.layer1.0.conv1.weight",
+              "derm_backbone.projector.4.bias", "cross_proj.1.1.weight"):
+        out["grad_full." + k] = dict(model.named_parameters())[k].grad.double().numpy()
+    for k in ("derm_backbone.encoder.layer3.1.conv2.weight", "clinic_backbone.projector.0.weight",
+              "clinic_backbone.encoder.layer2.0.downsample.0.weight",
+              "cross_proj.0.6.weight", "derm_backbone.encoder.layer4.0.conv2.weight"):
+        out["grad_sub." + k] = _subsample(dict(model.named_parameters())[k].grad)
+
+    # eval-mode extract (simclr.py:393-396): pre-step weights, post-forward running statistics
+    # (taken before optimizer.step(): the first Adam step is sign-like, hence ill-conditioned)
+    model.eval()
+    with torch.no_grad():
+        feats = model.extract(derm[0], clinic[0])
+    out["extract_derm"] = feats[0].double().numpy()
+    out["extract_clinic"] = feats[1].double().numpy()
+    model.train()
+
+    optimizer.step()
+    sd = model.state_dict()
+    out["post_param_norm"] = np.array([sd[k].double().norm().item() for k in names])
+    out["post_param_sum"] = np.array([sd[k].double().sum().item() for k in names])
+    bn_keys = [k for k in sd if k.endswith(("running_mean", "running_var"))]
+    out["post_buf_sum"] = np.array([sd[k].double().sum().item() for k in bn_keys])
+    out["post_buf_norm"] = np.array([sd[k].double().norm().item() for k in bn_keys])
+    out["post_nbt"] = np.array([int(sd[k]) for k in sd if k.endswith("num_batches_tracked")], dtype=np.int64)
+    for k in ("derm_backbone.encoder.bn1.running_mean", "derm_backbone.encoder.bn1.running_var",
+              "clinic_backbone.encoder.layer4.2.bn3.running_var", "cross_proj.0.7.running_mean",
+              "derm_backbone.projector.1.running_var"):
+        out["post_buf_full." + k] = sd[k].double().numpy()
+
+    path = os.path.join(OUT, f"sm3_v32_{tag}.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: loss={loss.item():.8f} ({os.path.getsize(path)/1024:.0f} KiB)")
+    return names
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    cls = _import_reference()
+    names = run_case(cls, batch=4, size=64, seed=1, dtype=torch.float32, style=0, lr=1e-3, tag="b4_s64_f32")
+    run_case(cls, batch=4, size=64, seed=1, dtype=torch.float64, style=0, lr=1e-3, tag="b4_s64_f64")
+    run_case(cls, batch=3, size=96, seed=2, dtype=torch.float64, style=2, lr=1e-3, tag="b3_s96_style2_f64")
+    with open(os.path.join(OUT, "param_names.txt"), "w") as f:
+        f.write("\n".join(names) + "\n")
+    # the 700 state_dict keys = checkpoint wire format (tools/backbone_train.py:578-587)
+    keys = [k for k, _ in procedural.sm3_v32_spec()]
+    with open(os.path.join(OUT, "state_dict_keys.txt"), "w") as f:
+        f.write("\n".join(keys) + "\n")
+
+
+if __name__ == "__main__":
+    main()
