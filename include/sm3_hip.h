@@ -1,0 +1,165 @@
+/*
+ * sm3_hip.h -- C ABI of libsm3hip.so: the MI355X (gfx950) kernels of the SM3 pre-training hot path.
+ *
+ * The reference (Dylan-H-Wang/skin-sm3) is pure Python and has no FFI of its own: every entry point
+ * below replaces the ATen/cuDNN/cuBLAS work behind one call site of the reference, cited as
+ * file:line under /root/reference.  The library has no PyTorch types in its signatures: device
+ * pointers, sizes, a hipStream_t passed as void*.  All tensors are dense; activations are NHWC
+ * ("rows x channels", channels contiguous), weights are [Cout][taps][Cin] (= the memory order of a
+ * torch channels_last OIHW tensor).  `dtype` selects the storage/MFMA type of activations and
+ * weight copies: SM3_F32 (exact-f32 MFMA, parity mode) or SM3_BF16 (bf16 MFMA, fp32 accumulate).
+ * Statistics, master weights, gradients of weights and optimizer state are always fp32 (BN sums fp64).
+ *
+ * Every function returns 0 on success, a positive hipError_t on a runtime failure, or a negative
+ * SM3_E* code on a rejected argument; nothing is launched when an argument is rejected.
+ * Nothing here allocates, frees or synchronises: safe to capture into a hipGraph.
+ */
+#ifndef SM3_HIP_H
+#define SM3_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SM3_F32 0
+#define SM3_BF16 1
+
+#define SM3_EINVAL (-1)   /* bad size / null pointer */
+#define SM3_EALIGN (-2)   /* channel count not a multiple of the kernel's K chunk */
+#define SM3_EDTYPE (-3)
+
+#define SM3_MAX_TAPS 9
+
+/* ABI version, bumped on any signature change. */
+int sm3_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Gather-GEMM convolution: forward conv, data-gradient of a conv, and bias-free Linear.
+ *   replaces nn.Conv2d forward/backward-data  (src/models/resnet.py:49-67 conv3x3/conv1x1, used at
+ *   :144-148,:260; stem :208-210 via sm3_stem_im2col) and nn.Linear(bias=False)
+ *   (src/models/simclr.py:17-27).
+ *
+ *   y[n, oy*osy+ooy, ox*osx+oox, co] = sum_t sum_ci x[n, oy*sy+dy[t], ox*sx+dx[t], ci]
+ *                                                 * w[co*w_row_stride + wtap[t]*Ci + ci]   (+ addend)
+ *   for (n,oy,ox) in N x Ho x Wo; out-of-range x reads are zero.  Ci must be a multiple of
+ *   128 bytes / sizeof(T) (64 bf16 / 32 f32).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sm3_conv_desc {
+    int32_t dtype;
+    int32_t N, Hi, Wi, Ci;          /* x: [N,Hi,Wi,Ci] */
+    int32_t Ho, Wo, Co;             /* iteration space and GEMM-N */
+    int32_t sy, sx;
+    int32_t ntaps;
+    int32_t dy[SM3_MAX_TAPS], dx[SM3_MAX_TAPS], wtap[SM3_MAX_TAPS];
+    int32_t w_row_stride;           /* elements between rows (co) of w */
+    int32_t Hout, Wout;             /* y: [N,Hout,Wout,Co] */
+    int32_t osy, osx, ooy, oox;
+} sm3_conv_desc;
+
+/* number of [2][Co] fp32 partial-statistics rows sm3_conv_gather_gemm writes for this desc */
+int sm3_conv_partial_rows(const sm3_conv_desc* d);
+
+/* stat_partials (nullable): [partial_rows][2][Co] fp32 -- per-row-block sum and sum of squares of
+ * the stored (rounded) outputs, for train-mode BatchNorm (resnet.py:145-149,211,261).
+ * addend (nullable): same indexing as y, added in the epilogue (may alias y). */
+int sm3_conv_gather_gemm(const sm3_conv_desc* d, const void* x, const void* w, void* y,
+                         const void* addend, float* stat_partials, void* stream);
+
+/* Weight gradient of the forward conv described by d (autograd of the same call sites):
+ *   dw[co*w_row_stride + wtap[t]*Ci + ci] += sum_{n,oy,ox} dy[(n,oy,ox), co] * x[n, oy*sy+dy[t], ox*sx+dx[t], ci]
+ * dy is dense [N*Ho*Wo, Co]; dw is fp32 and is accumulated into (float atomics, split over pixels).
+ * Columns wtap[t]*Ci+ci >= w_row_stride are dropped (the zero-padded K tail of the stem im2col). */
+int sm3_conv_wgrad(const sm3_conv_desc* d, const void* x, const void* dy, float* dw, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm (2d and 1d: rows x C), train and eval.  replaces nn.BatchNorm2d/1d (+SyncBatchNorm,
+ * tools/backbone_train.py:510) at resnet.py:145-149,211,261 and simclr.py:20-26.
+ * ------------------------------------------------------------------------------------------ */
+/* sums[0..C) = sum over partial rows of p[r][0][c]; sums[C..2C) likewise of p[r][1][c]  (fp64) */
+int sm3_bn_stats_reduce(const float* partials, int rows, int C, double* sums, void* stream);
+/* From (possibly all-reduced) sums and the global element count per channel: mean, biased var ->
+ * scale = gamma*invstd, shift = beta - mean*scale; running stats momentum update with the unbiased
+ * variance; saves mean / invstd for backward.  gamma/beta NULL => affine=False. */
+int sm3_bn_finalize(const double* sums, double count, int C, const float* gamma, const float* beta,
+                    float eps, float momentum, float* running_mean, float* running_var,
+                    int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean,
+                    float* save_invstd, void* stream);
+/* eval mode: scale/shift from the running statistics */
+int sm3_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean,
+                            const float* running_var, float eps, int C, float* scale, float* shift,
+                            void* stream);
+/* y = [relu]( x*scale + shift [+ residual] ), x,residual,y: [rows, C] of dtype; out_f32 != 0 stores y as fp32.
+ * replaces the bn->relu / bn->add->relu chains of Bottleneck.forward (resnet.py:154-174). */
+int sm3_bn_act(int dtype, const void* x, const float* scale, const float* shift, const void* residual,
+               int relu, int out_f32, void* y, int64_t rows, int C, void* stream);
+/* Backward, phase 1: dz = dy * (y > 0 if y != NULL); writes dz (may alias dy; NULL to skip) and
+ * per-block partial sums [bwd_partial_rows][2][C] of (dz, dz * xhat), xhat = (x-mean)*invstd. */
+int sm3_bn_bwd_partial_rows(int64_t rows, int C);
+int sm3_bn_bwd_reduce(int dtype, const void* dy, const void* y, const void* x, const float* mean,
+                      const float* invstd, void* dz, int64_t rows, int C, float* partials, void* stream);
+/* Backward, phase 2: dx = gamma*invstd*(dz - sum_dz/count - xhat*sum_dz_xhat/count) with the
+ * (all-reduced) global sums; dgamma += local sum(dz*xhat), dbeta += local sum(dz) (NULL to skip). */
+int sm3_bn_bwd_apply(int dtype, const void* dz, const void* x, const float* mean, const float* invstd,
+                     const float* gamma, const double* global_sums, double count,
+                     const double* local_sums, float* dgamma, float* dbeta, void* dx, int64_t rows,
+                     int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Stem, pooling.  replaces resnet.py:208-213,224,294-305.
+ * ------------------------------------------------------------------------------------------ */
+/* 7x7/2 pad-3 im2col of an NCHW fp32 image batch into rows [N*Ho*Wo, Kpad] of dtype,
+ * k = (kh*7+kw)*3 + c for k < 147, zero for 147 <= k < Kpad. */
+int sm3_stem_im2col(int dtype, const float* x_nchw, void* cols, int N, int H, int W, int Kpad, void* stream);
+int sm3_maxpool3x3s2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream);
+/* dx[argmax window position] += dy, argmax recomputed from x (first maximum in (kh,kw) scan order) */
+int sm3_maxpool3x3s2_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int C, void* stream);
+/* feat[n,c] = mean over HW; feat_f32 and feat_t (dtype copy for the projector GEMM) both optional */
+int sm3_avgpool_fwd(int dtype, const void* x, float* feat_f32, void* feat_t, int N, int HW, int C, void* stream);
+int sm3_avgpool_bwd(int dtype, const void* dfeat, void* dx, int N, int HW, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight layout preparation (per optimizer step).  w: fp32 master [Co][taps][Ci].
+ *   w_fwd   (nullable): dtype [Co][ld_fwd]  (ld_fwd >= taps*Ci, tail zero-filled)
+ *   w_dgrad (nullable): dtype [Ci][taps][Co]   (the transposed filter bank used by the data gradient)
+ * ------------------------------------------------------------------------------------------ */
+int sm3_weight_prep(int dtype, const float* w, int Co, int taps, int Ci, void* w_fwd, int ld_fwd,
+                    void* w_dgrad, void* stream);
+/* elementwise cast fp32 -> dtype */
+int sm3_cast_from_f32(int dtype, const float* src, void* dst, int64_t n, void* stream);
+int sm3_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * NT-Xent.  replaces F.normalize + matmul + mask/select + /T (simclr.py:62-88, 294-320) and
+ * nn.CrossEntropyLoss (tools/backbone_train.py:531, applied :101-102,119-120).
+ * R = 2B rows, D = proj_dim.
+ * ------------------------------------------------------------------------------------------ */
+/* zn = z / max(|z|,1e-12); logits[i][0] = S[i][p]/T, logits[i][1..] = S[i][j != i,p]/T ascending j, p=(i+R/2)%R */
+int sm3_ntxent_logits(const float* z, int R, int D, float temperature, float* zn, float* inv_norm,
+                      float* logits, void* stream);
+/* d(loss)/dz from d(loss)/dlogits (reference layout), written as dtype */
+int sm3_ntxent_logits_bwd(int dtype, const float* dlogits, const float* zn, const float* inv_norm, int R,
+                          int D, float temperature, void* dz, void* stream);
+/* mean cross-entropy against label 0 of logits [R][Cc]; loss[0] += weight*CE; dlogits = weight*grad */
+int sm3_ce_label0(const float* logits, int R, int Cc, float weight, float* loss, float* dlogits, void* stream);
+/* fused: loss[0] += weight * NTXent(z); dz = weight * dNTXent/dz (dtype); never materialises logits.
+ * workspace: R*D + 2*R floats (normalised rows, inverse norms, per-row logsumexp). */
+int sm3_ntxent_fused(int dtype, const float* z, int R, int D, float temperature, float weight,
+                     float* workspace, float* loss, void* dz, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * AdamW over a flat fp32 buffer.  replaces torch.optim.AdamW(eps=1e-5, wd) + GradScaler unscale
+ * (tools/backbone_train.py:124-127, 525-527).  g is multiplied by grad_scale first.
+ * found_inf (nullable): if *found_inf != 0 the step is skipped (GradScaler semantics).
+ * ------------------------------------------------------------------------------------------ */
+int sm3_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+              float eps, float weight_decay, int step, float grad_scale, const int32_t* found_inf,
+              void* stream);
+/* found_inf[0] |= any(!isfinite(g)) */
+int sm3_check_finite(const float* g, int64_t n, int32_t* found_inf, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,358 @@
+// BatchNorm (2d / 1d as rows x C, channels contiguous): statistics finalisation, fused
+// normalise(+residual)(+ReLU) apply, and the two-phase backward.  All HBM-bound: 16-byte vector
+// accesses, a thread keeps one channel vector for its whole row walk so per-channel parameters
+// are loaded once.  Statistics are combined in fp64 so E[x^2]-E[x]^2 loses nothing.
+//
+// Reference call sites replaced: nn.BatchNorm2d / BatchNorm1d in train mode
+// (src/models/resnet.py:145-149,211,261; src/models/simclr.py:20-26), the bn->relu and
+// bn->add->relu chains of Bottleneck.forward (resnet.py:154-174), SyncBatchNorm's two
+// cross-rank reductions (tools/backbone_train.py:510) -- the reductions themselves are done by
+// the host between sm3_bn_stats_reduce and sm3_bn_finalize / sm3_bn_bwd_apply.
+#include "common.h"
+
+namespace {
+
+// 2-D work decomposition shared by the row-walk kernels.
+struct RowWalk {
+    int tbx, tby;   // threads along channel vectors / rows
+    int gx, gy;     // blocks along channel vectors / row groups
+};
+static RowWalk make_walk(int64_t rows, int cvecs, int max_gy) {
+    RowWalk w;
+    if (cvecs >= 256) {
+        w.tbx = 256;
+    } else {
+        w.tbx = cvecs;
+    }
+    w.tby = 256 / w.tbx;
+    if (w.tby < 1) w.tby = 1;
+    w.gx = (cvecs + w.tbx - 1) / w.tbx;
+    int64_t gy = (rows + (int64_t)w.tby * 4 - 1) / ((int64_t)w.tby * 4);
+    if (gy > max_gy) gy = max_gy;
+    if (gy < 1) gy = 1;
+    w.gy = (int)gy;
+    return w;
+}
+
+__global__ void bn_stats_reduce_kernel(const float* __restrict__ partials, int rows, int C, double* __restrict__ sums) {
+    // one thread per (stat, channel) column; rows are reduced in fp64, 4 independent chains
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;  // in [0, 2C)
+    if (col >= 2 * C) return;
+    const int stat = col / C, c = col - stat * C;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int r = 0;
+    for (; r + 3 < rows; r += 4) {
+        a0 += (double)partials[((long)(r + 0) * 2 + stat) * C + c];
+        a1 += (double)partials[((long)(r + 1) * 2 + stat) * C + c];
+        a2 += (double)partials[((long)(r + 2) * 2 + stat) * C + c];
+        a3 += (double)partials[((long)(r + 3) * 2 + stat) * C + c];
+    }
+    for (; r < rows; ++r) a0 += (double)partials[((long)r * 2 + stat) * C + c];
+    sums[col] = (a0 + a1) + (a2 + a3);
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, int C, const float* gamma,
+                                   const float* beta, float eps, float momentum, float* running_mean,
+                                   float* running_var, int64_t* nbt, float* scale, float* shift, float* save_mean,
+                                   float* save_invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) nbt[0] += 1;
+    if (c >= C) return;
+    const double mean = sums[c] / count;
+    double var = sums[C + c] / count - mean * mean;
+    if (var < 0) var = 0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = (float)(g * invstd);
+    scale[c] = sc;
+    shift[c] = (float)((double)b - mean * (double)g * invstd);
+    if (save_mean) save_mean[c] = (float)mean;
+    if (save_invstd) save_invstd[c] = (float)invstd;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) {
+        const double unbiased = var * (count / fmax(count - 1.0, 1.0));
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_eval_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                               int C, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = 1.f / sqrtf(rv[c] + eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    scale[c] = g * invstd;
+    shift[c] = b - rm[c] * g * invstd;
+}
+
+template <typename T, bool OUT_F32>
+__global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, const T* __restrict__ res,
+                                                     int relu, void* __restrict__ y, int64_t rows, int C, int tbx,
+                                                     int tby) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    const int tx = threadIdx.x % tbx, ty = threadIdx.x / tbx;
+    const int cv = blockIdx.x * tbx + tx;
+    if (cv * E >= C || ty >= tby) return;
+    float sc[E], sh[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        sc[e] = scale[cv * E + e];
+        sh[e] = shift[cv * E + e];
+    }
+    const int64_t rstep = (int64_t)gridDim.y * tby;
+    for (int64_t r = (int64_t)blockIdx.y * tby + ty; r < rows; r += rstep) {
+        const int64_t off = r * C + (int64_t)cv * E;
+        float v[E];
+        unpack16<T>(*reinterpret_cast<const uint4*>(x + off), v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = v[e] * sc[e] + sh[e];
+        if (res) {
+            float q[E];
+            unpack16<T>(*reinterpret_cast<const uint4*>(res + off), q);
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] += q[e];
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if constexpr (OUT_F32) {
+            float* yo = reinterpret_cast<float*>(y) + off;
+#pragma unroll
+            for (int e = 0; e < E; e += 4)
+                *reinterpret_cast<float4*>(yo + e) = make_float4(v[e], v[e + 1], v[e + 2], v[e + 3]);
+        } else {
+            *reinterpret_cast<uint4*>(reinterpret_cast<T*>(y) + off) = pack16<T>(v);
+        }
+    }
+}
+
+// phase 1 of backward: relu mask, optional dz write-back, partial sums of dz and dz*xhat
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                            const T* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, T* __restrict__ dz,
+                                                            int64_t rows, int C, float* __restrict__ partials,
+                                                            int tbx, int tby) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    __shared__ float sred[256 * 2 * 8];
+    const int tx = threadIdx.x % tbx, ty = threadIdx.x / tbx;
+    const int cv = blockIdx.x * tbx + tx;
+    const bool active = (cv * E < C) && (ty < tby);
+    float s1[E], s2[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) s1[e] = s2[e] = 0.f;
+    if (active) {
+        float mu[E], is[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            mu[e] = mean[cv * E + e];
+            is[e] = invstd[cv * E + e];
+        }
+        const int64_t rstep = (int64_t)gridDim.y * tby;
+        for (int64_t r = (int64_t)blockIdx.y * tby + ty; r < rows; r += rstep) {
+            const int64_t off = r * C + (int64_t)cv * E;
+            float g[E], xv[E];
+            unpack16<T>(*reinterpret_cast<const uint4*>(dy + off), g);
+            unpack16<T>(*reinterpret_cast<const uint4*>(x + off), xv);
+            if (y) {
+                float yv[E];
+                unpack16<T>(*reinterpret_cast<const uint4*>(y + off), yv);
+#pragma unroll
+                for (int e = 0; e < E; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
+                if (dz) *reinterpret_cast<uint4*>(dz + off) = pack16<T>(g);
+            } else if (dz && dz != dy) {
+                *reinterpret_cast<uint4*>(dz + off) = pack16<T>(g);
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                s1[e] += g[e];
+                s2[e] += g[e] * (xv[e] - mu[e]) * is[e];
+            }
+        }
+    }
+    // reduce over ty within the block
+    float* mine = sred + threadIdx.x * 2 * E;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        mine[e] = s1[e];
+        mine[E + e] = s2[e];
+    }
+    __syncthreads();
+    if (ty == 0 && cv * E < C) {
+        for (int j = 1; j < tby; ++j) {
+            const float* o = sred + (j * tbx + tx) * 2 * E;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                s1[e] += o[e];
+                s2[e] += o[E + e];
+            }
+        }
+        float* p1 = partials + ((int64_t)blockIdx.y * 2 + 0) * C + (int64_t)cv * E;
+        float* p2 = partials + ((int64_t)blockIdx.y * 2 + 1) * C + (int64_t)cv * E;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            p1[e] = s1[e];
+            p2[e] = s2[e];
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ x,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const double* __restrict__ gsums, double count,
+                                                           T* __restrict__ dx, int64_t rows, int C, int tbx, int tby) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    const int tx = threadIdx.x % tbx, ty = threadIdx.x / tbx;
+    const int cv = blockIdx.x * tbx + tx;
+    if (cv * E >= C || ty >= tby) return;
+    float mu[E], is[E], k0[E], k1[E], k2[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int c = cv * E + e;
+        mu[e] = mean[c];
+        is[e] = invstd[c];
+        const float g = gamma ? gamma[c] : 1.f;
+        k0[e] = g * is[e];                                  // dx = k0 * (dz - k1 - xhat * k2)
+        k1[e] = (float)(gsums[c] / count);
+        k2[e] = (float)(gsums[C + c] / count);
+    }
+    const int64_t rstep = (int64_t)gridDim.y * tby;
+    for (int64_t r = (int64_t)blockIdx.y * tby + ty; r < rows; r += rstep) {
+        const int64_t off = r * C + (int64_t)cv * E;
+        float g[E], xv[E];
+        unpack16<T>(*reinterpret_cast<const uint4*>(dz + off), g);
+        unpack16<T>(*reinterpret_cast<const uint4*>(x + off), xv);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const float xh = (xv[e] - mu[e]) * is[e];
+            g[e] = k0[e] * (g[e] - k1[e] - xh * k2[e]);
+        }
+        *reinterpret_cast<uint4*>(dx + off) = pack16<T>(g);
+    }
+}
+
+__global__ void bn_param_grad_kernel(const double* __restrict__ lsums, int C, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (dbeta) dbeta[c] += (float)lsums[c];
+    if (dgamma) dgamma[c] += (float)lsums[C + c];
+}
+
+}  // namespace
+
+extern "C" int sm3_bn_stats_reduce(const float* partials, int rows, int C, double* sums, void* stream) {
+    if (!partials || !sums || rows <= 0 || C <= 0) return SM3_EINVAL;
+    hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((2 * C + 63) / 64), dim3(64), 0, (hipStream_t)stream, partials,
+                       rows, C, sums);
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_bn_finalize(const double* sums, double count, int C, const float* gamma, const float* beta,
+                               float eps, float momentum, float* running_mean, float* running_var,
+                               int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean,
+                               float* save_invstd, void* stream) {
+    if (!sums || !scale || !shift || C <= 0 || count <= 0) return SM3_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, C,
+                       gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift,
+                       save_mean, save_invstd);
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean,
+                                       const float* running_var, float eps, int C, float* scale, float* shift,
+                                       void* stream) {
+    if (!running_mean || !running_var || !scale || !shift || C <= 0) return SM3_EINVAL;
+    hipLaunchKernelGGL(bn_eval_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                       running_mean, running_var, eps, C, scale, shift);
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_bn_act(int dtype, const void* x, const float* scale, const float* shift, const void* residual,
+                          int relu, int out_f32, void* y, int64_t rows, int C, void* stream) {
+    if (!x || !scale || !shift || !y || rows <= 0 || C <= 0) return SM3_EINVAL;
+    if (dtype != SM3_F32 && dtype != SM3_BF16) return SM3_EDTYPE;
+    const int E = dtype == SM3_F32 ? 4 : 8;
+    if (C % E) return SM3_EALIGN;
+    const RowWalk w = make_walk(rows, C / E, 8192);
+    dim3 grid(w.gx, w.gy), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SM3_F32) {
+        // f32 storage: the two output forms coincide
+        hipLaunchKernelGGL((bn_act_kernel<float, false>), grid, block, 0, st, (const float*)x, scale, shift,
+                           (const float*)residual, relu, y, rows, C, w.tbx, w.tby);
+    } else if (out_f32) {
+        hipLaunchKernelGGL((bn_act_kernel<bf16_t, true>), grid, block, 0, st, (const bf16_t*)x, scale, shift,
+                           (const bf16_t*)residual, relu, y, rows, C, w.tbx, w.tby);
+    } else {
+        hipLaunchKernelGGL((bn_act_kernel<bf16_t, false>), grid, block, 0, st, (const bf16_t*)x, scale, shift,
+                           (const bf16_t*)residual, relu, y, rows, C, w.tbx, w.tby);
+    }
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+static int bwd_gy(int64_t rows) {
+    int64_t gy = (rows + 63) / 64;
+    if (gy > 1024) gy = 1024;
+    if (gy < 1) gy = 1;
+    return (int)gy;
+}
+
+extern "C" int sm3_bn_bwd_partial_rows(int64_t rows, int C) {
+    (void)C;
+    return rows > 0 ? bwd_gy(rows) : SM3_EINVAL;
+}
+
+extern "C" int sm3_bn_bwd_reduce(int dtype, const void* dy, const void* y, const void* x, const float* mean,
+                                 const float* invstd, void* dz, int64_t rows, int C, float* partials, void* stream) {
+    if (!dy || !x || !mean || !invstd || !partials || rows <= 0 || C <= 0) return SM3_EINVAL;
+    if (dtype != SM3_F32 && dtype != SM3_BF16) return SM3_EDTYPE;
+    const int E = dtype == SM3_F32 ? 4 : 8;
+    if (C % E) return SM3_EALIGN;
+    RowWalk w = make_walk(rows, C / E, 1 << 30);
+    w.gy = bwd_gy(rows);
+    dim3 grid(w.gx, w.gy), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SM3_F32)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, block, 0, st, (const float*)dy, (const float*)y,
+                           (const float*)x, mean, invstd, (float*)dz, rows, C, partials, w.tbx, w.tby);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)y,
+                           (const bf16_t*)x, mean, invstd, (bf16_t*)dz, rows, C, partials, w.tbx, w.tby);
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_bn_bwd_apply(int dtype, const void* dz, const void* x, const float* mean, const float* invstd,
+                                const float* gamma, const double* global_sums, double count,
+                                const double* local_sums, float* dgamma, float* dbeta, void* dx, int64_t rows, int C,
+                                void* stream) {
+    if (!dz || !x || !mean || !invstd || !global_sums || !dx || rows <= 0 || C <= 0 || count <= 0) return SM3_EINVAL;
+    if (dtype != SM3_F32 && dtype != SM3_BF16) return SM3_EDTYPE;
+    const int E = dtype == SM3_F32 ? 4 : 8;
+    if (C % E) return SM3_EALIGN;
+    const RowWalk w = make_walk(rows, C / E, 8192);
+    dim3 grid(w.gx, w.gy), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SM3_F32)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, block, 0, st, (const float*)dz, (const float*)x, mean,
+                           invstd, gamma, global_sums, count, (float*)dx, rows, C, w.tbx, w.tby);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)dz, (const bf16_t*)x, mean,
+                           invstd, gamma, global_sums, count, (bf16_t*)dx, rows, C, w.tbx, w.tby);
+    SM3_CHECK_LAUNCH();
+    if ((dgamma || dbeta) && local_sums) {
+        hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, local_sums, C, dgamma,
+                           dbeta);
+        SM3_CHECK_LAUNCH();
+    }
+    return 0;
+}

@@ -1,0 +1,116 @@
+// Shared device/host helpers for the SM3 HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/sm3_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct bf16_t {
+    uint16_t v;
+};
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+
+// round-to-nearest-even; NaN stays NaN (plain cast lowers to v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, h);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+template <typename T>
+struct ElemTraits;
+template <>
+struct ElemTraits<float> {
+    static constexpr int kPer16B = 4;
+    __device__ static __forceinline__ float load(const float* p) { return *p; }
+    __device__ static __forceinline__ float round(float v) { return v; }
+};
+template <>
+struct ElemTraits<bf16_t> {
+    static constexpr int kPer16B = 8;
+    __device__ static __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(p->v); }
+    __device__ static __forceinline__ float round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+};
+
+// 16 bytes of T -> floats
+template <typename T>
+__device__ __forceinline__ void unpack16(const uint4& u, float* f);
+template <>
+__device__ __forceinline__ void unpack16<float>(const uint4& u, float* f) {
+    f[0] = __uint_as_float(u.x);
+    f[1] = __uint_as_float(u.y);
+    f[2] = __uint_as_float(u.z);
+    f[3] = __uint_as_float(u.w);
+}
+template <>
+__device__ __forceinline__ void unpack16<bf16_t>(const uint4& u, float* f) {
+    f[0] = __uint_as_float(u.x << 16);
+    f[1] = __uint_as_float(u.x & 0xffff0000u);
+    f[2] = __uint_as_float(u.y << 16);
+    f[3] = __uint_as_float(u.y & 0xffff0000u);
+    f[4] = __uint_as_float(u.z << 16);
+    f[5] = __uint_as_float(u.z & 0xffff0000u);
+    f[6] = __uint_as_float(u.w << 16);
+    f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+template <typename T>
+__device__ __forceinline__ uint4 pack16(const float* f);
+template <>
+__device__ __forceinline__ uint4 pack16<float>(const float* f) {
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+}
+template <>
+__device__ __forceinline__ uint4 pack16<bf16_t>(const float* f) {
+    return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
+                      pack_bf16x2(f[6], f[7]));
+}
+
+// n / d for 0 <= n < 2^31 with a precomputed multiplier (host: make_fastdiv)
+struct FastDiv {
+    uint32_t mul, shr, d;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    if (d <= 1) {
+        f.mul = 0;
+        f.shr = 0;
+        return f;
+    }
+    uint32_t l = 0;
+    while ((1u << l) < d) ++l;
+    uint32_t p = 31 + l;
+    uint64_t m = ((1ull << p) + d - 1) / d;
+    f.mul = (uint32_t)m;
+    f.shr = p - 32;
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+    return f.d <= 1 ? n : (__umulhi(n, f.mul) >> f.shr);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+#define SM3_CHECK_LAUNCH()                          \
+    do {                                            \
+        hipError_t e_ = hipGetLastError();          \
+        if (e_ != hipSuccess) return (int)e_;       \
+    } while (0)

@@ -1,0 +1,347 @@
+// Stem im2col, max / average pooling (NHWC), weight layout preparation, casts.  HBM-bound
+// helpers around the MFMA kernels: 16-byte vector accesses along the channel axis.
+//
+// Reference call sites replaced: stem nn.Conv2d(3,64,7,2,3) input gather (src/models/resnet.py:208-210,294),
+// nn.MaxPool2d(3,2,1) (:213,297), nn.AdaptiveAvgPool2d(1)+flatten (:224,304-305) and their autograd.
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ void store_elem(T* p, float v);
+template <>
+__device__ __forceinline__ void store_elem<float>(float* p, float v) { *p = v; }
+template <>
+__device__ __forceinline__ void store_elem<bf16_t>(bf16_t* p, float v) { p->v = f32_to_bf16(v); }
+
+// cols[m][k], m = (n, oy, ox), k = (kh*7 + kw)*3 + c ; one thread per 16-byte chunk of a row
+template <typename T>
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ x, T* __restrict__ cols, int N,
+                                                          int H, int W, int Ho, int Wo, int Kpad) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    const int cpr = Kpad / E;
+    const int64_t total = (int64_t)N * Ho * Wo * cpr;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % cpr);
+        const int64_t m = idx / cpr;
+        const int ox = (int)(m % Wo);
+        const int oy = (int)((m / Wo) % Ho);
+        const int n = (int)(m / ((int64_t)Wo * Ho));
+        float v[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int k = ch * E + e;
+            float val = 0.f;
+            if (k < 147) {
+                const int tap = k / 3, c = k - tap * 3;
+                const int kh = tap / 7, kw = tap - kh * 7;
+                const int iy = oy * 2 - 3 + kh, ix = ox * 2 - 3 + kw;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                    val = x[(((int64_t)n * 3 + c) * H + iy) * W + ix];
+            }
+            v[e] = val;
+        }
+        *reinterpret_cast<uint4*>(cols + m * Kpad + (int64_t)ch * E) = pack16<T>(v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H,
+                                                          int W, int C, int Ho, int Wo) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    const int cv = C / E;
+    const int64_t total = (int64_t)N * Ho * Wo * cv;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cv);
+        const int64_t pix = idx / cv;
+        const int ox = (int)(pix % Wo);
+        const int oy = (int)((pix / Wo) % Ho);
+        const int n = (int)(pix / ((int64_t)Wo * Ho));
+        float best[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) best[e] = -INFINITY;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int iy = oy * 2 - 1 + kh;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ix = ox * 2 - 1 + kw;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                float v[E];
+                unpack16<T>(*reinterpret_cast<const uint4*>(x + (((int64_t)n * H + iy) * W + ix) * C + (int64_t)c * E), v);
+#pragma unroll
+                for (int e = 0; e < E; ++e) best[e] = fmaxf(best[e], v[e]);
+            }
+        }
+        *reinterpret_cast<uint4*>(y + pix * C + (int64_t)c * E) = pack16<T>(best);
+    }
+}
+
+// gather form of the backward: input pixel (iy,ix) receives dy of every window whose FIRST maximum
+// (scan order kh, then kw, strict '>' as ATen) sits on it.  No atomics, deterministic.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                          T* __restrict__ dx, int N, int H, int W, int C, int Ho,
+                                                          int Wo) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    const int cv = C / E;
+    const int64_t total = (int64_t)N * H * W * cv;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cv);
+        const int64_t pix = idx / cv;
+        const int ix = (int)(pix % W);
+        const int iy = (int)((pix / W) % H);
+        const int n = (int)(pix / ((int64_t)W * H));
+        float g[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) g[e] = 0.f;
+        const int oy_lo = max(0, (iy) / 2), oy_hi = min(Ho - 1, (iy + 1) / 2);
+        const int ox_lo = max(0, (ix) / 2), ox_hi = min(Wo - 1, (ix + 1) / 2);
+        for (int oy = oy_lo; oy <= oy_hi; ++oy)
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                float best[E];
+                int arg[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    best[e] = -INFINITY;
+                    arg[e] = -1;
+                }
+                int self = -2;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int yy = oy * 2 - 1 + kh;
+                    if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int xx = ox * 2 - 1 + kw;
+                        if ((unsigned)xx >= (unsigned)W) continue;
+                        const int pos = kh * 3 + kw;
+                        if (yy == iy && xx == ix) self = pos;
+                        float v[E];
+                        unpack16<T>(*reinterpret_cast<const uint4*>(x + (((int64_t)n * H + yy) * W + xx) * C + (int64_t)c * E), v);
+#pragma unroll
+                        for (int e = 0; e < E; ++e)
+                            if (v[e] > best[e] || arg[e] < 0) {
+                                best[e] = v[e];
+                                arg[e] = pos;
+                            }
+                    }
+                }
+                float d[E];
+                unpack16<T>(*reinterpret_cast<const uint4*>(dy + (((int64_t)n * Ho + oy) * Wo + ox) * C + (int64_t)c * E), d);
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if (arg[e] == self) g[e] += d[e];
+            }
+        *reinterpret_cast<uint4*>(dx + pix * C + (int64_t)c * E) = pack16<T>(g);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ x, float* __restrict__ f32,
+                                                          T* __restrict__ ft, int N, int HW, int C) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    const int cv = C / E;
+    const int64_t total = (int64_t)N * cv;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % cv);
+    const int n = (int)(idx / cv);
+    float s[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) s[e] = 0.f;
+    for (int i = 0; i < HW; ++i) {
+        float v[E];
+        unpack16<T>(*reinterpret_cast<const uint4*>(x + ((int64_t)n * HW + i) * C + (int64_t)c * E), v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) s[e] += v[e];
+    }
+    const float inv = 1.f / (float)HW;
+#pragma unroll
+    for (int e = 0; e < E; ++e) s[e] *= inv;
+    if (f32) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) f32[(int64_t)n * C + (int64_t)c * E + e] = s[e];
+    }
+    if (ft) *reinterpret_cast<uint4*>(ft + (int64_t)n * C + (int64_t)c * E) = pack16<T>(s);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ df, T* __restrict__ dx, int N, int HW,
+                                                          int C) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    const int cv = C / E;
+    const int64_t total = (int64_t)N * HW * cv;
+    const float inv = 1.f / (float)HW;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cv);
+        const int64_t pix = idx / cv;
+        const int n = (int)(pix / HW);
+        float v[E];
+        unpack16<T>(*reinterpret_cast<const uint4*>(df + (int64_t)n * C + (int64_t)c * E), v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] *= inv;
+        *reinterpret_cast<uint4*>(dx + pix * C + (int64_t)c * E) = pack16<T>(v);
+    }
+}
+
+template <typename T>
+__global__ void weight_prep_kernel(const float* __restrict__ w, int Co, int taps, int Ci, T* __restrict__ wf, int ld,
+                                   T* __restrict__ wd) {
+    const int64_t nf = wf ? (int64_t)Co * ld : 0;
+    const int64_t nd = wd ? (int64_t)Co * taps * Ci : 0;
+    const int K = taps * Ci;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nf + nd;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        if (idx < nf) {
+            const int co = (int)(idx / ld), k = (int)(idx % ld);
+            store_elem<T>(wf + idx, k < K ? w[(int64_t)co * K + k] : 0.f);
+        } else {
+            // wd[ci][t][co] = w[co][t][ci]
+            const int64_t j = idx - nf;
+            const int co = (int)(j % Co);
+            const int t = (int)((j / Co) % taps);
+            const int ci = (int)(j / ((int64_t)Co * taps));
+            store_elem<T>(wd + j, w[((int64_t)co * taps + t) * Ci + ci]);
+        }
+    }
+}
+
+template <typename T>
+__global__ void cast_from_f32_kernel(const float* __restrict__ s, T* __restrict__ d, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        store_elem<T>(d + i, s[i]);
+}
+template <typename T>
+__global__ void cast_to_f32_kernel(const T* __restrict__ s, float* __restrict__ d, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        d[i] = ElemTraits<T>::load(s + i);
+}
+
+inline unsigned grid_for(int64_t total, int per_block = 256, int64_t cap = 8192) {
+    int64_t g = (total + per_block - 1) / per_block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16)  \
+    if ((dtype) == SM3_F32) { CALL_F32; }       \
+    else if ((dtype) == SM3_BF16) { CALL_BF16; } \
+    else return SM3_EDTYPE;
+
+extern "C" int sm3_stem_im2col(int dtype, const float* x_nchw, void* cols, int N, int H, int W, int Kpad,
+                               void* stream) {
+    if (!x_nchw || !cols || N <= 0 || H <= 0 || W <= 0 || Kpad < 147) return SM3_EINVAL;
+    const int E = dtype == SM3_F32 ? 4 : 8;
+    if (Kpad % E) return SM3_EALIGN;
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    const int64_t total = (int64_t)N * Ho * Wo * (Kpad / E);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned g = grid_for(total, 256, 1 << 20);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(g), dim3(256), 0, st, x_nchw, (float*)cols, N, H, W, Ho, Wo, Kpad),
+               hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, dim3(g), dim3(256), 0, st, x_nchw, (bf16_t*)cols, N, H, W, Ho, Wo, Kpad));
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_maxpool3x3s2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream) {
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) return SM3_EINVAL;
+    const int E = dtype == SM3_F32 ? 4 : 8;
+    if (C % E) return SM3_EALIGN;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const unsigned g = grid_for((int64_t)N * Ho * Wo * (C / E), 256, 1 << 20);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, (float*)y, N, H, W, C, Ho, Wo),
+               hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, Ho, Wo));
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_maxpool3x3s2_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int C,
+                                    void* stream) {
+    if (!x || !dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0) return SM3_EINVAL;
+    const int E = dtype == SM3_F32 ? 4 : 8;
+    if (C % E) return SM3_EALIGN;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const unsigned g = grid_for((int64_t)N * H * W * (C / E), 256, 1 << 20);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, (const float*)dy, (float*)dx, N, H, W, C, Ho, Wo),
+               hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo));
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_avgpool_fwd(int dtype, const void* x, float* feat_f32, void* feat_t, int N, int HW, int C,
+                               void* stream) {
+    if (!x || N <= 0 || HW <= 0 || C <= 0 || (!feat_f32 && !feat_t)) return SM3_EINVAL;
+    const int E = dtype == SM3_F32 ? 4 : 8;
+    if (C % E) return SM3_EALIGN;
+    const int64_t total = (int64_t)N * (C / E);
+    const unsigned g = (unsigned)((total + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(avgpool_fwd_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, feat_f32, (float*)feat_t, N, HW, C),
+               hipLaunchKernelGGL(avgpool_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, feat_f32, (bf16_t*)feat_t, N, HW, C));
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_avgpool_bwd(int dtype, const void* dfeat, void* dx, int N, int HW, int C, void* stream) {
+    if (!dfeat || !dx || N <= 0 || HW <= 0 || C <= 0) return SM3_EINVAL;
+    const int E = dtype == SM3_F32 ? 4 : 8;
+    if (C % E) return SM3_EALIGN;
+    const unsigned g = grid_for((int64_t)N * HW * (C / E));
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)dfeat, (float*)dx, N, HW, C),
+               hipLaunchKernelGGL(avgpool_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)dfeat, (bf16_t*)dx, N, HW, C));
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_weight_prep(int dtype, const float* w, int Co, int taps, int Ci, void* w_fwd, int ld_fwd,
+                               void* w_dgrad, void* stream) {
+    if (!w || Co <= 0 || taps <= 0 || Ci <= 0 || (!w_fwd && !w_dgrad)) return SM3_EINVAL;
+    if (w_fwd && ld_fwd < taps * Ci) return SM3_EINVAL;
+    const int64_t total = (w_fwd ? (int64_t)Co * ld_fwd : 0) + (w_dgrad ? (int64_t)Co * taps * Ci : 0);
+    const unsigned g = grid_for(total);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(weight_prep_kernel<float>, dim3(g), dim3(256), 0, st, w, Co, taps, Ci, (float*)w_fwd, ld_fwd, (float*)w_dgrad),
+               hipLaunchKernelGGL(weight_prep_kernel<bf16_t>, dim3(g), dim3(256), 0, st, w, Co, taps, Ci, (bf16_t*)w_fwd, ld_fwd, (bf16_t*)w_dgrad));
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_cast_from_f32(int dtype, const float* src, void* dst, int64_t n, void* stream) {
+    if (!src || !dst || n <= 0) return SM3_EINVAL;
+    const unsigned g = grid_for(n);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(cast_from_f32_kernel<float>, dim3(g), dim3(256), 0, st, src, (float*)dst, n),
+               hipLaunchKernelGGL(cast_from_f32_kernel<bf16_t>, dim3(g), dim3(256), 0, st, src, (bf16_t*)dst, n));
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, void* stream) {
+    if (!src || !dst || n <= 0) return SM3_EINVAL;
+    const unsigned g = grid_for(n);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(cast_to_f32_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)src, dst, n),
+               hipLaunchKernelGGL(cast_to_f32_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)src, dst, n));
+    SM3_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,94 @@
+"""ctypes binding of libsm3hip.so (C ABI in include/sm3_hip.h).
+
+The product path has no CPU fallback: importing this module without the built library raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsm3hip.so")
+
+SM3_F32, SM3_BF16 = 0, 1
+MAX_TAPS = 9
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32),
+        ("N", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("Ci", C.c_int32),
+        ("Ho", C.c_int32), ("Wo", C.c_int32), ("Co", C.c_int32),
+        ("sy", C.c_int32), ("sx", C.c_int32),
+        ("ntaps", C.c_int32),
+        ("dy", C.c_int32 * MAX_TAPS), ("dx", C.c_int32 * MAX_TAPS), ("wtap", C.c_int32 * MAX_TAPS),
+        ("w_row_stride", C.c_int32),
+        ("Hout", C.c_int32), ("Wout", C.c_int32),
+        ("osy", C.c_int32), ("osx", C.c_int32), ("ooy", C.c_int32), ("oox", C.c_int32),
+    ]
+
+
+_P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+_DESC = C.POINTER(ConvDesc)
+
+# name -> argtypes ; every function returns int.  Must list every symbol include/sm3_hip.h declares
+# (tests/test_abi.py checks both directions).
+SIGNATURES = {
+    "sm3_abi_version": [],
+    "sm3_conv_partial_rows": [_DESC],
+    "sm3_conv_gather_gemm": [_DESC, _P, _P, _P, _P, _P, _P],
+    "sm3_conv_wgrad": [_DESC, _P, _P, _P, _P],
+    "sm3_bn_stats_reduce": [_P, _I, _I, _P, _P],
+    "sm3_bn_finalize": [_P, _D, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
+    "sm3_bn_eval_scale_shift": [_P, _P, _P, _P, _F, _I, _P, _P, _P],
+    "sm3_bn_act": [_I, _P, _P, _P, _P, _I, _I, _P, _L, _I, _P],
+    "sm3_bn_bwd_partial_rows": [_L, _I],
+    "sm3_bn_bwd_reduce": [_I, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P],
+    "sm3_bn_bwd_apply": [_I, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _P, _L, _I, _P],
+    "sm3_stem_im2col": [_I, _P, _P, _I, _I, _I, _I, _P],
+    "sm3_maxpool3x3s2_fwd": [_I, _P, _P, _I, _I, _I, _I, _P],
+    "sm3_maxpool3x3s2_bwd": [_I, _P, _P, _P, _I, _I, _I, _I, _P],
+    "sm3_avgpool_fwd": [_I, _P, _P, _P, _I, _I, _I, _P],
+    "sm3_avgpool_bwd": [_I, _P, _P, _I, _I, _I, _P],
+    "sm3_weight_prep": [_I, _P, _I, _I, _I, _P, _I, _P, _P],
+    "sm3_cast_from_f32": [_I, _P, _P, _L, _P],
+    "sm3_cast_to_f32": [_I, _P, _P, _L, _P],
+    "sm3_ntxent_logits": [_P, _I, _I, _F, _P, _P, _P, _P],
+    "sm3_ntxent_logits_bwd": [_I, _P, _P, _P, _I, _I, _F, _P, _P],
+    "sm3_ce_label0": [_P, _I, _I, _F, _P, _P, _P],
+    "sm3_ntxent_fused": [_I, _P, _I, _I, _F, _F, _P, _P, _P, _P],
+    "sm3_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P, _P],
+    "sm3_check_finite": [_P, _L, _P, _P],
+}
+
+_lib = None
+
+
+class SM3LibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libsm3hip.so; raise (never fall back) when it is missing or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SM3LibraryError(
+            f"{LIB_PATH} not found: build it with `make -C skin-sm3_amd/csrc` (or __graft_entry__.build()). "
+            "The SM3 HIP path has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise SM3LibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "SM3_EINVAL", -2: "SM3_EALIGN", -3: "SM3_EDTYPE"}.get(rc, f"hipError {rc}")
+        raise SM3LibraryError(f"{what} failed: {kind}")

@@ -1,0 +1,336 @@
+"""Tensor-level wrappers over the C ABI (include/sm3_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every kernel is ours.  Each wrapper
+checks on the host that shapes/dtypes/devices match what the kernel's grid assumes before launching.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, SM3_BF16, SM3_F32, check
+
+TORCH_DTYPE = {SM3_F32: torch.float32, SM3_BF16: torch.bfloat16}
+K_CHUNK = {SM3_F32: 32, SM3_BF16: 64}  # elements per 128-byte K chunk
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype=None, name="tensor"):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on the GPU (the SM3 HIP path has no CPU fallback)")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def dtype_code(torch_dtype):
+    if torch_dtype == torch.float32:
+        return SM3_F32
+    if torch_dtype == torch.bfloat16:
+        return SM3_BF16
+    raise ValueError(f"unsupported activation dtype {torch_dtype}")
+
+
+# ------------------------------------------------------------------------------------------
+# conv descriptors
+# ------------------------------------------------------------------------------------------
+def make_desc(dtype, N, Hi, Wi, Ci, Ho, Wo, Co, sy, sx, taps, w_row_stride, Hout=None, Wout=None,
+              osy=1, osx=1, ooy=0, oox=0):
+    """taps: list of (dy, dx, wtap)."""
+    d = ConvDesc()
+    d.dtype = dtype
+    d.N, d.Hi, d.Wi, d.Ci = N, Hi, Wi, Ci
+    d.Ho, d.Wo, d.Co = Ho, Wo, Co
+    d.sy, d.sx = sy, sx
+    d.ntaps = len(taps)
+    if not 1 <= len(taps) <= _lib.MAX_TAPS:
+        raise ValueError("1..9 taps")
+    for i, (dy, dx, wt) in enumerate(taps):
+        d.dy[i], d.dx[i], d.wtap[i] = dy, dx, wt
+    d.w_row_stride = w_row_stride
+    d.Hout = Ho if Hout is None else Hout
+    d.Wout = Wo if Wout is None else Wout
+    d.osy, d.osx, d.ooy, d.oox = osy, osx, ooy, oox
+    return d
+
+
+def fwd_desc(dtype, N, Hi, Wi, Ci, Co, k, stride, pad):
+    """Forward conv k x k / stride / pad over NHWC x with OHWI weights [Co][k*k][Ci]."""
+    Ho = (Hi + 2 * pad - k) // stride + 1
+    Wo = (Wi + 2 * pad - k) // stride + 1
+    taps = [(kh - pad, kw - pad, kh * k + kw) for kh in range(k) for kw in range(k)]
+    return make_desc(dtype, N, Hi, Wi, Ci, Ho, Wo, Co, stride, stride, taps, k * k * Ci)
+
+
+def dgrad_descs(dtype, N, Hi, Wi, Ci, Co, k, stride, pad):
+    """Data gradient of fwd_desc(...) as gather-GEMMs over dY [N,Ho,Wo,Co] with the transposed filter
+    bank w_dgrad [Ci][k*k][Co]: one descriptor per output-parity class (stride^2 of them), each with
+    only the taps that hit real dY pixels.  Returns (descs, covers_everything)."""
+    Ho = (Hi + 2 * pad - k) // stride + 1
+    Wo = (Wi + 2 * pad - k) // stride + 1
+    descs, full = [], True
+    for py in range(stride):
+        for px in range(stride):
+            Hq = (Hi - py + stride - 1) // stride
+            Wq = (Wi - px + stride - 1) // stride
+            if Hq <= 0 or Wq <= 0:
+                continue
+            taps = [((py + pad - kh) // stride, (px + pad - kw) // stride, kh * k + kw)
+                    for kh in range(k) for kw in range(k)
+                    if (py + pad - kh) % stride == 0 and (px + pad - kw) % stride == 0]
+            if not taps:
+                full = False
+                continue
+            descs.append(make_desc(dtype, N, Ho, Wo, Co, Hq, Wq, Ci, 1, 1, taps, k * k * Co,
+                                   Hout=Hi, Wout=Wi, osy=stride, osx=stride, ooy=py, oox=px))
+    return descs, full
+
+
+def conv_partial_rows(desc):
+    return _lib.load().sm3_conv_partial_rows(C.byref(desc))
+
+
+def conv_gemm(desc, x, w, y, addend=None, partials=None):
+    tdt = TORCH_DTYPE[desc.dtype]
+    _chk(x, tdt, "x"); _chk(w, tdt, "w"); _chk(y, tdt, "y"); _chk(addend, tdt, "addend")
+    _chk(partials, torch.float32, "partials")
+    if x.numel() != desc.N * desc.Hi * desc.Wi * desc.Ci:
+        raise ValueError(f"x has {x.numel()} elements, descriptor says {desc.N}x{desc.Hi}x{desc.Wi}x{desc.Ci}")
+    if y.numel() != desc.N * desc.Hout * desc.Wout * desc.Co:
+        raise ValueError("y size does not match descriptor")
+    if addend is not None and addend.numel() != y.numel():
+        raise ValueError("addend size does not match y")
+    need_w = (desc.Co - 1) * desc.w_row_stride + max(desc.wtap[i] for i in range(desc.ntaps)) * desc.Ci + desc.Ci
+    if w.numel() < need_w:
+        raise ValueError("w too small for descriptor")
+    if desc.Ci % K_CHUNK[desc.dtype]:
+        raise ValueError(f"Ci={desc.Ci} is not a multiple of {K_CHUNK[desc.dtype]}")
+    if partials is not None and partials.numel() < conv_partial_rows(desc) * 2 * desc.Co:
+        raise ValueError("partials workspace too small")
+    check(_lib.load().sm3_conv_gather_gemm(C.byref(desc), _ptr(x), _ptr(w), _ptr(y), _ptr(addend), _ptr(partials),
+                                           _stream()), "sm3_conv_gather_gemm")
+
+
+def conv_wgrad(desc, x, dy, dw):
+    tdt = TORCH_DTYPE[desc.dtype]
+    _chk(x, tdt, "x"); _chk(dy, tdt, "dy"); _chk(dw, torch.float32, "dw")
+    if x.numel() != desc.N * desc.Hi * desc.Wi * desc.Ci:
+        raise ValueError("x size does not match descriptor")
+    if dy.numel() != desc.N * desc.Ho * desc.Wo * desc.Co:
+        raise ValueError("dy size does not match descriptor")
+    if dw.numel() < desc.Co * desc.w_row_stride:
+        raise ValueError("dw too small")
+    check(_lib.load().sm3_conv_wgrad(C.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _stream()), "sm3_conv_wgrad")
+
+
+# ------------------------------------------------------------------------------------------
+# batch norm
+# ------------------------------------------------------------------------------------------
+def bn_stats_reduce(partials, rows, Cn, sums):
+    _chk(partials, torch.float32, "partials"); _chk(sums, torch.float64, "sums")
+    if partials.numel() < rows * 2 * Cn or sums.numel() < 2 * Cn:
+        raise ValueError("bn_stats_reduce: buffer too small")
+    check(_lib.load().sm3_bn_stats_reduce(_ptr(partials), rows, Cn, _ptr(sums), _stream()), "sm3_bn_stats_reduce")
+
+
+def bn_finalize(sums, count, Cn, gamma, beta, eps, momentum, running_mean, running_var, nbt, scale, shift,
+                save_mean, save_invstd):
+    for t, n in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var"),
+                 (scale, "scale"), (shift, "shift"), (save_mean, "save_mean"), (save_invstd, "save_invstd")):
+        _chk(t, torch.float32, n)
+        if t is not None and t.numel() < Cn:
+            raise ValueError(f"{n} too small")
+    _chk(sums, torch.float64, "sums"); _chk(nbt, torch.int64, "num_batches_tracked")
+    check(_lib.load().sm3_bn_finalize(_ptr(sums), float(count), Cn, _ptr(gamma), _ptr(beta), eps, momentum,
+                                      _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(scale), _ptr(shift),
+                                      _ptr(save_mean), _ptr(save_invstd), _stream()), "sm3_bn_finalize")
+
+
+def bn_eval_scale_shift(gamma, beta, running_mean, running_var, eps, Cn, scale, shift):
+    for t in (gamma, beta, running_mean, running_var, scale, shift):
+        _chk(t, torch.float32)
+    check(_lib.load().sm3_bn_eval_scale_shift(_ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), eps,
+                                              Cn, _ptr(scale), _ptr(shift), _stream()), "sm3_bn_eval_scale_shift")
+
+
+def bn_act(dtype, x, scale, shift, residual, relu, y, rows, Cn, out_f32=False):
+    tdt = TORCH_DTYPE[dtype]
+    _chk(x, tdt, "x"); _chk(residual, tdt, "residual"); _chk(scale, torch.float32); _chk(shift, torch.float32)
+    _chk(y, torch.float32 if out_f32 else tdt, "y")
+    if x.numel() != rows * Cn or y.numel() != rows * Cn or (residual is not None and residual.numel() != rows * Cn):
+        raise ValueError("bn_act: size mismatch")
+    check(_lib.load().sm3_bn_act(dtype, _ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), int(relu), int(out_f32),
+                                 _ptr(y), rows, Cn, _stream()), "sm3_bn_act")
+
+
+def bn_bwd_partial_rows(rows, Cn):
+    return _lib.load().sm3_bn_bwd_partial_rows(rows, Cn)
+
+
+def bn_bwd_reduce(dtype, dy, y, x, mean, invstd, dz, rows, Cn, partials):
+    tdt = TORCH_DTYPE[dtype]
+    for t, n in ((dy, "dy"), (y, "y"), (x, "x"), (dz, "dz")):
+        _chk(t, tdt, n)
+        if t is not None and t.numel() != rows * Cn:
+            raise ValueError(f"bn_bwd_reduce: {n} size mismatch")
+    _chk(partials, torch.float32)
+    if partials.numel() < bn_bwd_partial_rows(rows, Cn) * 2 * Cn:
+        raise ValueError("bn_bwd_reduce: partials too small")
+    check(_lib.load().sm3_bn_bwd_reduce(dtype, _ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(dz), rows,
+                                        Cn, _ptr(partials), _stream()), "sm3_bn_bwd_reduce")
+
+
+def bn_bwd_apply(dtype, dz, x, mean, invstd, gamma, gsums, count, lsums, dgamma, dbeta, dx, rows, Cn):
+    tdt = TORCH_DTYPE[dtype]
+    for t, n in ((dz, "dz"), (x, "x"), (dx, "dx")):
+        _chk(t, tdt, n)
+        if t.numel() != rows * Cn:
+            raise ValueError(f"bn_bwd_apply: {n} size mismatch")
+    _chk(gsums, torch.float64); _chk(lsums, torch.float64)
+    _chk(dgamma, torch.float32); _chk(dbeta, torch.float32); _chk(gamma, torch.float32)
+    check(_lib.load().sm3_bn_bwd_apply(dtype, _ptr(dz), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(gsums),
+                                       float(count), _ptr(lsums), _ptr(dgamma), _ptr(dbeta), _ptr(dx), rows, Cn,
+                                       _stream()), "sm3_bn_bwd_apply")
+
+
+# ------------------------------------------------------------------------------------------
+# stem / pooling / weights
+# ------------------------------------------------------------------------------------------
+def stem_im2col(dtype, x_nchw, cols, Kpad):
+    _chk(x_nchw, torch.float32, "x"); _chk(cols, TORCH_DTYPE[dtype], "cols")
+    N, Cc, H, W = x_nchw.shape
+    if Cc != 3:
+        raise ValueError("stem expects 3 input channels")
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if cols.numel() != N * Ho * Wo * Kpad:
+        raise ValueError("cols size mismatch")
+    check(_lib.load().sm3_stem_im2col(dtype, _ptr(x_nchw), _ptr(cols), N, H, W, Kpad, _stream()), "sm3_stem_im2col")
+
+
+def maxpool_fwd(dtype, x, y, N, H, W, Cn):
+    _chk(x, TORCH_DTYPE[dtype]); _chk(y, TORCH_DTYPE[dtype])
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if x.numel() != N * H * W * Cn or y.numel() != N * Ho * Wo * Cn:
+        raise ValueError("maxpool_fwd: size mismatch")
+    check(_lib.load().sm3_maxpool3x3s2_fwd(dtype, _ptr(x), _ptr(y), N, H, W, Cn, _stream()), "sm3_maxpool3x3s2_fwd")
+
+
+def maxpool_bwd(dtype, x, dy, dx, N, H, W, Cn):
+    for t in (x, dy, dx):
+        _chk(t, TORCH_DTYPE[dtype])
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if x.numel() != N * H * W * Cn or dx.numel() != x.numel() or dy.numel() != N * Ho * Wo * Cn:
+        raise ValueError("maxpool_bwd: size mismatch")
+    check(_lib.load().sm3_maxpool3x3s2_bwd(dtype, _ptr(x), _ptr(dy), _ptr(dx), N, H, W, Cn, _stream()),
+          "sm3_maxpool3x3s2_bwd")
+
+
+def avgpool_fwd(dtype, x, feat_f32, feat_t, N, HW, Cn):
+    _chk(x, TORCH_DTYPE[dtype]); _chk(feat_f32, torch.float32); _chk(feat_t, TORCH_DTYPE[dtype])
+    if x.numel() != N * HW * Cn:
+        raise ValueError("avgpool_fwd: size mismatch")
+    for t in (feat_f32, feat_t):
+        if t is not None and t.numel() != N * Cn:
+            raise ValueError("avgpool_fwd: feature size mismatch")
+    check(_lib.load().sm3_avgpool_fwd(dtype, _ptr(x), _ptr(feat_f32), _ptr(feat_t), N, HW, Cn, _stream()),
+          "sm3_avgpool_fwd")
+
+
+def avgpool_bwd(dtype, dfeat, dx, N, HW, Cn):
+    _chk(dfeat, TORCH_DTYPE[dtype]); _chk(dx, TORCH_DTYPE[dtype])
+    if dfeat.numel() != N * Cn or dx.numel() != N * HW * Cn:
+        raise ValueError("avgpool_bwd: size mismatch")
+    check(_lib.load().sm3_avgpool_bwd(dtype, _ptr(dfeat), _ptr(dx), N, HW, Cn, _stream()), "sm3_avgpool_bwd")
+
+
+def weight_prep(dtype, w, Co, taps, Ci, w_fwd, ld_fwd, w_dgrad):
+    _chk(w, torch.float32, "w"); _chk(w_fwd, TORCH_DTYPE[dtype]); _chk(w_dgrad, TORCH_DTYPE[dtype])
+    if w.numel() != Co * taps * Ci:
+        raise ValueError("weight_prep: master size mismatch")
+    if w_fwd is not None and w_fwd.numel() != Co * ld_fwd:
+        raise ValueError("weight_prep: w_fwd size mismatch")
+    if w_dgrad is not None and w_dgrad.numel() != Co * taps * Ci:
+        raise ValueError("weight_prep: w_dgrad size mismatch")
+    check(_lib.load().sm3_weight_prep(dtype, _ptr(w), Co, taps, Ci, _ptr(w_fwd), ld_fwd, _ptr(w_dgrad), _stream()),
+          "sm3_weight_prep")
+
+
+def cast_from_f32(dtype, src, dst):
+    _chk(src, torch.float32); _chk(dst, TORCH_DTYPE[dtype])
+    if src.numel() != dst.numel():
+        raise ValueError("cast: size mismatch")
+    check(_lib.load().sm3_cast_from_f32(dtype, _ptr(src), _ptr(dst), src.numel(), _stream()), "sm3_cast_from_f32")
+
+
+def cast_to_f32(dtype, src, dst):
+    _chk(src, TORCH_DTYPE[dtype]); _chk(dst, torch.float32)
+    if src.numel() != dst.numel():
+        raise ValueError("cast: size mismatch")
+    check(_lib.load().sm3_cast_to_f32(dtype, _ptr(src), _ptr(dst), src.numel(), _stream()), "sm3_cast_to_f32")
+
+
+# ------------------------------------------------------------------------------------------
+# NT-Xent
+# ------------------------------------------------------------------------------------------
+def ntxent_logits(z, temperature, zn, inv_norm, logits):
+    for t in (z, zn, inv_norm, logits):
+        _chk(t, torch.float32)
+    R, D = z.shape
+    if zn.numel() != R * D or inv_norm.numel() != R or logits.numel() != R * (R - 1):
+        raise ValueError("ntxent_logits: size mismatch")
+    check(_lib.load().sm3_ntxent_logits(_ptr(z), R, D, temperature, _ptr(zn), _ptr(inv_norm), _ptr(logits), _stream()),
+          "sm3_ntxent_logits")
+
+
+def ntxent_logits_bwd(dtype, dlogits, zn, inv_norm, temperature, dz):
+    _chk(dlogits, torch.float32); _chk(zn, torch.float32); _chk(inv_norm, torch.float32); _chk(dz, TORCH_DTYPE[dtype])
+    R, D = zn.shape
+    if dlogits.numel() != R * (R - 1) or dz.numel() != R * D:
+        raise ValueError("ntxent_logits_bwd: size mismatch")
+    check(_lib.load().sm3_ntxent_logits_bwd(dtype, _ptr(dlogits), _ptr(zn), _ptr(inv_norm), R, D, temperature, _ptr(dz),
+                                            _stream()), "sm3_ntxent_logits_bwd")
+
+
+def ce_label0(logits, weight, loss, dlogits):
+    _chk(logits, torch.float32); _chk(loss, torch.float32); _chk(dlogits, torch.float32)
+    R, Cc = logits.shape
+    if dlogits is not None and dlogits.numel() != logits.numel():
+        raise ValueError("ce_label0: size mismatch")
+    check(_lib.load().sm3_ce_label0(_ptr(logits), R, Cc, weight, _ptr(loss), _ptr(dlogits), _stream()), "sm3_ce_label0")
+
+
+def ntxent_fused(dtype, z, temperature, weight, workspace, loss, dz):
+    _chk(z, torch.float32); _chk(workspace, torch.float32); _chk(loss, torch.float32); _chk(dz, TORCH_DTYPE[dtype])
+    R, D = z.shape
+    if workspace.numel() < R * D + 2 * R or dz.numel() != R * D:
+        raise ValueError("ntxent_fused: size mismatch")
+    check(_lib.load().sm3_ntxent_fused(dtype, _ptr(z), R, D, temperature, weight, _ptr(workspace), _ptr(loss), _ptr(dz),
+                                       _stream()), "sm3_ntxent_fused")
+
+
+# ------------------------------------------------------------------------------------------
+# optimizer
+# ------------------------------------------------------------------------------------------
+def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, found_inf=None):
+    for t in (p, g, m, v):
+        _chk(t, torch.float32)
+        if t.numel() != p.numel():
+            raise ValueError("adamw: size mismatch")
+    _chk(found_inf, torch.int32)
+    check(_lib.load().sm3_adamw(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay,
+                                step, grad_scale, _ptr(found_inf), _stream()), "sm3_adamw")
+
+
+def check_finite(g, found_inf):
+    _chk(g, torch.float32); _chk(found_inf, torch.int32)
+    check(_lib.load().sm3_check_finite(_ptr(g), g.numel(), _ptr(found_inf), _stream()), "sm3_check_finite")

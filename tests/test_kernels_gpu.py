@@ -1,0 +1,346 @@
+"""Kernel-level parity (GPU): every C-ABI entry point against a plain PyTorch CPU fp32/fp64 reference of
+the same op on the same seeded inputs.  bf16 cases feed the reference the bf16-rounded inputs, so only
+accumulation order and the final rounding differ."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _ops():
+    from sm3hip import ops
+    return ops
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def nhwc(x, dt):
+    return x.permute(0, 2, 3, 1).contiguous().to(dt).to(dev())
+
+
+def from_nhwc(y):
+    return y.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rnd(x, dt):
+    return x.to(dt).float()
+
+
+def tol(dt, scale):
+    return (2e-5 if dt == torch.float32 else 1.2e-2) * scale
+
+
+CONV_CASES = [
+    # N, Ci, Co, H, W, k, s, p
+    (2, 64, 64, 14, 14, 1, 1, 0),
+    (2, 64, 256, 9, 7, 1, 1, 0),
+    (3, 128, 128, 12, 10, 3, 1, 1),
+    (2, 64, 64, 13, 11, 3, 2, 1),
+    (2, 256, 512, 10, 10, 1, 2, 0),
+    (1, 512, 128, 7, 7, 1, 1, 0),
+    (5, 128, 192, 6, 6, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(case, dt):
+    ops = _ops()
+    N, Ci, Co, H, W, k, s, p = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) / math.sqrt(Ci * k * k)
+    code = ops.dtype_code(dt)
+    xr, wr = rnd(x, dt), rnd(w, dt)
+    ref = F.conv2d(xr.double(), wr.double(), stride=s, padding=p)
+    Ho, Wo = ref.shape[2:]
+
+    xd = nhwc(x, dt)
+    w_ohwi = w.permute(0, 2, 3, 1).contiguous()  # [Co][k][k][Ci]
+    wd = w_ohwi.to(dt).to(dev())
+    d = ops.fwd_desc(code, N, H, W, Ci, Co, k, s, p)
+    assert (d.Ho, d.Wo) == (Ho, Wo)
+    y = torch.empty(N, Ho, Wo, Co, dtype=dt, device=dev())
+    prow = ops.conv_partial_rows(d)
+    partials = torch.full((prow, 2, Co), float("nan"), device=dev())
+    ops.conv_gemm(d, xd, wd, y, None, partials)
+    torch.cuda.synchronize()
+    got = from_nhwc(y)
+    scale = ref.abs().max().item()
+    assert (got.double() - ref).abs().max().item() < tol(dt, scale)
+    # BN partial sums are sums of the stored values
+    yv = y.float().reshape(-1, Co).double()
+    ps = partials.double().sum(0).cpu()
+    assert torch.allclose(ps[0], yv.sum(0).cpu(), rtol=1e-4, atol=1e-3 * scale)
+    assert torch.allclose(ps[1], (yv * yv).sum(0).cpu(), rtol=1e-4, atol=1e-3 * scale * scale)
+
+    # ---- data gradient ----
+    dy = torch.randn(N, Co, Ho, Wo, generator=g)
+    dyr = rnd(dy, dt)
+    ref_dx = torch.nn.grad.conv2d_input((N, Ci, H, W), wr.double(), dyr.double(), stride=s, padding=p)
+    dyd = nhwc(dy, dt)
+    # transposed filter bank via the library's own weight_prep
+    w_master = w_ohwi.to(dev())
+    w_dg = torch.empty(Ci, k * k, Co, dtype=dt, device=dev())
+    w_f = torch.empty(Co, k * k * Ci, dtype=dt, device=dev())
+    ops.weight_prep(code, w_master, Co, k * k, Ci, w_f, k * k * Ci, w_dg)
+    torch.cuda.synchronize()
+    assert torch.equal(w_f.cpu().reshape(-1), wd.cpu().reshape(-1))
+    descs, full = ops.dgrad_descs(code, N, H, W, Ci, Co, k, s, p)
+    addend = torch.randn(N, H, W, Ci, generator=g).to(dt)
+    dx = addend.clone().to(dev()) if not full else torch.empty(N, H, W, Ci, dtype=dt, device=dev())
+    add_dev = addend.to(dev())
+    for dd in descs:
+        ops.conv_gemm(dd, dyd, w_dg, dx, dx if not full else add_dev, None)
+    torch.cuda.synchronize()
+    want = ref_dx + addend.float().permute(0, 3, 1, 2).double()
+    sc = want.abs().max().item()
+    assert (from_nhwc(dx).double() - want).abs().max().item() < tol(dt, sc) * 2
+
+    # ---- weight gradient (accumulates) ----
+    ref_dw = torch.nn.grad.conv2d_weight(xr.double(), (Co, Ci, k, k), dyr.double(), stride=s, padding=p)
+    dw = torch.ones(Co, k * k * Ci, device=dev())
+    ops.conv_wgrad(d, xd, dyd, dw)
+    torch.cuda.synchronize()
+    got_dw = (dw.cpu() - 1).reshape(Co, k, k, Ci).permute(0, 3, 1, 2)
+    sc = ref_dw.abs().max().item()
+    assert (got_dw.double() - ref_dw).abs().max().item() < tol(dt, sc) * 2
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+def test_linear_as_conv(dt):
+    ops = _ops()
+    code = ops.dtype_code(dt)
+    g = torch.Generator().manual_seed(5)
+    M, K, Nn = 24, 2048, 128
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(Nn, K, generator=g) / math.sqrt(K)
+    ref = rnd(x, dt).double() @ rnd(w, dt).double().t()
+    d = ops.fwd_desc(code, M, 1, 1, K, Nn, 1, 1, 0)
+    y = torch.empty(M, Nn, dtype=dt, device=dev())
+    ops.conv_gemm(d, x.to(dt).to(dev()), w.to(dt).to(dev()), y, None, None)
+    torch.cuda.synchronize()
+    assert (y.float().cpu().double() - ref).abs().max().item() < tol(dt, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2 * 9 * 9, 64), (300, 256), (7, 2048), (1000, 128)])
+def test_bn_train_forward_backward(shape, dt):
+    ops = _ops()
+    code = ops.dtype_code(dt)
+    rows, Cn = shape
+    g = torch.Generator().manual_seed(rows)
+    x = rnd(torch.randn(rows, Cn, generator=g) * 2 + 0.5, dt)
+    res = rnd(torch.randn(rows, Cn, generator=g), dt)
+    gamma = torch.rand(Cn, generator=g) + 0.5
+    beta = torch.randn(Cn, generator=g) * 0.1
+    rm, rv = torch.zeros(Cn), torch.ones(Cn)
+    xd64 = x.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rm64, rv64 = rm.double(), rv.double()
+    ref_bn = F.batch_norm(xd64, rm64, rv64, g64, b64, True, 0.1, 1e-5)
+    ref_y = F.relu(ref_bn + res.double())
+
+    # forward: partial sums (one row per 128-row block, as the conv epilogue would write) -> reduce -> finalize
+    D = dev()
+    xdv = x.to(dt).to(D)
+    nblk = (rows + 127) // 128
+    partials = torch.zeros(nblk, 2, Cn)
+    for b in range(nblk):
+        blk = x[b * 128:(b + 1) * 128].double()
+        partials[b, 0] = blk.sum(0).float()
+        partials[b, 1] = (blk * blk).sum(0).float()
+    partials = partials.to(D)
+    sums = torch.empty(2 * Cn, dtype=torch.float64, device=D)
+    ops.bn_stats_reduce(partials, nblk, Cn, sums)
+    scale, shift = torch.empty(Cn, device=D), torch.empty(Cn, device=D)
+    mean, invstd = torch.empty(Cn, device=D), torch.empty(Cn, device=D)
+    rmd, rvd = rm.clone().to(D), rv.clone().to(D)
+    nbt = torch.zeros((), dtype=torch.int64, device=D)
+    ops.bn_finalize(sums, rows, Cn, gamma.to(D), beta.to(D), 1e-5, 0.1, rmd, rvd, nbt, scale, shift, mean, invstd)
+    y = torch.empty(rows, Cn, dtype=dt, device=D)
+    ops.bn_act(code, xdv, scale, shift, res.to(dt).to(D), True, y, rows, Cn)
+    torch.cuda.synchronize()
+    assert int(nbt) == 1
+    sc = ref_y.abs().max().item()
+    assert (y.float().cpu().double() - ref_y.detach()).abs().max().item() < tol(dt, sc)
+    assert torch.allclose(rmd.cpu(), rm64.float(), atol=1e-5, rtol=1e-4)  # rm64/rv64 updated in place by F.batch_norm
+    assert torch.allclose(rvd.cpu(), rv64.float(), atol=1e-5, rtol=1e-4)
+
+    # backward
+    dy = rnd(torch.randn(rows, Cn, generator=g), dt)
+    ref_y.backward(dy.double())
+    prow = ops.bn_bwd_partial_rows(rows, Cn)
+    bpart = torch.full((prow, 2, Cn), float("nan"), device=D)
+    dz = dy.to(dt).to(D).clone()
+    y_ref_dev = ref_y.detach().float().to(dt).to(D)  # mask source: exact reference activations
+    ops.bn_bwd_reduce(code, dz, y_ref_dev, xdv, mean, invstd, dz, rows, Cn, bpart)
+    lsums = torch.empty(2 * Cn, dtype=torch.float64, device=D)
+    ops.bn_stats_reduce(bpart, prow, Cn, lsums)
+    dx = torch.empty(rows, Cn, dtype=dt, device=D)
+    dgamma, dbeta = torch.ones(Cn, device=D), torch.ones(Cn, device=D)
+    ops.bn_bwd_apply(code, dz, xdv, mean, invstd, gamma.to(D), lsums, rows, lsums, dgamma, dbeta, dx, rows, Cn)
+    torch.cuda.synchronize()
+    mask = (ref_y.detach() > 0).double()
+    assert torch.equal(dz.float().cpu().double(), dy.double() * mask)
+    sc = xd64.grad.abs().max().item()
+    assert (dx.float().cpu().double() - xd64.grad).abs().max().item() < tol(dt, sc) * 4
+    assert torch.allclose((dgamma.cpu() - 1).double(), g64.grad, rtol=2e-3, atol=2e-3 * g64.grad.abs().max().item())
+    assert torch.allclose((dbeta.cpu() - 1).double(), b64.grad, rtol=2e-3, atol=2e-3 * b64.grad.abs().max().item())
+
+
+def test_bn_eval_and_f32_out():
+    ops = _ops()
+    D = dev()
+    Cn, rows = 128, 50
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(rows, Cn, generator=g).bfloat16()
+    gamma, beta = torch.rand(Cn, generator=g) + 0.5, torch.randn(Cn, generator=g)
+    rm, rv = torch.randn(Cn, generator=g), torch.rand(Cn, generator=g) + 0.5
+    ref = F.batch_norm(x.float(), rm, rv, gamma, beta, False, 0.1, 1e-5)
+    scale, shift = torch.empty(Cn, device=D), torch.empty(Cn, device=D)
+    ops.bn_eval_scale_shift(gamma.to(D), beta.to(D), rm.to(D), rv.to(D), 1e-5, Cn, scale, shift)
+    y = torch.empty(rows, Cn, device=D)
+    ops.bn_act(ops.dtype_code(torch.bfloat16), x.to(D), scale, shift, None, False, y, rows, Cn, out_f32=True)
+    torch.cuda.synchronize()
+    assert torch.allclose(y.cpu(), ref, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+def test_stem_im2col_matches_conv(dt):
+    ops = _ops()
+    code = ops.dtype_code(dt)
+    g = torch.Generator().manual_seed(11)
+    N, H, W = 2, 30, 26
+    x = torch.randn(N, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    ref = F.conv2d(rnd(x, dt).double(), rnd(w, dt).double(), stride=2, padding=3)
+    Ho, Wo = ref.shape[2:]
+    Kpad = 192
+    cols = torch.empty(N * Ho * Wo, Kpad, dtype=dt, device=dev())
+    ops.stem_im2col(code, x.to(dev()), cols, Kpad)
+    wm = w.permute(0, 2, 3, 1).contiguous().reshape(64, 147).to(dev())
+    wf = torch.empty(64, Kpad, dtype=dt, device=dev())
+    ops.weight_prep(code, wm, 64, 1, 147, wf, Kpad, None)
+    d = ops.fwd_desc(code, N * Ho * Wo, 1, 1, Kpad, 64, 1, 1, 0)
+    y = torch.empty(N * Ho * Wo, 64, dtype=dt, device=dev())
+    ops.conv_gemm(d, cols, wf, y, None, None)
+    # stem weight gradient through the padded-K path: columns >= 147 must be dropped
+    dy = torch.randn(N, 64, Ho, Wo, generator=g)
+    ref_dw = torch.nn.grad.conv2d_weight(rnd(x, dt).double(), (64, 3, 7, 7), rnd(dy, dt).double(), stride=2, padding=3)
+    d.w_row_stride = 147
+    dw = torch.zeros(64 * 147 + 64, device=dev())
+    ops.conv_wgrad(d, cols, nhwc(dy, dt).reshape(-1, 64), dw)
+    torch.cuda.synchronize()
+    got = y.float().cpu().reshape(N, Ho, Wo, 64).permute(0, 3, 1, 2)
+    assert (got.double() - ref).abs().max().item() < tol(dt, ref.abs().max().item())
+    assert float(dw[64 * 147:].abs().sum()) == 0.0
+    got_dw = dw[:64 * 147].cpu().reshape(64, 7, 7, 3).permute(0, 3, 1, 2)
+    assert (got_dw.double() - ref_dw).abs().max().item() < tol(dt, ref_dw.abs().max().item()) * 2
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+def test_pools(dt):
+    ops = _ops()
+    code = ops.dtype_code(dt)
+    g = torch.Generator().manual_seed(13)
+    N, Cn, H, W = 2, 64, 11, 14
+    x = F.relu(torch.randn(N, Cn, H, W, generator=g))  # many exact-zero ties, as after ReLU
+    xr = rnd(x, dt).double().requires_grad_(True)
+    ref = F.max_pool2d(xr, 3, 2, 1)
+    Ho, Wo = ref.shape[2:]
+    xd = nhwc(x, dt)
+    y = torch.empty(N, Ho, Wo, Cn, dtype=dt, device=dev())
+    ops.maxpool_fwd(code, xd, y, N, H, W, Cn)
+    dy = rnd(torch.randn(N, Cn, Ho, Wo, generator=g), dt)
+    ref.backward(dy.double())
+    dx = torch.empty_like(xd)
+    ops.maxpool_bwd(code, xd, nhwc(dy, dt), dx, N, H, W, Cn)
+    torch.cuda.synchronize()
+    assert torch.equal(from_nhwc(y).double(), ref.detach())
+    assert (from_nhwc(dx).double() - xr.grad).abs().max().item() < tol(dt, 4.0)
+
+    # average pool
+    HW = H * W
+    f32 = torch.empty(N, Cn, device=dev())
+    ft = torch.empty(N, Cn, dtype=dt, device=dev())
+    ops.avgpool_fwd(code, xd, f32, ft, N, HW, Cn)
+    want = rnd(x, dt).double().mean(dim=(2, 3))
+    df = rnd(torch.randn(N, Cn, generator=g), dt)
+    dxa = torch.empty_like(xd)
+    ops.avgpool_bwd(code, df.to(dt).to(dev()), dxa, N, HW, Cn)
+    torch.cuda.synchronize()
+    assert torch.allclose(f32.cpu().double(), want, atol=1e-5)
+    assert (ft.float().cpu().double() - want).abs().max().item() < tol(dt, 1.0)
+    want_dx = (df.double() / HW)[:, :, None, None].expand(N, Cn, H, W)
+    assert (from_nhwc(dxa).double() - want_dx).abs().max().item() < tol(dt, 1.0)
+
+
+@pytest.mark.parametrize("R", [8, 64, 130])
+def test_ntxent_logits_and_backward(R):
+    ops = _ops()
+    from oracle import sm3_oracle as O
+    D = dev()
+    g = torch.Generator().manual_seed(R)
+    z = torch.randn(R, 128, generator=g)
+    z64 = z.double().requires_grad_(True)
+    ref_logits, _ = O.ntxent_logits(z64, 0.1)
+    zn, inv = torch.empty(R, 128, device=D), torch.empty(R, device=D)
+    logits = torch.full((R, R - 1), float("nan"), device=D)
+    ops.ntxent_logits(z.to(D), 0.1, zn, inv, logits)
+    torch.cuda.synchronize()
+    assert (logits.cpu().double() - ref_logits.detach()).abs().max().item() < 2e-5
+    # CE + its gradient
+    loss = torch.zeros(1, device=D)
+    dlog = torch.empty_like(logits)
+    ops.ce_label0(logits, 0.5, loss, dlog)
+    ref_loss = 0.5 * O.cross_entropy_zero_label(ref_logits)
+    ref_loss.backward()
+    dz = torch.empty(R, 128, device=D)
+    ops.ntxent_logits_bwd(0, dlog, zn, inv, 0.1, dz)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(ref_loss)) < 2e-5
+    sc = z64.grad.abs().max().item()
+    assert (dz.cpu().double() - z64.grad).abs().max().item() < 1e-4 * sc + 1e-7
+
+    # fused path: same loss and gradient without the logits tensor
+    ws = torch.empty(R * 128 + 2 * R, device=D)
+    loss2 = torch.zeros(1, device=D)
+    dz2 = torch.empty(R, 128, device=D)
+    ops.ntxent_fused(0, z.to(D), 0.1, 0.5, ws, loss2, dz2)
+    torch.cuda.synchronize()
+    assert abs(float(loss2) - float(ref_loss)) < 2e-5
+    assert (dz2.cpu().double() - z64.grad).abs().max().item() < 1e-4 * sc + 1e-7
+
+
+def test_adamw_matches_torch():
+    ops = _ops()
+    from oracle import sm3_oracle as O
+    D = dev()
+    g = torch.Generator().manual_seed(17)
+    n = 100003
+    npad = (n + 3) // 4 * 4
+    p = torch.randn(npad, generator=g)
+    grads = [torch.randn(npad, generator=g) * 0.01 for _ in range(3)]
+    pr, mr, vr = p.double().clone(), torch.zeros(npad, dtype=torch.float64), torch.zeros(npad, dtype=torch.float64)
+    pd, md, vd = p.clone().to(D), torch.zeros(npad, device=D), torch.zeros(npad, device=D)
+    for step, gr in enumerate(grads, start=1):
+        O.adamw_step(pr, gr.double(), mr, vr, step, 1e-3, eps=1e-5, weight_decay=5e-2)
+        ops.adamw(pd, gr.to(D), md, vd, 1e-3, 0.9, 0.999, 1e-5, 5e-2, step)
+    torch.cuda.synchronize()
+    assert torch.allclose(pd.cpu().double(), pr, atol=2e-6, rtol=1e-5)
+    # skip-on-overflow
+    found = torch.zeros(1, dtype=torch.int32, device=D)
+    bad = grads[0].clone(); bad[5] = float("inf")
+    ops.check_finite(bad.to(D), found)
+    before = pd.clone()
+    ops.adamw(pd, bad.to(D), md, vd, 1e-3, 0.9, 0.999, 1e-5, 5e-2, 4, 1.0, found)
+    torch.cuda.synchronize()
+    assert int(found) == 1 and torch.equal(before, pd)
