@@ -1,0 +1,25 @@
+"""sm3hip -- MI355X-native kernels and engine for the SM3 pre-training hot path.
+
+`import sm3hip` never touches the GPU; the HIP library is loaded on first use and its absence is a
+hard error (sm3hip._lib.SM3LibraryError): there is no CPU fallback in the product path.
+"""
+import os
+
+import torch
+
+_DEFAULT_DTYPE = {"bf16": torch.bfloat16, "f32": torch.float32, "fp32": torch.float32}[
+    os.environ.get("SM3_DTYPE", "bf16").lower()
+]
+
+
+def set_default_dtype(dtype):
+    """Activation/MFMA dtype of engines created afterwards: torch.bfloat16 (throughput) or torch.float32
+    (exact-f32 MFMA parity mode)."""
+    global _DEFAULT_DTYPE
+    if dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError("sm3hip supports torch.bfloat16 and torch.float32")
+    _DEFAULT_DTYPE = dtype
+
+
+def default_dtype():
+    return _DEFAULT_DTYPE

@@ -1,0 +1,575 @@
+"""SM3 pre-training engine: sequences the HIP kernels of libsm3hip.so for the hot path
+
+    dual ResNet-50 forward/backward  ->  BN-MLP projectors  ->  in-modal + cross-modal NT-Xent
+
+mirroring SimCLRSkinV32.forward (reference src/models/simclr.py:415-482) and the autograd backward
+that tools/backbone_train.py:125 triggers.  The host side is Python (as in the reference); every
+arithmetic op on the path is one of our kernels, called through the C ABI with raw device
+pointers.  PyTorch supplies device memory (caching allocator), the stream and torch.distributed.
+
+Data layout in HBM
+  activations   NHWC, `dtype` (bf16 for throughput, f32 for the exact-parity mode)
+  master params one flat fp32 buffer; conv weights in [Cout][kh][kw][Cin] order (= torch channels_last
+                OIHW), exposed to the caller as ordinary nn.Parameters that are views into it
+  gradients     one flat fp32 buffer with the same offsets (weight gradients are accumulated into it
+                by the wgrad kernel, so the two views of a step simply add up)
+  per-step      `dtype` copies of every filter bank in forward order and in data-gradient order
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import ops
+from ._lib import SM3_BF16, SM3_F32
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+STEM_KPAD = 192  # 7*7*3 = 147 padded to a multiple of the 128-byte K chunk for both dtypes
+RESNET50_LAYERS = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))
+
+
+# ------------------------------------------------------------------------------------------
+# flat parameter / gradient storage
+# ------------------------------------------------------------------------------------------
+class ParamStore:
+    """All parameters of a module in one flat fp32 buffer (64-byte aligned slots); parameters become
+    views, conv weights with channels_last strides so their memory is [Cout][kh][kw][Cin]."""
+
+    def __init__(self, module, device):
+        self.module = module
+        self.device = device
+        self.names, self.offsets, self.shapes = [], {}, {}
+        off = 0
+        for name, p in module.named_parameters():
+            self.names.append(name)
+            self.offsets[name] = off
+            self.shapes[name] = tuple(p.shape)
+            off += (p.numel() + 15) // 16 * 16
+        self.total = off
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=device)
+        self.flat_g = torch.zeros(off, dtype=torch.float32, device=device)
+        self._bind()
+
+    def _view(self, flat, name):
+        shape = self.shapes[name]
+        n = math.prod(shape) if shape else 1
+        v = flat[self.offsets[name]: self.offsets[name] + n]
+        if len(shape) == 4:
+            o, i, h, w = shape
+            return v.view(o, h, w, i).permute(0, 3, 1, 2)  # OIHW shape, OHWI memory
+        return v.view(shape)
+
+    def _bind(self):
+        params = dict(self.module.named_parameters())
+        with torch.no_grad():
+            for name in self.names:
+                p = params[name]
+                v = self._view(self.flat_p, name)
+                v.copy_(p.data.to(device=self.device, dtype=torch.float32))
+                p.data = v
+                p.grad = None
+        self._ptrs = {n: params[n].data_ptr() for n in self.names}
+
+    def bound(self):
+        params = dict(self.module.named_parameters())
+        return all(params[n].data_ptr() == self._ptrs[n] and params[n].device == self.flat_p.device
+                   for n in self.names)
+
+    def rebind_if_needed(self):
+        if not self.bound():
+            self._bind()
+
+    def flat2d(self, flat, name):
+        """[Cout, taps*Cin] (conv / linear) or [C] view of a slot."""
+        shape = self.shapes[name]
+        n = math.prod(shape)
+        v = flat[self.offsets[name]: self.offsets[name] + n]
+        return v.view(shape[0], -1) if len(shape) >= 2 else v
+
+    def grad_views(self, flat=None):
+        flat = self.flat_g if flat is None else flat
+        return [self._view(flat, n) for n in self.names]
+
+
+# ------------------------------------------------------------------------------------------
+# layer units
+# ------------------------------------------------------------------------------------------
+class ConvUnit:
+    def __init__(self, name, Ci, Co, k, stride, pad, stem=False):
+        self.name, self.Ci, self.Co, self.k, self.stride, self.pad, self.stem = name, Ci, Co, k, stride, pad, stem
+        self.taps = k * k
+        self.w_fwd = self.w_dgrad = None
+        self._fd, self._dd = {}, {}
+
+    def alloc(self, dtype, device, need_dgrad=True):
+        tdt = ops.TORCH_DTYPE[dtype]
+        if self.stem:
+            self.w_fwd = torch.empty(self.Co, STEM_KPAD, dtype=tdt, device=device)
+        else:
+            self.w_fwd = torch.empty(self.Co, self.taps * self.Ci, dtype=tdt, device=device)
+            if need_dgrad:
+                self.w_dgrad = torch.empty(self.Ci, self.taps, self.Co, dtype=tdt, device=device)
+
+    def refresh(self, dtype, master2d):
+        if self.stem:
+            ops.weight_prep(dtype, master2d, self.Co, 1, 147, self.w_fwd, STEM_KPAD, None)
+        else:
+            ops.weight_prep(dtype, master2d, self.Co, self.taps, self.Ci, self.w_fwd, self.taps * self.Ci,
+                            self.w_dgrad)
+
+    def fwd_desc(self, dtype, N, H, W):
+        key = (dtype, N, H, W)
+        if key not in self._fd:
+            if self.stem:  # GEMM over the im2col rows: N here is the row count
+                d = ops.fwd_desc(dtype, N, 1, 1, STEM_KPAD, self.Co, 1, 1, 0)
+            else:
+                d = ops.fwd_desc(dtype, N, H, W, self.Ci, self.Co, self.k, self.stride, self.pad)
+            self._fd[key] = d
+        return self._fd[key]
+
+    def wgrad_desc(self, dtype, N, H, W):
+        if not self.stem:
+            return self.fwd_desc(dtype, N, H, W)
+        key = ("wg", dtype, N)
+        if key not in self._fd:
+            d = ops.fwd_desc(dtype, N, 1, 1, STEM_KPAD, self.Co, 1, 1, 0)
+            d.w_row_stride = 147  # gradient rows are the unpadded [64][147] master layout
+            self._fd[key] = d
+        return self._fd[key]
+
+    def dgrad_descs(self, dtype, N, H, W):
+        key = (dtype, N, H, W)
+        if key not in self._dd:
+            self._dd[key] = ops.dgrad_descs(dtype, N, H, W, self.Ci, self.Co, self.k, self.stride, self.pad)
+        return self._dd[key]
+
+
+class BNUnit:
+    def __init__(self, name, C, affine=True):
+        self.name, self.C, self.affine = name, C, affine
+
+
+class Rec:
+    """What one conv+BN(+act) application saves for backward."""
+    __slots__ = ("cu", "bu", "N", "H", "W", "Ho", "Wo", "x_in", "xo", "mean", "invstd", "y", "relu")
+
+
+class EncoderPlan:
+    def __init__(self, prefix, block_counts=(3, 4, 6, 3)):
+        self.prefix = prefix
+        self.stem = ConvUnit(prefix + "conv1", 3, 64, 7, 2, 3, stem=True)
+        self.stem_bn = BNUnit(prefix + "bn1", 64)
+        self.blocks = []
+        inpl = 64
+        for li, ((planes, _, stride), nblocks) in enumerate(zip(RESNET50_LAYERS, block_counts), start=1):
+            for b in range(nblocks):
+                p = f"{prefix}layer{li}.{b}."
+                s = stride if b == 0 else 1
+                blk = {
+                    "c1": ConvUnit(p + "conv1", inpl, planes, 1, 1, 0), "b1": BNUnit(p + "bn1", planes),
+                    "c2": ConvUnit(p + "conv2", planes, planes, 3, s, 1), "b2": BNUnit(p + "bn2", planes),
+                    "c3": ConvUnit(p + "conv3", planes, planes * 4, 1, 1, 0), "b3": BNUnit(p + "bn3", planes * 4),
+                }
+                if b == 0:
+                    blk["cd"] = ConvUnit(p + "downsample.0", inpl, planes * 4, 1, s, 0)
+                    blk["bd"] = BNUnit(p + "downsample.1", planes * 4)
+                    inpl = planes * 4
+                self.blocks.append(blk)
+        self.out_dim = inpl
+
+    def conv_units(self):
+        yield self.stem
+        for blk in self.blocks:
+            for k in ("c1", "c2", "c3", "cd"):
+                if k in blk:
+                    yield blk[k]
+
+
+class ProjectorPlan:
+    def __init__(self, prefix, in_dim, proj_dim):
+        self.prefix = prefix
+        self.l0 = ConvUnit(prefix + "0", in_dim, in_dim, 1, 1, 0)
+        self.b1 = BNUnit(prefix + "1", in_dim)
+        self.l3 = ConvUnit(prefix + "3", in_dim, in_dim, 1, 1, 0)
+        self.b4 = BNUnit(prefix + "4", in_dim)
+        self.l6 = ConvUnit(prefix + "6", in_dim, proj_dim, 1, 1, 0)
+        self.b7 = BNUnit(prefix + "7", proj_dim, affine=False)
+
+    def conv_units(self):
+        return (self.l0, self.l3, self.l6)
+
+
+# ------------------------------------------------------------------------------------------
+# the engine
+# ------------------------------------------------------------------------------------------
+def enc_mod_out_dim(enc_mod):
+    return 512 * 4
+
+
+class SM3Engine:
+    """Runs SimCLRSkinV3 / V32 (and a bare encoder) on the HIP kernels.
+
+    module      the nn.Module that owns the parameters/buffers (src.models.simclr.SimCLRSkinV32 mirror)
+    dtype       torch.bfloat16 (MFMA bf16, fp32 accumulate) or torch.float32 (exact-f32 MFMA)
+    stat_sync   None, or a callable(t: fp64 CUDA tensor) that sums t over data-parallel ranks in place
+                (SyncBatchNorm semantics, tools/backbone_train.py:510); world_size scales the counts.
+    """
+
+    def __init__(self, module, dtype=torch.bfloat16, kind="v32"):
+        """kind: "v32" (SimCLRSkinV32: independent cross projectors), "v3" (SimCLRSkinV3: one shared cross
+        projector), "simclr" (one SimCLR branch: encoder.* + projector.*) or "encoder" (a bare ResNet)."""
+        self.module = module
+        self.tdt = dtype
+        self.dtype = ops.dtype_code(dtype)
+        self.kind = kind
+        self.store = None
+        self.stat_sync = None
+        self.world_size = 1
+        self.grad_ready = None  # callback(first_param_name, last_param_name) for gradient-bucket overlap
+        self.branches = OrderedDict()
+        self.cross = None
+        if kind in ("v32", "v3"):
+            proj_dim = module.proj_dim
+            for key in ("derm", "clinic"):
+                enc_mod = getattr(module, key + "_backbone").encoder
+                self.branches[key] = (EncoderPlan(f"{key}_backbone.encoder.", enc_mod.block_counts),
+                                      ProjectorPlan(f"{key}_backbone.projector.", enc_mod_out_dim(enc_mod), proj_dim))
+            if kind == "v3":
+                cp = ProjectorPlan("cross_proj.", 2048, proj_dim)
+                self.cross = (cp, cp)
+            else:
+                self.cross = (ProjectorPlan("cross_proj.0.", 2048, proj_dim),
+                              ProjectorPlan("cross_proj.1.", 2048, proj_dim))
+        elif kind == "simclr":
+            self.branches["main"] = (EncoderPlan("encoder.", module.encoder.block_counts),
+                                     ProjectorPlan("projector.", module.encoder_out_dim, module.proj_dim))
+        elif kind == "encoder":
+            self.branches["main"] = (EncoderPlan("", module.block_counts), None)
+        else:
+            raise ValueError(kind)
+        self._ws = {}
+        self._allocated = False
+
+    # ---- setup ---------------------------------------------------------------------------
+    def _all_conv_units(self):
+        seen = set()
+        plans = [p for pair in self.branches.values() for p in pair if p is not None]
+        plans += list(self.cross or ())
+        for plan in plans:
+            for cu in plan.conv_units():
+                if id(cu) not in seen:
+                    seen.add(id(cu))
+                    yield cu
+
+    def prepare(self, device):
+        """Bind parameters into the flat store (idempotent; re-binds after module.cuda()/to())."""
+        if self.store is None or self.store.flat_p.device != device:
+            self.store = ParamStore(self.module, device)
+            self._allocated = False
+        else:
+            self.store.rebind_if_needed()
+        if not self._allocated:
+            for cu in self._all_conv_units():
+                cu.alloc(self.dtype, device)
+            self._allocated = True
+        self.buffers = dict(self.module.named_buffers())
+        for name, b in self.buffers.items():
+            if b.device != device:
+                raise RuntimeError(f"buffer {name} is on {b.device}, expected {device}: call module.to(device) first")
+
+    def refresh_weights(self):
+        """fp32 master -> `dtype` filter banks (forward and data-gradient order); once per step."""
+        for cu in self._all_conv_units():
+            wname = cu.name + ".weight"
+            if wname not in self.store.offsets:
+                continue  # projector dropped by the caller (mlc_train.py:344-346 sets them to None)
+            cu.refresh(self.dtype, self.store.flat2d(self.store.flat_p, wname))
+
+    def _work(self, key, numel, dtype=torch.float32):
+        t = self._ws.get(key)
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            t = torch.empty(max(numel, 1), dtype=dtype, device=self.store.flat_p.device)
+            self._ws[key] = t
+        return t
+
+    def _p(self, name):
+        return self.store.flat2d(self.store.flat_p, name)
+
+    def _g(self, name):
+        return self.store.flat2d(self.store.flat_g, name)
+
+    # ---- conv + BN (+residual) (+ReLU) ---------------------------------------------------
+    def conv_bn(self, cu, bu, x, N, H, W, relu, residual=None, train=True, save=None, out_f32=False, y_out=None):
+        dev = x.device
+        d = cu.fwd_desc(self.dtype, N, H, W)
+        Ho, Wo = (1, 1) if cu.stem else (d.Ho, d.Wo)
+        rows = N if cu.stem else N * Ho * Wo
+        C = cu.Co
+        xo = torch.empty(rows, C, dtype=self.tdt, device=dev)
+        scale, shift = self._work("scale", 2048), self._work("shift", 2048)
+        gamma = self._p(bu.name + ".weight") if bu.affine else None
+        beta = self._p(bu.name + ".bias") if bu.affine else None
+        rm, rv = self.buffers[bu.name + ".running_mean"], self.buffers[bu.name + ".running_var"]
+        mean = invstd = None
+        if train:
+            prow = ops.conv_partial_rows(d)
+            partials = self._work("partials", prow * 2 * C)
+            ops.conv_gemm(d, x, cu.w_fwd, xo, None, partials)
+            sums = self._work("sums", 2 * 2048, torch.float64)
+            ops.bn_stats_reduce(partials, prow, C, sums)
+            count = rows
+            if self.stat_sync is not None:
+                self.stat_sync(sums[: 2 * C])
+                count = rows * self.world_size
+            mean = torch.empty(C, dtype=torch.float32, device=dev)
+            invstd = torch.empty(C, dtype=torch.float32, device=dev)
+            ops.bn_finalize(sums, count, C, gamma, beta, BN_EPS, BN_MOMENTUM, rm, rv,
+                            self.buffers[bu.name + ".num_batches_tracked"], scale, shift, mean, invstd)
+        else:
+            ops.conv_gemm(d, x, cu.w_fwd, xo, None, None)
+            ops.bn_eval_scale_shift(gamma, beta, rm, rv, BN_EPS, C, scale, shift)
+        if y_out is None:
+            y_out = torch.empty(rows, C, dtype=torch.float32 if out_f32 else self.tdt, device=dev)
+        ops.bn_act(self.dtype, xo, scale, shift, residual, relu, y_out, rows, C, out_f32=out_f32)
+        if save is not None:
+            r = Rec()
+            r.cu, r.bu, r.N, r.H, r.W, r.Ho, r.Wo = cu, bu, N, H, W, Ho, Wo
+            r.x_in, r.xo, r.mean, r.invstd, r.y, r.relu = x, xo, mean, invstd, y_out, relu
+            save.append(r)
+        return y_out, Ho, Wo
+
+    def bn_backward(self, r, dy, keep_dz):
+        """dy: gradient w.r.t. the unit's output (post-activation).  Masks it in place when the unit has a
+        ReLU.  Returns (gradient w.r.t. the conv output, dz = masked dy)."""
+        C = r.cu.Co
+        rows = r.xo.shape[0]
+        prow = ops.bn_bwd_partial_rows(rows, C)
+        bpart = self._work("partials", prow * 2 * C)
+        ops.bn_bwd_reduce(self.dtype, dy, r.y if r.relu else None, r.xo, r.mean, r.invstd,
+                          dy if r.relu else None, rows, C, bpart)
+        lsums = self._work("lsums", 2 * 2048, torch.float64)
+        ops.bn_stats_reduce(bpart, prow, C, lsums)
+        gsums, count = lsums, rows
+        if self.stat_sync is not None:
+            gsums = self._work("gsums", 2 * 2048, torch.float64)
+            gsums[: 2 * C].copy_(lsums[: 2 * C])
+            self.stat_sync(gsums[: 2 * C])
+            count = rows * self.world_size
+        dxo = torch.empty_like(r.xo) if keep_dz else dy
+        gamma = self._p(r.bu.name + ".weight") if r.bu.affine else None
+        dgamma = self._g(r.bu.name + ".weight") if r.bu.affine else None
+        dbeta = self._g(r.bu.name + ".bias") if r.bu.affine else None
+        ops.bn_bwd_apply(self.dtype, dy, r.xo, r.mean, r.invstd, gamma, gsums, count, lsums, dgamma, dbeta, dxo,
+                         rows, C)
+        return dxo, dy
+
+    def conv_backward(self, r, dxo, need_dx=True, addend=None, into=None):
+        cu = r.cu
+        ops.conv_wgrad(cu.wgrad_desc(self.dtype, r.N, r.H, r.W), r.x_in, dxo, self._g(cu.name + ".weight"))
+        if not need_dx:
+            return None
+        descs, full = cu.dgrad_descs(self.dtype, r.N, r.H, r.W)
+        if into is not None:  # accumulate into an existing gradient
+            for dd in descs:
+                ops.conv_gemm(dd, dxo, cu.w_dgrad, into, into, None)
+            return into
+        if full:
+            dx = torch.empty(r.N * r.H * r.W, cu.Ci, dtype=self.tdt, device=dxo.device)
+            for dd in descs:
+                ops.conv_gemm(dd, dxo, cu.w_dgrad, dx, addend, None)
+            return dx
+        dx = addend.clone() if addend is not None else torch.zeros(r.N * r.H * r.W, cu.Ci, dtype=self.tdt,
+                                                                   device=dxo.device)
+        for dd in descs:
+            ops.conv_gemm(dd, dxo, cu.w_dgrad, dx, dx, None)
+        return dx
+
+    # ---- encoder -------------------------------------------------------------------------
+    def encoder_forward(self, plan, x, train, feat_f32, feat_t, save=None):
+        """x: NCHW fp32 [N,3,H,W] (as the loader delivers it, tools/backbone_train.py:89-92).
+        Writes the pooled features into feat_f32 [N,2048] (fp32) and feat_t (dtype copy, optional)."""
+        if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("encoder input must be NCHW float32 with 3 channels")
+        x = x.contiguous()
+        N, _, H, W = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        recs = [] if save is not None else None
+        cols = torch.empty(N * Ho * Wo, STEM_KPAD, dtype=self.tdt, device=x.device)
+        ops.stem_im2col(self.dtype, x, cols, STEM_KPAD)
+        y, _, _ = self.conv_bn(plan.stem, plan.stem_bn, cols, N * Ho * Wo, 1, 1, True, None, train, recs)
+        Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+        p = torch.empty(N * Hp * Wp, 64, dtype=self.tdt, device=x.device)
+        ops.maxpool_fwd(self.dtype, y, p, N, Ho, Wo, 64)
+        cur, h, w = p, Hp, Wp
+        block_recs = []
+        for blk in plan.blocks:
+            br = [] if save is not None else None
+            y1, h1, w1 = self.conv_bn(blk["c1"], blk["b1"], cur, N, h, w, True, None, train, br)
+            y2, h2, w2 = self.conv_bn(blk["c2"], blk["b2"], y1, N, h1, w1, True, None, train, br)
+            if "cd" in blk:
+                idn, _, _ = self.conv_bn(blk["cd"], blk["bd"], cur, N, h, w, False, None, train, br)
+            else:
+                idn = cur
+            y3, h3, w3 = self.conv_bn(blk["c3"], blk["b3"], y2, N, h2, w2, True, idn, train, br)
+            block_recs.append(br)
+            cur, h, w = y3, h3, w3
+        ops.avgpool_fwd(self.dtype, cur, feat_f32, feat_t, N, h * w, plan.out_dim)
+        if save is not None:
+            save.append({"plan": plan, "stem": recs[0], "stem_hw": (Ho, Wo), "pool_hw": (Hp, Wp),
+                         "blocks": block_recs, "N": N, "last_hw": (h, w)})
+
+    def encoder_backward(self, ctx, dfeat, last_view=True):
+        """dfeat: [N,2048] `dtype` gradient of the pooled features.  On the last view of a step each stage's
+        parameter gradients are final once its blocks are done: grad_ready fires per stage so the caller can
+        start that bucket's all-reduce while earlier stages are still computing."""
+        plan, N = ctx["plan"], ctx["N"]
+        h, w = ctx["last_hw"]
+        dcur = torch.empty(N * h * w, plan.out_dim, dtype=self.tdt, device=dfeat.device)
+        ops.avgpool_bwd(self.dtype, dfeat, dcur, N, h * w, plan.out_dim)
+        for bi in range(len(plan.blocks) - 1, -1, -1):
+            blk, br = plan.blocks[bi], ctx["blocks"][bi]
+            if "cd" in blk:
+                r1, r2, rd, r3 = br
+            else:
+                (r1, r2, r3), rd = br, None
+            dx3, dz = self.bn_backward(r3, dcur, keep_dz=True)
+            dy2 = self.conv_backward(r3, dx3)
+            del dx3
+            dx2, _ = self.bn_backward(r2, dy2, keep_dz=False)
+            dy1 = self.conv_backward(r2, dx2)
+            del dx2, dy2
+            dx1, _ = self.bn_backward(r1, dy1, keep_dz=False)
+            if rd is not None:
+                dxd, _ = self.bn_backward(rd, dz, keep_dz=False)
+                din = self.conv_backward(r1, dx1)
+                self.conv_backward(rd, dxd, into=din)
+            else:
+                din = self.conv_backward(r1, dx1, addend=dz)
+            dcur = din
+            if last_view and "cd" in blk and bi > 0:  # first block of a stage: the stage is complete
+                stage = blk["c1"].name.rsplit(".", 2)[0]  # e.g. derm_backbone.encoder.layer4
+                self._notify(stage + ".", stage + ".")
+        # maxpool -> stem BN/ReLU -> stem weight gradient (no data gradient: the image needs none)
+        Ho, Wo = ctx["stem_hw"]
+        rs = ctx["stem"]
+        dy = torch.empty(N * Ho * Wo, 64, dtype=self.tdt, device=dfeat.device)
+        ops.maxpool_bwd(self.dtype, rs.y, dcur, dy, N, Ho, Wo, 64)
+        dxo, _ = self.bn_backward(rs, dy, keep_dz=False)
+        self.conv_backward(rs, dxo, need_dx=False)
+        if last_view:
+            self._notify(plan.prefix + "conv1", plan.prefix + "layer1.")
+
+    # ---- projector -----------------------------------------------------------------------
+    def projector_forward(self, plan, x_t, M, train, z_out, save=None):
+        """x_t [M,2048] `dtype` -> z_out [M,proj_dim] fp32 (view into the caller's [2B,proj] buffer)."""
+        recs = [] if save is not None else None
+        h, _, _ = self.conv_bn(plan.l0, plan.b1, x_t, M, 1, 1, True, None, train, recs)
+        h, _, _ = self.conv_bn(plan.l3, plan.b4, h, M, 1, 1, True, None, train, recs)
+        self.conv_bn(plan.l6, plan.b7, h, M, 1, 1, False, None, train, recs, out_f32=True, y_out=z_out)
+        if save is not None:
+            save.append(recs)
+
+    def projector_backward(self, recs, dz, addend=None, into=None):
+        """dz [M,proj_dim] `dtype` -> gradient w.r.t. the projector input [M,2048] (+addend)."""
+        r0, r3, r6 = recs
+        dx, _ = self.bn_backward(r6, dz, keep_dz=False)
+        d = self.conv_backward(r6, dx)
+        dx, _ = self.bn_backward(r3, d, keep_dz=False)
+        d = self.conv_backward(r3, dx)
+        dx, _ = self.bn_backward(r0, d, keep_dz=False)
+        if into is not None:
+            return self.conv_backward(r0, dx, into=into)
+        return self.conv_backward(r0, dx, addend=addend)
+
+    # ---- whole model ---------------------------------------------------------------------
+    @staticmethod
+    def cross_pairs(style):
+        return {0: [(0, 0), (1, 1)], 1: [(0, 1), (1, 0)], 2: [(0, 0), (0, 1), (1, 0), (1, 1)]}[style]
+
+    def forward(self, views, style=0, train=True, want_grad=True):
+        """views: dict branch -> [x_view0, x_view1] (NCHW fp32).  SimCLRSkinV32.forward / SimCLR.forward.
+        Returns (zs, feats, saved): zs[name] is the fp32 [2B,proj] projector output whose NT-Xent logits the
+        caller emits; feats[branch] = (fp32, dtype) pooled features [2B,2048]; saved feeds backward()."""
+        first = next(iter(views.values()))[0]
+        dev = first.device
+        self.prepare(dev)
+        self.refresh_weights()
+        B = first.shape[0]
+        saved = {"B": B, "style": style} if want_grad else None
+        sv = (lambda: []) if want_grad else (lambda: None)
+        zs, feats = OrderedDict(), {}
+        for key, (plan, proj) in self.branches.items():
+            imgs = views[key]
+            f32 = torch.empty(2 * B, plan.out_dim, dtype=torch.float32, device=dev)
+            ft = torch.empty(2 * B, plan.out_dim, dtype=self.tdt, device=dev)
+            ctxs = sv()
+            for v in (0, 1):  # the two views go through the encoder separately: BN statistics per view (simclr.py:58-59)
+                self.encoder_forward(plan, imgs[v], train, f32[v * B:(v + 1) * B], ft[v * B:(v + 1) * B], ctxs)
+            feats[key] = (f32, ft)
+            precs = sv()
+            if proj is not None:  # in-modal projector on cat([f1, f2])  (simclr.py:61)
+                z = torch.empty(2 * B, self.module.proj_dim, dtype=torch.float32, device=dev)
+                self.projector_forward(proj, ft, 2 * B, train, z, precs)
+                zs[key] = z
+            if want_grad:
+                saved[key] = {"enc": ctxs, "proj": precs[0] if proj is not None else None}
+        cross_saved = []
+        if self.cross is not None:  # cross-modal: each projector sees its own B rows (simclr.py:293)
+            for ci, (a, b) in enumerate(self.cross_pairs(style)):
+                z = torch.empty(2 * B, self.module.proj_dim, dtype=torch.float32, device=dev)
+                pa, pb = sv(), sv()
+                self.projector_forward(self.cross[0], feats["derm"][1][a * B:(a + 1) * B], B, train, z[:B], pa)
+                self.projector_forward(self.cross[1], feats["clinic"][1][b * B:(b + 1) * B], B, train, z[B:], pb)
+                zs[f"cross{ci}"] = z
+                if want_grad:
+                    cross_saved.append((a, b, pa[0], pb[0]))
+        if want_grad:
+            saved["cross"] = cross_saved
+        return zs, feats, saved
+
+    def _notify(self, plan_prefix_first, plan_prefix_last):
+        if self.grad_ready is not None:
+            self.grad_ready(plan_prefix_first, plan_prefix_last)
+
+    def backward(self, saved, dz, dfeat=None):
+        """dz: dict name -> [2B,proj] `dtype` gradient of the projector outputs; dfeat: optional dict branch ->
+        [2B,2048] `dtype` gradient arriving at the pooled features directly.  Accumulates parameter gradients
+        into the flat gradient buffer (self.store.flat_g)."""
+        B = saved["B"]
+        dfe = {}
+        for key, (plan, proj) in self.branches.items():
+            extra = dfeat.get(key) if dfeat is not None else None
+            if proj is not None and key in dz:
+                dfe[key] = self.projector_backward(saved[key]["proj"], dz[key], addend=extra)  # [2B,2048]
+            elif extra is not None:
+                dfe[key] = extra.clone()
+            else:
+                dfe[key] = torch.zeros(2 * B, plan.out_dim, dtype=self.tdt, device=self.store.flat_p.device)
+        for ci, (a, b, pa, pb) in enumerate(saved["cross"]):
+            d = dz[f"cross{ci}"]
+            self.projector_backward(pa, d[:B], into=dfe["derm"][a * B:(a + 1) * B])
+            self.projector_backward(pb, d[B:], into=dfe["clinic"][b * B:(b + 1) * B])
+        # all projector gradients are final here
+        for key, (plan, proj) in self.branches.items():
+            if proj is not None:
+                self._notify(proj.prefix, proj.prefix)
+        if self.cross is not None:
+            self._notify(self.cross[0].prefix, self.cross[-1].prefix)
+        for key, (plan, proj) in self.branches.items():
+            for v in (1, 0):
+                self.encoder_backward(saved[key]["enc"][v], dfe[key][v * B:(v + 1) * B], last_view=(v == 0))
+                saved[key]["enc"][v] = None  # free the view's activations as soon as it is done
+
+    def encoder_only(self, branch, x, train, want_grad):
+        """One encoder call (SimCLRSkinV3.extract / a bare ResNet forward): fp32 features [N,2048] and the
+        context for encoder_backward when want_grad."""
+        dev = x.device
+        self.prepare(dev)
+        self.refresh_weights()
+        plan = self.branches[branch][0]
+        N = x.shape[0]
+        f32 = torch.empty(N, plan.out_dim, dtype=torch.float32, device=dev)
+        ctxs = [] if want_grad else None
+        self.encoder_forward(plan, x, train, f32, None, ctxs)
+        return f32, (ctxs[0] if want_grad else None)

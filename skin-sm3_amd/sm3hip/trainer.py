@@ -1,0 +1,123 @@
+"""Fused SM3 training step (the path bench.py times and tools/backbone_train.py drives by default):
+
+    zero grads -> forward (4 encoder passes, 4+ projector passes) -> fused NT-Xent loss + d(z) for every
+    loss term -> backward -> (data parallel: bucketed gradient all-reduce over RCCL, overlapped with the
+    remaining backward) -> fused AdamW over the flat parameter buffer
+
+Equivalent to tools/backbone_train.py:98-127 of the reference (loss composition :99-121, AdamW :525-527);
+no autograd graph, no logits tensors, no host synchronisation inside the step.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .bridge import sm3_engine_for
+
+
+class SM3Trainer:
+    def __init__(self, model, lr, weight_decay=5e-2, eps=1e-5, betas=(0.9, 0.999), style=0, data_parallel=None,
+                 sync_bn=None):
+        self.model = model
+        self.kind = model._KIND
+        self.lr, self.wd, self.eps, self.betas, self.style = lr, weight_decay, eps, betas, style
+        self.step_count = 0
+        self.m = self.v = None
+        self.dp = data_parallel if data_parallel is not None else (dist.is_available() and dist.is_initialized()
+                                                                   and dist.get_world_size() > 1)
+        self.sync_bn = self.dp if sync_bn is None else sync_bn
+        self.world = dist.get_world_size() if self.dp else 1
+        self._handles = []
+        self._pending = []
+        self.loss = None
+
+    # ---- loss weights: tools/backbone_train.py:99-121 -----------------------------------
+    def _weights(self, names):
+        w = {}
+        ncross = sum(1 for n in names if n.startswith("cross"))
+        for n in names:
+            w[n] = (0.25 if self.style == 2 else 0.5) if n.startswith("cross") else 1.0
+        assert ncross in (0, 2, 4)
+        return w
+
+    def _engine(self):
+        eng = sm3_engine_for(self.model, self.kind)
+        if self.dp and self.sync_bn:
+            eng.world_size = self.world
+            eng.stat_sync = lambda t: dist.all_reduce(t)
+            eng.__dict__["_explicit_sync"] = True
+        return eng
+
+    def _bucket_ready(self, eng, first, last):
+        """Gradients of the parameters whose names start with first..last are final: all-reduce that slice of
+        the flat gradient buffer now, on RCCL's stream, while backward continues."""
+        st = eng.store
+        names = st.names
+        lo = next(i for i, n in enumerate(names) if n.startswith(first))
+        hi = max(i for i, n in enumerate(names) if n.startswith(last))
+        a = st.offsets[names[lo]]
+        b = st.offsets[names[hi]] + (st._view(st.flat_g, names[hi]).numel() + 15) // 16 * 16
+        self._handles.append(dist.all_reduce(st.flat_g[a:b], async_op=True))
+
+    def step(self, derm_imgs, clinic_imgs):
+        """One optimizer step on this rank's batch; returns the (device, fp32, 1-element) loss tensor."""
+        eng = self._engine()
+        dev = derm_imgs[0].device
+        eng.prepare(dev)
+        st = eng.store
+        if self.m is None or self.m.numel() != st.total or self.m.device != dev:
+            self.m = torch.zeros(st.total, dtype=torch.float32, device=dev)
+            self.v = torch.zeros(st.total, dtype=torch.float32, device=dev)
+        st.flat_g.zero_()
+        self.model.train()
+        zs, _feats, saved = eng.forward({"derm": list(derm_imgs), "clinic": list(clinic_imgs)}, self.style, True, True)
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        weights = self._weights(list(zs))
+        dz = {}
+        T = float(self.model.temperature)
+        for name, z in zs.items():
+            R, D = z.shape
+            ws = eng._work("ntxent_ws", R * D + 2 * R)
+            dz[name] = torch.empty(R, D, dtype=eng.tdt, device=dev)
+            ops.ntxent_fused(eng.dtype, z, T, weights[name], ws, loss, dz[name])
+        self._handles = []
+        eng.grad_ready = (lambda f, l: self._bucket_ready(eng, f, l)) if self.dp else None
+        eng.backward(saved, dz)
+        eng.grad_ready = None
+        for h in self._handles:
+            h.wait()
+        self.step_count += 1
+        ops.adamw(st.flat_p, st.flat_g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                  self.step_count, 1.0 / self.world)
+        self.loss = loss
+        return loss
+
+    # ---- checkpoint wire format: tools/backbone_train.py:578-587 ---------------------------
+    def optimizer_state_dict(self):
+        """torch.optim.AdamW-compatible state_dict (exp_avg / exp_avg_sq per parameter, shared step)."""
+        eng = self._engine()
+        st = eng.store
+        state = {}
+        for i, n in enumerate(st.names):
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": st._view(self.m, n).clone(), "exp_avg_sq": st._view(self.v, n).clone()}
+        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.wd, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(st.names)))}
+        return {"state": state if self.m is not None else {}, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        eng = self._engine()
+        dev = next(self.model.parameters()).device
+        eng.prepare(dev)
+        st = eng.store
+        self.m = torch.zeros(st.total, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(st.total, dtype=torch.float32, device=dev)
+        for i, n in enumerate(st.names):
+            s = sd["state"].get(i)
+            if s is None:
+                continue
+            st._view(self.m, n).copy_(s["exp_avg"])
+            st._view(self.v, n).copy_(s["exp_avg_sq"])
+            self.step_count = int(s["step"])
+        g = sd["param_groups"][0]
+        self.lr, self.wd, self.eps, self.betas = g["lr"], g["weight_decay"], g["eps"], tuple(g["betas"])
