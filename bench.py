@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""SM3 pre-training throughput on MI355X: `python bench.py --gpus N --steps K --warmup W`.
+
+One "step" = one optimizer step of SimCLRSkinV32(resnet50) on a batch of synthetic pairs per GPU
+(BASELINE.json configs[1]: 224x224 derm+clinical pairs, ResNet-50 x2, batch 256 per GPU, bf16 MFMA with fp32
+accumulate): forward (4 encoder passes + 6 projector passes), 4-term NT-Xent loss, backward, (N>1: RCCL
+gradient all-reduce + SyncBN statistics), fused AdamW.  Inputs are resident in HBM before the timed region.
+For N>1 the driver launches this file under torch.distributed.run, one rank per GPU (weak scaling).
+
+Prints ONE JSON line on rank 0 (see the contract in the task description) with two extra objects:
+  roofline      achieved TFLOP/s of the dominant kernel (the 128x128 bf16 gather-GEMM convolution,
+                conv_igemm_kernel<bf16_t,128,128,2,2>): algorithmic FLOPs of its launches / their summed
+                duration, timed live with HIP events on the launch stream during the timed steps
+  cpu_baseline  the CPU oracle (oracle/sm3_oracle.py, kind "port") timed on this box's host cores on a bounded
+                sample of the same workload (B=8 pairs per step, fp32)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "skin-sm3_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense, MI355X_MICROARCH.md "Chip-level parameters"
+FLOP_PER_PAIR_224 = 98.5e9
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="pairs per GPU")
+    ap.add_argument("--img", type=int, default=224)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--breakdown", default=None, help="write a per-kernel-class time/FLOP/byte table (one extra, "
+                                                       "untimed, fully instrumented step) to this file")
+    return ap.parse_args()
+
+
+def cpu_baseline(batch, img, steps):
+    """Times the CPU oracle's full training step (forward, 4-term loss, backward, AdamW) on all host cores."""
+    from oracle import procedural, sm3_oracle as O
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    P, B = O.split_state(procedural.make_state_dict(seed=0), torch.float32)
+    g = torch.Generator().manual_seed(3407)
+    derm = [torch.randn(batch, 3, img, img, generator=g) for _ in range(2)]
+    clinic = [torch.randn(batch, 3, img, img, generator=g) for _ in range(2)]
+    opt = {}
+    O.train_step(P, B, derm, clinic, 0, 0.1, opt, lr=1e-6)  # warm-up
+    times = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        O.train_step(P, B, derm, clinic, 0, 0.1, opt, lr=1e-6)
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": batch / med, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/sm3_oracle.py train_step, B={batch} pairs/step, {img}x{img}, fp32, 1 warm-up + "
+                      f"{steps} timed steps, median {med:.2f} s/step"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from sm3hip import ops, profiler
+    from sm3hip.trainer import SM3Trainer
+    from src.models.simclr import SimCLRSkinV32
+
+    tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(3407)  # identical random-init weights on every rank (Kaiming fan_out, resnet.py:227-232)
+    model = SimCLRSkinV32("resnet50", None, 128, 0.1)
+    model.sm3_dtype = tdt
+    model.to(dev)
+    trainer = SM3Trainer(model, lr=1e-6, weight_decay=5e-2, eps=1e-5, style=0)  # run.sh:6 lr
+
+    g = torch.Generator(device=dev).manual_seed(3407 + rank)
+    B, S = args.batch, args.img
+    derm = [torch.randn(B, 3, S, S, device=dev, generator=g) for _ in range(2)]
+    clinic = [torch.randn(B, 3, S, S, device=dev, generator=g) for _ in range(2)]
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(derm, clinic)
+    prof = profiler.Profiler(only={"conv_gemm_128x128"})
+    sync()
+    ops.set_profiler(prof)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(derm, clinic)
+    sync()
+    elapsed = time.perf_counter() - t0
+    ops.set_profiler(None)
+    loss_val = float(loss)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t)
+    pairs_per_s = world * B * args.steps / elapsed
+
+    table = prof.summary()
+    dom = table.get("conv_gemm_128x128", {"flops": 0.0, "ms": 0.0, "launches": 0})
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+    peak = MFMA_PEAK_TFLOPS[args.dtype]
+    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": None,
+                "kernel": f"conv_igemm_kernel<{'bf16_t' if args.dtype == 'bf16' else 'float'},128,128,2,2>",
+                "launches_per_step": dom["launches"] // max(args.steps, 1),
+                "avg_launch_us": round(1e3 * dom["ms"] / max(dom["launches"], 1), 2),
+                "avg_launch_gflop": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 3),
+                "whole_step_mfma_frac": round(pairs_per_s / world * (FLOP_PER_PAIR_224 * (S / 224.0) ** 2) / (peak * 1e12), 4)}
+
+    if args.breakdown and rank == 0:
+        full = profiler.Profiler()
+        ops.set_profiler(full)
+        trainer.step(derm, clinic)
+        torch.cuda.synchronize()
+        ops.set_profiler(None)
+        with open(args.breakdown, "w") as f:
+            f.write(full.format_table(f"per-kernel-class breakdown of one step, B={B}, {S}x{S}, {args.dtype}"))
+
+    if rank == 0:
+        out = {
+            "metric": "SM3 pretrain images/sec (paired 224x224)",
+            "value": round(pairs_per_s, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"SM3 pretrain step, SimCLRSkinV32(resnet50 x2), synthetic {S}x{S} derm+clinical "
+                                   f"pairs, batch {B}/GPU, style 0, AdamW, random-init weights",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "encoder_images_per_s": round(4 * pairs_per_s, 1),
+                       "loss": round(loss_val, 5)},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_batch, S, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,37 @@ TORCH_DTYPE = {SM3_F32: torch.float32, SM3_BF16: torch.bfloat16}
 K_CHUNK = {SM3_F32: 32, SM3_BF16: 64}  # elements per 128-byte K chunk
 
 
+_PROFILER = None
+
+
+def set_profiler(p):
+    """Install a sm3hip.profiler.Profiler (or None): wrappers then bracket their launches with HIP events."""
+    global _PROFILER
+    _PROFILER = p
+
+
+class _prof:
+    """with _prof(tag, flops, bytes): launch  -- no-op unless a profiler that wants `tag` is installed."""
+    __slots__ = ("tag", "flops", "nbytes", "start")
+
+    def __init__(self, tag, flops=0.0, nbytes=0.0):
+        self.tag, self.flops, self.nbytes, self.start = tag, flops, nbytes, None
+
+    def __enter__(self):
+        p = _PROFILER
+        if p is not None and p.wants(self.tag):
+            self.start = p.begin()
+
+    def __exit__(self, *exc):
+        if self.start is not None:
+            _PROFILER.end(self.tag, self.flops, self.nbytes, self.start)
+        return False
+
+
+def _sz(dtype):
+    return 4 if dtype == SM3_F32 else 2
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -117,8 +148,14 @@ def conv_gemm(desc, x, w, y, addend=None, partials=None):
         raise ValueError(f"Ci={desc.Ci} is not a multiple of {K_CHUNK[desc.dtype]}")
     if partials is not None and partials.numel() < conv_partial_rows(desc) * 2 * desc.Co:
         raise ValueError("partials workspace too small")
-    check(_lib.load().sm3_conv_gather_gemm(C.byref(desc), _ptr(x), _ptr(w), _ptr(y), _ptr(addend), _ptr(partials),
-                                           _stream()), "sm3_conv_gather_gemm")
+    M = desc.N * desc.Ho * desc.Wo
+    flops = 2.0 * M * desc.Co * desc.ntaps * desc.Ci
+    sz = _sz(desc.dtype)
+    nbytes = sz * (min(x.numel(), M * desc.ntaps * desc.Ci) + M * desc.Co * (2 if addend is not None else 1)
+                   + desc.Co * desc.ntaps * desc.Ci)
+    with _prof("conv_gemm_128x64" if desc.Co <= 64 else "conv_gemm_128x128", flops, nbytes):
+        check(_lib.load().sm3_conv_gather_gemm(C.byref(desc), _ptr(x), _ptr(w), _ptr(y), _ptr(addend),
+                                               _ptr(partials), _stream()), "sm3_conv_gather_gemm")
 
 
 def conv_wgrad(desc, x, dy, dw):
@@ -130,7 +167,11 @@ def conv_wgrad(desc, x, dy, dw):
         raise ValueError("dy size does not match descriptor")
     if dw.numel() < desc.Co * desc.w_row_stride:
         raise ValueError("dw too small")
-    check(_lib.load().sm3_conv_wgrad(C.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _stream()), "sm3_conv_wgrad")
+    M = desc.N * desc.Ho * desc.Wo
+    sz = _sz(desc.dtype)
+    with _prof("conv_wgrad", 2.0 * M * desc.Co * desc.ntaps * desc.Ci,
+               sz * (x.numel() + dy.numel()) + 4 * desc.Co * desc.w_row_stride):
+        check(_lib.load().sm3_conv_wgrad(C.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _stream()), "sm3_conv_wgrad")
 
 
 # ------------------------------------------------------------------------------------------
@@ -140,7 +181,8 @@ def bn_stats_reduce(partials, rows, Cn, sums):
     _chk(partials, torch.float32, "partials"); _chk(sums, torch.float64, "sums")
     if partials.numel() < rows * 2 * Cn or sums.numel() < 2 * Cn:
         raise ValueError("bn_stats_reduce: buffer too small")
-    check(_lib.load().sm3_bn_stats_reduce(_ptr(partials), rows, Cn, _ptr(sums), _stream()), "sm3_bn_stats_reduce")
+    with _prof("bn_stats_reduce", 0.0, 4.0 * rows * 2 * Cn):
+        check(_lib.load().sm3_bn_stats_reduce(_ptr(partials), rows, Cn, _ptr(sums), _stream()), "sm3_bn_stats_reduce")
 
 
 def bn_finalize(sums, count, Cn, gamma, beta, eps, momentum, running_mean, running_var, nbt, scale, shift,
@@ -151,9 +193,10 @@ def bn_finalize(sums, count, Cn, gamma, beta, eps, momentum, running_mean, runni
         if t is not None and t.numel() < Cn:
             raise ValueError(f"{n} too small")
     _chk(sums, torch.float64, "sums"); _chk(nbt, torch.int64, "num_batches_tracked")
-    check(_lib.load().sm3_bn_finalize(_ptr(sums), float(count), Cn, _ptr(gamma), _ptr(beta), eps, momentum,
-                                      _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(scale), _ptr(shift),
-                                      _ptr(save_mean), _ptr(save_invstd), _stream()), "sm3_bn_finalize")
+    with _prof("bn_finalize", 0.0, 40.0 * Cn):
+        check(_lib.load().sm3_bn_finalize(_ptr(sums), float(count), Cn, _ptr(gamma), _ptr(beta), eps, momentum,
+                                          _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(scale), _ptr(shift),
+                                          _ptr(save_mean), _ptr(save_invstd), _stream()), "sm3_bn_finalize")
 
 
 def bn_eval_scale_shift(gamma, beta, running_mean, running_var, eps, Cn, scale, shift):
@@ -169,8 +212,10 @@ def bn_act(dtype, x, scale, shift, residual, relu, y, rows, Cn, out_f32=False):
     _chk(y, torch.float32 if out_f32 else tdt, "y")
     if x.numel() != rows * Cn or y.numel() != rows * Cn or (residual is not None and residual.numel() != rows * Cn):
         raise ValueError("bn_act: size mismatch")
-    check(_lib.load().sm3_bn_act(dtype, _ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), int(relu), int(out_f32),
-                                 _ptr(y), rows, Cn, _stream()), "sm3_bn_act")
+    n = rows * Cn
+    with _prof("bn_act", 0.0, _sz(dtype) * n * (2 if residual is None else 3)):
+        check(_lib.load().sm3_bn_act(dtype, _ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), int(relu),
+                                     int(out_f32), _ptr(y), rows, Cn, _stream()), "sm3_bn_act")
 
 
 def bn_bwd_partial_rows(rows, Cn):
@@ -186,8 +231,10 @@ def bn_bwd_reduce(dtype, dy, y, x, mean, invstd, dz, rows, Cn, partials):
     _chk(partials, torch.float32)
     if partials.numel() < bn_bwd_partial_rows(rows, Cn) * 2 * Cn:
         raise ValueError("bn_bwd_reduce: partials too small")
-    check(_lib.load().sm3_bn_bwd_reduce(dtype, _ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(dz), rows,
-                                        Cn, _ptr(partials), _stream()), "sm3_bn_bwd_reduce")
+    n = rows * Cn
+    with _prof("bn_bwd_reduce", 0.0, _sz(dtype) * n * (2 + (1 if y is not None else 0) + (1 if dz is not None else 0))):
+        check(_lib.load().sm3_bn_bwd_reduce(dtype, _ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(dz),
+                                            rows, Cn, _ptr(partials), _stream()), "sm3_bn_bwd_reduce")
 
 
 def bn_bwd_apply(dtype, dz, x, mean, invstd, gamma, gsums, count, lsums, dgamma, dbeta, dx, rows, Cn):
@@ -198,9 +245,10 @@ def bn_bwd_apply(dtype, dz, x, mean, invstd, gamma, gsums, count, lsums, dgamma,
             raise ValueError(f"bn_bwd_apply: {n} size mismatch")
     _chk(gsums, torch.float64); _chk(lsums, torch.float64)
     _chk(dgamma, torch.float32); _chk(dbeta, torch.float32); _chk(gamma, torch.float32)
-    check(_lib.load().sm3_bn_bwd_apply(dtype, _ptr(dz), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(gsums),
-                                       float(count), _ptr(lsums), _ptr(dgamma), _ptr(dbeta), _ptr(dx), rows, Cn,
-                                       _stream()), "sm3_bn_bwd_apply")
+    with _prof("bn_bwd_apply", 0.0, _sz(dtype) * rows * Cn * 3):
+        check(_lib.load().sm3_bn_bwd_apply(dtype, _ptr(dz), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma),
+                                           _ptr(gsums), float(count), _ptr(lsums), _ptr(dgamma), _ptr(dbeta), _ptr(dx),
+                                           rows, Cn, _stream()), "sm3_bn_bwd_apply")
 
 
 # ------------------------------------------------------------------------------------------
@@ -214,7 +262,8 @@ def stem_im2col(dtype, x_nchw, cols, Kpad):
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     if cols.numel() != N * Ho * Wo * Kpad:
         raise ValueError("cols size mismatch")
-    check(_lib.load().sm3_stem_im2col(dtype, _ptr(x_nchw), _ptr(cols), N, H, W, Kpad, _stream()), "sm3_stem_im2col")
+    with _prof("stem_im2col", 0.0, 4.0 * x_nchw.numel() + _sz(dtype) * cols.numel()):
+        check(_lib.load().sm3_stem_im2col(dtype, _ptr(x_nchw), _ptr(cols), N, H, W, Kpad, _stream()), "sm3_stem_im2col")
 
 
 def maxpool_fwd(dtype, x, y, N, H, W, Cn):
@@ -222,7 +271,8 @@ def maxpool_fwd(dtype, x, y, N, H, W, Cn):
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     if x.numel() != N * H * W * Cn or y.numel() != N * Ho * Wo * Cn:
         raise ValueError("maxpool_fwd: size mismatch")
-    check(_lib.load().sm3_maxpool3x3s2_fwd(dtype, _ptr(x), _ptr(y), N, H, W, Cn, _stream()), "sm3_maxpool3x3s2_fwd")
+    with _prof("maxpool_fwd", 0.0, _sz(dtype) * (x.numel() + y.numel())):
+        check(_lib.load().sm3_maxpool3x3s2_fwd(dtype, _ptr(x), _ptr(y), N, H, W, Cn, _stream()), "sm3_maxpool3x3s2_fwd")
 
 
 def maxpool_bwd(dtype, x, dy, dx, N, H, W, Cn):
@@ -231,8 +281,9 @@ def maxpool_bwd(dtype, x, dy, dx, N, H, W, Cn):
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     if x.numel() != N * H * W * Cn or dx.numel() != x.numel() or dy.numel() != N * Ho * Wo * Cn:
         raise ValueError("maxpool_bwd: size mismatch")
-    check(_lib.load().sm3_maxpool3x3s2_bwd(dtype, _ptr(x), _ptr(dy), _ptr(dx), N, H, W, Cn, _stream()),
-          "sm3_maxpool3x3s2_bwd")
+    with _prof("maxpool_bwd", 0.0, _sz(dtype) * (2 * x.numel() + dy.numel())):
+        check(_lib.load().sm3_maxpool3x3s2_bwd(dtype, _ptr(x), _ptr(dy), _ptr(dx), N, H, W, Cn, _stream()),
+              "sm3_maxpool3x3s2_bwd")
 
 
 def avgpool_fwd(dtype, x, feat_f32, feat_t, N, HW, Cn):
@@ -242,15 +293,17 @@ def avgpool_fwd(dtype, x, feat_f32, feat_t, N, HW, Cn):
     for t in (feat_f32, feat_t):
         if t is not None and t.numel() != N * Cn:
             raise ValueError("avgpool_fwd: feature size mismatch")
-    check(_lib.load().sm3_avgpool_fwd(dtype, _ptr(x), _ptr(feat_f32), _ptr(feat_t), N, HW, Cn, _stream()),
-          "sm3_avgpool_fwd")
+    with _prof("avgpool", 0.0, _sz(dtype) * x.numel()):
+        check(_lib.load().sm3_avgpool_fwd(dtype, _ptr(x), _ptr(feat_f32), _ptr(feat_t), N, HW, Cn, _stream()),
+              "sm3_avgpool_fwd")
 
 
 def avgpool_bwd(dtype, dfeat, dx, N, HW, Cn):
     _chk(dfeat, TORCH_DTYPE[dtype]); _chk(dx, TORCH_DTYPE[dtype])
     if dfeat.numel() != N * Cn or dx.numel() != N * HW * Cn:
         raise ValueError("avgpool_bwd: size mismatch")
-    check(_lib.load().sm3_avgpool_bwd(dtype, _ptr(dfeat), _ptr(dx), N, HW, Cn, _stream()), "sm3_avgpool_bwd")
+    with _prof("avgpool", 0.0, _sz(dtype) * dx.numel()):
+        check(_lib.load().sm3_avgpool_bwd(dtype, _ptr(dfeat), _ptr(dx), N, HW, Cn, _stream()), "sm3_avgpool_bwd")
 
 
 def weight_prep(dtype, w, Co, taps, Ci, w_fwd, ld_fwd, w_dgrad):
@@ -261,8 +314,9 @@ def weight_prep(dtype, w, Co, taps, Ci, w_fwd, ld_fwd, w_dgrad):
         raise ValueError("weight_prep: w_fwd size mismatch")
     if w_dgrad is not None and w_dgrad.numel() != Co * taps * Ci:
         raise ValueError("weight_prep: w_dgrad size mismatch")
-    check(_lib.load().sm3_weight_prep(dtype, _ptr(w), Co, taps, Ci, _ptr(w_fwd), ld_fwd, _ptr(w_dgrad), _stream()),
-          "sm3_weight_prep")
+    with _prof("weight_prep", 0.0, w.numel() * (4.0 + 2 * _sz(dtype))):
+        check(_lib.load().sm3_weight_prep(dtype, _ptr(w), Co, taps, Ci, _ptr(w_fwd), ld_fwd, _ptr(w_dgrad), _stream()),
+              "sm3_weight_prep")
 
 
 def cast_from_f32(dtype, src, dst):
@@ -314,8 +368,9 @@ def ntxent_fused(dtype, z, temperature, weight, workspace, loss, dz):
     R, D = z.shape
     if workspace.numel() < R * D + 2 * R or dz.numel() != R * D:
         raise ValueError("ntxent_fused: size mismatch")
-    check(_lib.load().sm3_ntxent_fused(dtype, _ptr(z), R, D, temperature, weight, _ptr(workspace), _ptr(loss), _ptr(dz),
-                                       _stream()), "sm3_ntxent_fused")
+    with _prof("ntxent_fused", 6.0 * R * R * D, 4.0 * R * D * 3):
+        check(_lib.load().sm3_ntxent_fused(dtype, _ptr(z), R, D, temperature, weight, _ptr(workspace), _ptr(loss),
+                                           _ptr(dz), _stream()), "sm3_ntxent_fused")
 
 
 # ------------------------------------------------------------------------------------------
@@ -327,8 +382,9 @@ def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0,
         if t.numel() != p.numel():
             raise ValueError("adamw: size mismatch")
     _chk(found_inf, torch.int32)
-    check(_lib.load().sm3_adamw(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay,
-                                step, grad_scale, _ptr(found_inf), _stream()), "sm3_adamw")
+    with _prof("adamw", 0.0, 28.0 * p.numel()):
+        check(_lib.load().sm3_adamw(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay,
+                                    step, grad_scale, _ptr(found_inf), _stream()), "sm3_adamw")
 
 
 def check_finite(g, found_inf):
