@@ -146,6 +146,7 @@ def main():
     names = run_case(cls, batch=4, size=64, seed=1, dtype=torch.float32, style=0, lr=1e-3, tag="b4_s64_f32")
     run_case(cls, batch=4, size=64, seed=1, dtype=torch.float64, style=0, lr=1e-3, tag="b4_s64_f64")
     run_case(cls, batch=3, size=96, seed=2, dtype=torch.float64, style=2, lr=1e-3, tag="b3_s96_style2_f64")
+    run_case(cls, batch=8, size=64, seed=3, dtype=torch.float64, style=1, lr=1e-3, tag="b8_s64_style1_f64")
     with open(os.path.join(OUT, "param_names.txt"), "w") as f:
         f.write("\n".join(names) + "\n")
     # the 700 state_dict keys = checkpoint wire format (tools/backbone_train.py:578-587)

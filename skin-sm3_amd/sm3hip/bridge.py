@@ -65,8 +65,8 @@ def _scratch_backward(eng, fn):
 
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, eng, train, x, *params):
-        feat, ectx = eng.encoder_only("main", x, train, True)
+    def forward(ctx, eng, branch, train, x, *params):
+        feat, ectx = eng.encoder_only(branch, x, train, True)
         ctx.eng, ctx.ectx = eng, ectx
         return feat
 
@@ -77,15 +77,26 @@ class _EncoderFn(torch.autograd.Function):
         ops.cast_from_f32(eng.dtype, dfeat.contiguous().float(), d)
         grads = _scratch_backward(eng, lambda: eng.encoder_backward(ctx.ectx, d))
         ctx.ectx = None
-        return (None, None, None) + tuple(grads)
+        return (None, None, None, None) + tuple(grads)
 
 
 def encoder_features(resnet, x):
     """conv1 ... avgpool + flatten of a bare ResNet on the HIP engine: [N,2048] fp32."""
     eng = encoder_engine_for(resnet)
     if _needs_grad(resnet):
-        return _EncoderFn.apply(eng, resnet.training, x, *_params(resnet))
+        return _EncoderFn.apply(eng, "main", resnet.training, x, *_params(resnet))
     feat, _ = eng.encoder_only("main", x, resnet.training, False)
+    return feat
+
+
+def branch_features(model, kind, branch, x):
+    """SimCLRSkinV3.extract: one encoder of the SM3 model, run by the model's own engine (same dtype, same
+    flat parameter store); train/eval statistics follow that encoder module's flag, as nn.Module would."""
+    eng = sm3_engine_for(model, kind)
+    enc = getattr(model, branch + "_backbone").encoder
+    if _needs_grad(enc):
+        return _EncoderFn.apply(eng, branch, enc.training, x, *_params(model))
+    feat, _ = eng.encoder_only(branch, x, enc.training, False)
     return feat
 
 

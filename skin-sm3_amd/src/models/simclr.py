@@ -88,7 +88,9 @@ class SimCLRSkinV3(nn.Module):
         return (pairs[0], pairs[1], tuple(pairs[2:]))
 
     def extract(self, derm_imgs, clinic_imgs):
-        return [self.derm_backbone.encoder(derm_imgs), self.clinic_backbone.encoder(clinic_imgs)]
+        from sm3hip import bridge
+        return [bridge.branch_features(self, self._KIND, "derm", derm_imgs),
+                bridge.branch_features(self, self._KIND, "clinic", clinic_imgs)]
 
 
 class SimCLRSkinV32(SimCLRSkinV3):

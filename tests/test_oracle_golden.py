@@ -12,6 +12,7 @@ CASES = [
     ("b4_s64_f32", torch.float32, 2e-4, 2e-3),
     ("b4_s64_f64", torch.float64, 1e-9, 1e-8),
     ("b3_s96_style2_f64", torch.float64, 1e-9, 1e-8),
+    ("b8_s64_style1_f64", torch.float64, 1e-9, 1e-8),
 ]
 
 
