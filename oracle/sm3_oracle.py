@@ -43,16 +43,15 @@ def batchnorm(x, P, B, prefix, training, affine=True, stat_reduce=None):
     shape = [1, c] + [1] * (x.dim() - 2)
     if training:
         n = x.numel() // c
-        s1 = x.sum(dim=dims)
-        s2 = (x * x).sum(dim=dims)
         cnt = torch.tensor([float(n)], dtype=x.dtype)
         if stat_reduce is not None:
-            packed = stat_reduce(torch.cat([s1, s2, cnt]))
+            # SyncBatchNorm: statistics of the global batch from summed (sum x, sum x^2, count)
+            packed = stat_reduce(torch.cat([x.sum(dim=dims), (x * x).sum(dim=dims), cnt]))
             s1, s2, cnt = packed[:c], packed[c : 2 * c], packed[2 * c :]
-        mean = s1 / cnt
-        var = s2 / cnt - mean * mean  # biased
-        if stat_reduce is None:
-            # single-process: use the two-pass form, identical to ATen's CPU kernel rounding
+            mean = s1 / cnt
+            var = s2 / cnt - mean * mean  # biased
+        else:
+            # single process: the two-pass form (ATen's CPU kernel rounding)
             mean = x.mean(dim=dims)
             var = ((x - mean.view(shape)) ** 2).mean(dim=dims)
         with torch.no_grad():
@@ -172,10 +171,16 @@ def cross_entropy_zero_label(logits):
 def simclr_forward(x1, x2, P, B, prefix, temperature, training, stat_reduce=None, taps=None):
     """SimCLR.forward, src/models/simclr.py:54-91: the two views go through the encoder
     *separately* (BN statistics per view), the projector sees cat([f1, f2])."""
+    z, feats = simclr_projections(x1, x2, P, B, prefix, training, stat_reduce, taps)
+    return ntxent_logits(z, temperature), feats
+
+
+def simclr_projections(x1, x2, P, B, prefix, training, stat_reduce=None, taps=None):
+    """The part of SimCLR.forward before the similarity matrix (simclr.py:58-61): z [2B, proj_dim]."""
     f1 = resnet50_features(x1, P, B, prefix + "encoder.", training, stat_reduce, taps)
     f2 = resnet50_features(x2, P, B, prefix + "encoder.", training, stat_reduce)
     z = projector(torch.cat([f1, f2], dim=0), P, B, prefix + "projector.", training, stat_reduce)
-    return ntxent_logits(z, temperature), (f1, f2)
+    return z, (f1, f2)
 
 
 def cal_logits(f1, f2, P, B, proj1, proj2, temperature, training, stat_reduce=None):
@@ -184,6 +189,19 @@ def cal_logits(f1, f2, P, B, proj1, proj2, temperature, training, stat_reduce=No
     z = torch.cat([projector(f1, P, B, proj1, training, stat_reduce),
                    projector(f2, P, B, proj2, training, stat_reduce)], dim=0)
     return ntxent_logits(z, temperature)
+
+
+def sm3_v32_projections(P, B, derm_imgs, clinic_imgs, style, training=True, stat_reduce=None):
+    """Projector outputs of every loss term of SimCLRSkinV32.forward, in order derm, clinic, cross...;
+    each [2B, proj_dim] (rows: first half = first projector's B rows)."""
+    zd, df = simclr_projections(derm_imgs[0], derm_imgs[1], P, B, "derm_backbone.", training, stat_reduce)
+    zc, cf = simclr_projections(clinic_imgs[0], clinic_imgs[1], P, B, "clinic_backbone.", training, stat_reduce)
+    pairs = {0: [(0, 0), (1, 1)], 1: [(0, 1), (1, 0)], 2: [(0, 0), (0, 1), (1, 0), (1, 1)]}[style]
+    zs = [zd, zc]
+    for a, b in pairs:
+        zs.append(torch.cat([projector(df[a], P, B, "cross_proj.0.", training, stat_reduce),
+                             projector(cf[b], P, B, "cross_proj.1.", training, stat_reduce)], dim=0))
+    return zs
 
 
 def sm3_v32_forward(P, B, derm_imgs, clinic_imgs, style, temperature, training=True,

@@ -1,0 +1,168 @@
+"""Data-parallel path on CPU: world_size-2 gloo.
+
+1. Numerics of the design, with the CPU oracle as the compute: SyncBatchNorm by summed (sum x, sum x^2, count)
+   plus rank-averaged gradients equals a single process that normalises with full-batch statistics and
+   averages the per-shard (local-negatives) NT-Xent losses -- the reference's DDP + SyncBatchNorm semantics
+   (tools/backbone_train.py:510,522).
+2. Control flow of the product's trainer with the C ABI stubbed (tests/fakelib.py): both ranks issue the same
+   collective sequence (230 forward + 230 backward statistic all-reduces, then the gradient buckets) and the
+   fused AdamW receives grad_scale = 1/world.
+"""
+import os
+import socket
+import sys
+import traceback
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _spawn(fn, world=2):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_entry, args=(fn, r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in range(world):
+        r, ok, payload = q.get(timeout=600)
+        results[r] = (ok, payload)
+    for p in procs:
+        p.join(timeout=60)
+    for r, (ok, payload) in sorted(results.items()):
+        assert ok, f"rank {r} failed:\n{payload}"
+    return {r: payload for r, (ok, payload) in results.items()}
+
+
+def _entry(fn, rank, world, port, q):
+    try:
+        for p in (ROOT, os.path.join(ROOT, "skin-sm3_amd"), os.path.join(ROOT, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        torch.set_num_threads(4)
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        out = fn(rank, world)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, True, out))
+    except Exception:
+        q.put((rank, False, traceback.format_exc()))
+
+
+class _AllReduceSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = x.clone()
+        dist.all_reduce(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.clone()
+        dist.all_reduce(g)
+        return g
+
+
+def _oracle_rank(rank, world):
+    from oracle import procedural, sm3_oracle as O
+    Bl, size, seed, T = 3, 32, 5, 0.1
+    Bg = Bl * world
+    state = procedural.make_state_dict(seed=seed)
+    derm_np, clinic_np = procedural.make_pair_batch(Bg, size, seed)
+    sl = slice(rank * Bl, (rank + 1) * Bl)
+    dt = torch.float64
+    P, B = O.split_state(state, dt)
+    derm = [torch.from_numpy(a[sl]).to(dt) for a in derm_np]
+    clinic = [torch.from_numpy(a[sl]).to(dt) for a in clinic_np]
+    outs = O.sm3_v32_forward(P, B, derm, clinic, 0, T, True, stat_reduce=_AllReduceSum.apply)
+    loss = O.sm3_loss(outs, 0)
+    loss.backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in P.values()])
+    dist.all_reduce(flat)
+    flat /= world  # DDP: mean over ranks
+    result = None
+    if rank == 0:
+        # single-process reference: full-batch BN statistics, per-shard local-negative losses, averaged
+        P2, B2 = O.split_state(state, dt)
+        dfull = [torch.from_numpy(a).to(dt) for a in derm_np]
+        cfull = [torch.from_numpy(a).to(dt) for a in clinic_np]
+        zs = O.sm3_v32_projections(P2, B2, dfull, cfull, 0, True)
+        total = 0.0
+        for r in range(world):
+            rows = torch.cat([torch.arange(r * Bl, (r + 1) * Bl), Bg + torch.arange(r * Bl, (r + 1) * Bl)])
+            terms = [O.cross_entropy_zero_label(O.ntxent_logits(z[rows], T)[0]) for z in zs]
+            total = total + (terms[0] + terms[1] + 0.5 * terms[2] + 0.5 * terms[3]) / world
+        total.backward()
+        ref = torch.cat([p.grad.reshape(-1) for p in P2.values()])
+        bkeys = [k for k in B if k.endswith(("running_mean", "running_var"))]
+        buf_err = max(float((B[k] - B2[k]).abs().max()) for k in bkeys)
+        result = {"grad_rel": float((flat - ref).norm() / ref.norm()), "buf_err": buf_err,
+                  "nbt": int(B["derm_backbone.encoder.bn1.num_batches_tracked"])}
+    losses = [torch.zeros(1, dtype=dt) for _ in range(world)]
+    dist.all_gather(losses, loss.detach().reshape(1))
+    if rank == 0:
+        result["loss_mean"] = float(sum(losses) / world)
+        result["loss_ref"] = float(total)
+    return result
+
+
+def test_syncbn_and_grad_averaging_semantics_gloo():
+    out = _spawn(_oracle_rank)[0]
+    assert out["grad_rel"] < 1e-9, out
+    assert out["buf_err"] < 1e-10, out
+    assert abs(out["loss_mean"] - out["loss_ref"]) < 1e-10, out
+    assert out["nbt"] == 2
+
+
+def _trainer_rank(rank, world):
+    from fakelib import installed
+    from sm3hip.trainer import SM3Trainer
+    from src.models.simclr import SimCLRSkinV32
+    torch.manual_seed(0)
+    model = SimCLRSkinV32("resnet50", None, 128, 0.1)
+    model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    log = []
+    real_all_reduce = dist.all_reduce
+
+    def spy(t, *a, **k):
+        log.append((tuple(t.shape), str(t.dtype), bool(k.get("async_op", False))))
+        return real_all_reduce(t, *a, **k)
+
+    dist.all_reduce = spy
+    try:
+        with installed() as fake:
+            tr = SM3Trainer(model, lr=1e-3)
+            assert tr.dp and tr.world == world
+            x = [torch.randn(2, 3, 32, 32) for _ in range(4)]
+            tr.step(x[:2], x[2:])
+            st = tr._engine().store
+            grad_elems = sum(s[0] for s, dt, a in [(l[0], l[1], l[2]) for l in log] if dt == "torch.float32")
+            total = st.total
+    finally:
+        dist.all_reduce = real_all_reduce
+    stats = [l for l in log if l[1] == "torch.float64"]
+    buckets = [l for l in log if l[1] == "torch.float32"]
+    return {"n_stats": len(stats), "n_buckets": len(buckets), "bucket_elems": grad_elems, "total": total,
+            "seq": [(l[0], l[1]) for l in log], "async": all(l[2] for l in buckets)}
+
+
+def test_trainer_collective_pattern_gloo():
+    res = _spawn(_trainer_rank)
+    a, b = res[0], res[1]
+    assert a["seq"] == b["seq"]                       # identical collective order on both ranks: no deadlock by construction
+    assert a["n_stats"] == 460                        # 230 forward + 230 backward SyncBN reductions
+    assert a["bucket_elems"] == a["total"]            # gradient buckets tile the flat buffer exactly once
+    assert 4 <= a["n_buckets"] <= 16 and a["async"]

@@ -1,0 +1,136 @@
+"""CPU tests of the host side: module surface (names, state_dict, channels_last parameter views), engine
+control flow with stubbed kernels, gradient-bucket schedule coverage, loss weights."""
+import os
+from collections import Counter
+
+import pytest
+import torch
+
+from fakelib import installed
+
+
+@pytest.fixture(scope="module")
+def model():
+    from src.models.simclr import SimCLRSkinV32
+    torch.manual_seed(0)
+    return SimCLRSkinV32("resnet50", None, 128, 0.1)
+
+
+def test_module_surface_matches_reference(model, golden_dir):
+    keys = open(os.path.join(golden_dir, "state_dict_keys.txt")).read().split()
+    assert list(model.state_dict().keys()) == keys
+    names = open(os.path.join(golden_dir, "param_names.txt")).read().split()
+    assert [n for n, _ in model.named_parameters()] == names
+    assert model.derm_backbone.encoder_out_dim == 2048 and model.derm_feat_dim == 2048 and model.clinic_feat_dim == 2048
+    assert isinstance(model.derm_backbone.encoder.fc, torch.nn.Identity)
+    assert hasattr(model.derm_backbone.encoder, "layer4") and hasattr(model.derm_backbone.encoder, "conv1")
+    assert isinstance(model.cross_proj, torch.nn.ModuleList) and len(model.cross_proj) == 2
+    # SyncBatchNorm conversion (tools/backbone_train.py:510) keeps the key set
+    m2 = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    assert list(m2.state_dict().keys()) == keys
+
+
+def test_v3_has_shared_cross_projector():
+    from src.models.simclr import SimCLRSkinV3
+    m = SimCLRSkinV3("resnet50", None, 128, 0.5)
+    assert isinstance(m.cross_proj, torch.nn.Sequential)
+    assert sum(p.numel() for p in m.parameters()) == 81651840 - 8658944
+
+
+def test_param_store_views_are_channels_last_and_survive_load_state_dict(model):
+    from sm3hip.engine import ParamStore
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    st = ParamStore(model, torch.device("cpu"))
+    after = model.state_dict()
+    for k in before:
+        assert torch.equal(before[k], after[k]), k
+    w = dict(model.named_parameters())["derm_backbone.encoder.layer1.0.conv2.weight"]
+    assert tuple(w.shape) == (64, 64, 3, 3) and w.is_contiguous(memory_format=torch.channels_last)
+    assert st.bound()
+    # flat [Cout][kh][kw][Cin] order
+    flat = st.flat2d(st.flat_p, "derm_backbone.encoder.layer1.0.conv2.weight")
+    assert torch.equal(flat.view(64, 3, 3, 64), w.permute(0, 2, 3, 1))
+    # in-place load keeps the binding; .to()/_apply breaks it and is detected
+    model.load_state_dict(before)
+    assert st.bound()
+    total = sum((p.numel() + 15) // 16 * 16 for p in model.parameters())
+    assert st.total == total and st.flat_p.numel() == total
+
+
+def test_engine_dry_run_sequences_and_bucket_schedule(model):
+    """One full trainer step on CPU tensors with the C ABI stubbed out: every ops wrapper's host-side size /
+    dtype validation runs, and the gradient-ready notifications must cover every parameter exactly once."""
+    from sm3hip.trainer import SM3Trainer
+    with installed() as fake:
+        model.sm3_dtype = torch.bfloat16
+        tr = SM3Trainer(model, lr=1e-3, data_parallel=False)
+        eng = tr._engine()
+        x = [torch.randn(2, 3, 32, 32) for _ in range(4)]
+        eng.prepare(torch.device("cpu"))
+        ranges = []
+        orig_backward = eng.backward
+
+        def spy_backward(saved, dz, dfeat=None):
+            eng.grad_ready = lambda f, l: ranges.append((f, l))
+            orig_backward(saved, dz, dfeat)
+            eng.grad_ready = None
+
+        eng.backward = spy_backward
+        tr.step(x[:2], x[2:])
+        calls = Counter(fake.calls)
+    # 53 convs x 4 encoder passes + 3 linears x (2 in-modal + 4 cross) projector passes
+    assert calls["sm3_bn_finalize"] == 53 * 4 + 3 * 6 == 230  # 212 BN2d + 18 BN1d per step
+    assert calls["sm3_conv_wgrad"] == 230
+    assert calls["sm3_bn_bwd_apply"] == 230
+    assert calls["sm3_ntxent_fused"] == 4 and calls["sm3_adamw"] == 1
+    assert calls["sm3_stem_im2col"] == 4 and calls["sm3_maxpool3x3s2_bwd"] == 4
+    # bucket coverage
+    names = eng.store.names
+    covered = Counter()
+    for first, last in ranges:
+        lo = next(i for i, n in enumerate(names) if n.startswith(first))
+        hi = max(i for i, n in enumerate(names) if n.startswith(last))
+        for i in range(lo, hi + 1):
+            covered[names[i]] += 1
+    assert set(covered) == set(names)
+    assert all(v == 1 for v in covered.values()), [k for k, v in covered.items() if v != 1][:5]
+
+
+def test_ops_reject_bad_shapes_on_host():
+    from sm3hip import ops
+    with installed():
+        d = ops.fwd_desc(1, 2, 8, 8, 64, 64, 3, 1, 1)
+        x = torch.zeros(2, 8, 8, 64, dtype=torch.bfloat16)
+        w = torch.zeros(64, 9 * 64, dtype=torch.bfloat16)
+        y = torch.zeros(2, 8, 8, 64, dtype=torch.bfloat16)
+        ops.conv_gemm(d, x, w, y)
+        with pytest.raises(ValueError):
+            ops.conv_gemm(d, x[:1].contiguous(), w, y)
+        with pytest.raises(ValueError):
+            ops.conv_gemm(d, x.float(), w, y)
+        with pytest.raises(ValueError):
+            ops.conv_gemm(d, x, w[:, :64].contiguous(), y)
+        with pytest.raises(ValueError):
+            ops.bn_act(1, x, torch.zeros(64), torch.zeros(64), None, True, y[:1].contiguous(), 128, 64)
+        bad = ops.fwd_desc(1, 2, 8, 8, 48, 64, 1, 1, 0)  # Ci not a multiple of the 128-byte K chunk
+        with pytest.raises(ValueError):
+            ops.conv_gemm(bad, torch.zeros(2, 8, 8, 48, dtype=torch.bfloat16), torch.zeros(64, 48, dtype=torch.bfloat16), y)
+
+
+def test_cpu_tensors_are_refused_by_the_real_wrappers():
+    from sm3hip import ops
+    with pytest.raises(ValueError, match="GPU"):
+        ops.cast_from_f32(1, torch.zeros(8), torch.zeros(8, dtype=torch.bfloat16))
+
+
+def test_loss_weights_follow_reference():
+    from sm3hip.trainer import SM3Trainer
+
+    class M:
+        _KIND = "v32"
+    for style, w in ((0, 0.5), (1, 0.5), (2, 0.25)):
+        tr = SM3Trainer.__new__(SM3Trainer)
+        tr.style = style
+        names = ["derm", "clinic"] + [f"cross{i}" for i in range(4 if style == 2 else 2)]
+        ws = tr._weights(names)
+        assert ws["derm"] == 1.0 and ws["clinic"] == 1.0 and all(ws[n] == w for n in names[2:])
