@@ -48,15 +48,36 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(batch, img, steps):
-    """Times the CPU oracle's full training step (forward, 4-term loss, backward, AdamW) on all host cores."""
-    from oracle import procedural, sm3_oracle as O
+def usable_cores():
+    """Host cores this process may really use: CPU affinity capped by the cgroup CPU quota (the GPU box gives
+    one GPU's share of the host; spinning up one thread per visible core oversubscribes it badly)."""
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    cores = min(cores, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    cores = min(cores, max(1, q // p))
+        except Exception:
+            pass
+    return min(cores, int(os.environ.get("SM3_CPU_BASELINE_THREADS", "16")))
+
+
+def cpu_baseline(batch, img, steps):
+    """Times the CPU oracle's full training step (forward, 4-term loss, backward, AdamW) on the host cores."""
+    from oracle import procedural, sm3_oracle as O
+    cores = usable_cores()
     torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: oracle on {cores} threads, B={batch}", file=sys.stderr, flush=True)
     P, B = O.split_state(procedural.make_state_dict(seed=0), torch.float32)
     g = torch.Generator().manual_seed(3407)
     derm = [torch.randn(batch, 3, img, img, generator=g) for _ in range(2)]
@@ -68,6 +89,7 @@ def cpu_baseline(batch, img, steps):
         t0 = time.perf_counter()
         O.train_step(P, B, derm, clinic, 0, 0.1, opt, lr=1e-6)
         times.append(time.perf_counter() - t0)
+        print(f"[bench] cpu_baseline step {times[-1]:.2f} s", file=sys.stderr, flush=True)
     med = sorted(times)[len(times) // 2]
     return {"value": batch / med, "unit": "pairs/s", "cores": cores, "kind": "port",
             "sample": f"oracle/sm3_oracle.py train_step, B={batch} pairs/step, {img}x{img}, fp32, 1 warm-up + "

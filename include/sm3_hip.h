@@ -77,8 +77,10 @@ int sm3_conv_wgrad(const sm3_conv_desc* d, const void* x, const void* dy, float*
  * BatchNorm (2d and 1d: rows x C), train and eval.  replaces nn.BatchNorm2d/1d (+SyncBatchNorm,
  * tools/backbone_train.py:510) at resnet.py:145-149,211,261 and simclr.py:20-26.
  * ------------------------------------------------------------------------------------------ */
-/* sums[0..C) = sum over partial rows of p[r][0][c]; sums[C..2C) likewise of p[r][1][c]  (fp64) */
-int sm3_bn_stats_reduce(const float* partials, int rows, int C, double* sums, void* stream);
+/* sums[0..C) = sum over partial rows of p[r][0][c]; sums[C..2C) likewise of p[r][1][c]  (fp64, deterministic
+ * two-stage reduction).  workspace: SM3_BN_REDUCE_GROUPS * 2C doubles. */
+#define SM3_BN_REDUCE_GROUPS 64
+int sm3_bn_stats_reduce(const float* partials, int rows, int C, double* sums, double* workspace, void* stream);
 /* From (possibly all-reduced) sums and the global element count per channel: mean, biased var ->
  * scale = gamma*invstd, shift = beta - mean*scale; running stats momentum update with the unbiased
  * variance; saves mean / invstd for backward.  gamma/beta NULL => affine=False. */

@@ -34,21 +34,29 @@ static RowWalk make_walk(int64_t rows, int cvecs, int max_gy) {
     return w;
 }
 
-__global__ void bn_stats_reduce_kernel(const float* __restrict__ partials, int rows, int C, double* __restrict__ sums) {
-    // one thread per (stat, channel) column; rows are reduced in fp64, 4 independent chains
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;  // in [0, 2C)
-    if (col >= 2 * C) return;
-    const int stat = col / C, c = col - stat * C;
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    int r = 0;
-    for (; r + 3 < rows; r += 4) {
-        a0 += (double)partials[((long)(r + 0) * 2 + stat) * C + c];
-        a1 += (double)partials[((long)(r + 1) * 2 + stat) * C + c];
-        a2 += (double)partials[((long)(r + 2) * 2 + stat) * C + c];
-        a3 += (double)partials[((long)(r + 3) * 2 + stat) * C + c];
+// Stage A: grid (ceil(2C/64), G).  256 threads = 64 columns x 4 row lanes; a block sums its share of the
+// partial rows in fp64 and writes one row of the [G][2C] fp64 workspace.  Stage B sums the G rows.  Two tiny
+// launches, deterministic (no atomics); rows are read as 256-byte coalesced segments.
+__global__ __launch_bounds__(256) void bn_stats_reduce_a(const float* __restrict__ partials, int rows, int C,
+                                                         double* __restrict__ ws) {
+    __shared__ double red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + tx;  // in [0, 2C): stat-major within a partial row
+    double a = 0.0;
+    if (col < 2 * C) {
+        for (int r = blockIdx.y * 4 + ty; r < rows; r += gridDim.y * 4) a += (double)partials[(long)r * 2 * C + col];
     }
-    for (; r < rows; ++r) a0 += (double)partials[((long)r * 2 + stat) * C + c];
-    sums[col] = (a0 + a1) + (a2 + a3);
+    red[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && col < 2 * C) ws[(long)blockIdx.y * 2 * C + col] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+
+__global__ void bn_stats_reduce_b(const double* __restrict__ ws, int G, int C, double* __restrict__ sums) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= 2 * C) return;
+    double a = 0.0;
+    for (int g = 0; g < G; ++g) a += ws[(long)g * 2 * C + col];
+    sums[col] = a;
 }
 
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, int C, const float* gamma,
@@ -245,10 +253,15 @@ __global__ void bn_param_grad_kernel(const double* __restrict__ lsums, int C, fl
 
 }  // namespace
 
-extern "C" int sm3_bn_stats_reduce(const float* partials, int rows, int C, double* sums, void* stream) {
-    if (!partials || !sums || rows <= 0 || C <= 0) return SM3_EINVAL;
-    hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((2 * C + 63) / 64), dim3(64), 0, (hipStream_t)stream, partials,
-                       rows, C, sums);
+extern "C" int sm3_bn_stats_reduce(const float* partials, int rows, int C, double* sums, double* workspace,
+                                   void* stream) {
+    if (!partials || !sums || !workspace || rows <= 0 || C <= 0) return SM3_EINVAL;
+    int G = (rows + 31) / 32;
+    if (G > SM3_BN_REDUCE_GROUPS) G = SM3_BN_REDUCE_GROUPS;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_stats_reduce_a, dim3((2 * C + 63) / 64, G), dim3(256), 0, st, partials, rows, C, workspace);
+    SM3_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_stats_reduce_b, dim3((2 * C + 255) / 256), dim3(256), 0, st, workspace, G, C, sums);
     SM3_CHECK_LAUNCH();
     return 0;
 }

@@ -36,7 +36,7 @@ SIGNATURES = {
     "sm3_conv_partial_rows": [_DESC],
     "sm3_conv_gather_gemm": [_DESC, _P, _P, _P, _P, _P, _P],
     "sm3_conv_wgrad": [_DESC, _P, _P, _P, _P],
-    "sm3_bn_stats_reduce": [_P, _I, _I, _P, _P],
+    "sm3_bn_stats_reduce": [_P, _I, _I, _P, _P, _P],
     "sm3_bn_finalize": [_P, _D, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
     "sm3_bn_eval_scale_shift": [_P, _P, _P, _P, _F, _I, _P, _P, _P],
     "sm3_bn_act": [_I, _P, _P, _P, _P, _I, _I, _P, _L, _I, _P],

@@ -177,12 +177,28 @@ def conv_wgrad(desc, x, dy, dw):
 # ------------------------------------------------------------------------------------------
 # batch norm
 # ------------------------------------------------------------------------------------------
+BN_REDUCE_GROUPS = 64
+_bn_ws = {}
+
+
+def _bn_workspace(device, Cn):
+    """fp64 scratch of the two-stage statistics reduction (stream-ordered reuse, like any other workspace)."""
+    t = _bn_ws.get(device)
+    need = BN_REDUCE_GROUPS * 2 * Cn
+    if t is None or t.numel() < need:
+        t = torch.empty(max(need, BN_REDUCE_GROUPS * 2 * 2048), dtype=torch.float64, device=device)
+        _bn_ws[device] = t
+    return t
+
+
 def bn_stats_reduce(partials, rows, Cn, sums):
     _chk(partials, torch.float32, "partials"); _chk(sums, torch.float64, "sums")
     if partials.numel() < rows * 2 * Cn or sums.numel() < 2 * Cn:
         raise ValueError("bn_stats_reduce: buffer too small")
+    ws = _bn_workspace(partials.device, Cn)
     with _prof("bn_stats_reduce", 0.0, 4.0 * rows * 2 * Cn):
-        check(_lib.load().sm3_bn_stats_reduce(_ptr(partials), rows, Cn, _ptr(sums), _stream()), "sm3_bn_stats_reduce")
+        check(_lib.load().sm3_bn_stats_reduce(_ptr(partials), rows, Cn, _ptr(sums), _ptr(ws), _stream()),
+              "sm3_bn_stats_reduce")
 
 
 def bn_finalize(sums, count, Cn, gamma, beta, eps, momentum, running_mean, running_var, nbt, scale, shift,
