@@ -1,0 +1,152 @@
+"""SM3 self-supervised pre-training on MI355X -- entry point mirroring the reference's
+tools/backbone_train.py (flags of src/utils/misc.py:106-225 + backbone_train.py:612-624 that the pre-training
+recipe of run.sh:3-12 uses; one process per GPU; same checkpoint wire format, backbone_train.py:575-592).
+
+    python tools/backbone_train.py --data-name synthetic --data-path - -a resnet50 --arch-version v32 \
+        -b 512 -lr 1e-6 --temperature 0.1 --proj-dim 128 --epochs 1 --steps-per-epoch 20
+
+Differences, stated: the derm7pt dataset and its PIL augmentation pipeline are host-side and out of scope
+(SURVEY.md 2.1 #9-10), so `--data-name synthetic` generates normalised image pairs on the device; `--engine fused`
+(default) runs the fused step of sm3hip.trainer.SM3Trainer, `--engine compat` runs the reference's literal loop
+(model(...) -> CrossEntropyLoss -> backward -> torch.optim.AdamW, backbone_train.py:98-127) on the same kernels.
+`--amp` selects bf16 MFMA (the reference's fp16 autocast + GradScaler has no role with bf16's exponent range);
+without it the exact-f32 MFMA mode runs.
+"""
+import argparse
+import os
+import sys
+import time
+import traceback
+
+SCRIPT_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT_PATH = os.path.split(SCRIPT_DIR)[0]
+sys.path.insert(0, ROOT_PATH)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import torch.multiprocessing as mp  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+from src.models.simclr import SimCLRSkinV3, SimCLRSkinV32  # noqa: E402
+
+
+def get_parser():
+    p = argparse.ArgumentParser(description="SM3 SSL pre-training (MI355X)")
+    p.add_argument("--data-name", type=str, required=True)
+    p.add_argument("--data-path", type=str, required=True)
+    p.add_argument("--img-sz", nargs=2, type=int, default=[224, 224])
+    p.add_argument("-a", "--arch", default="resnet50", type=str)
+    p.add_argument("--arch-weights", default=None, type=str)
+    p.add_argument("--arch-version", default="v32", type=str,
+                   choices=["v3", "v311", "v312", "v32", "v321", "v322"])
+    p.add_argument("--proj-dim", default=128, type=int)
+    p.add_argument("--temperature", default=0.1, type=float)
+    p.add_argument("--use-checkpoint", action="store_true")
+    p.add_argument("--epochs", default=100, type=int)
+    p.add_argument("--steps-per-epoch", default=100, type=int, help="synthetic data only")
+    p.add_argument("-b", "--batch-size", default=64, type=int, help="global mini-batch size")
+    p.add_argument("-lr", "--base-lr", default=1e-3, type=float)
+    p.add_argument("--wd", default=5e-2, type=float)
+    p.add_argument("--port", default=29533, type=int)
+    p.add_argument("--seed", type=int, default=3407)
+    p.add_argument("--save-freq", type=int, default=50)
+    p.add_argument("--print-freq", type=int, default=50)
+    p.add_argument("--amp", action="store_true")
+    p.add_argument("--resume-path", type=str, default=None)
+    p.add_argument("--log-path", type=str, default="./logs")
+    p.add_argument("--engine", default="fused", choices=["fused", "compat"])
+    return p
+
+
+STYLE = {"v3": 0, "v32": 0, "v311": 1, "v321": 1, "v312": 2, "v322": 2}
+
+
+def synthetic_batch(bs, size, device, gen):
+    mk = lambda: torch.randn(bs, 3, size[0], size[1], device=device, generator=gen)
+    return [mk(), mk()], [mk(), mk()]
+
+
+def main(local_rank, args):
+    world = args.world_size
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{args.port}", world_size=world, rank=local_rank)
+    torch.manual_seed(args.seed)
+    bs = args.batch_size // world  # src/utils/misc.py:400
+    if args.data_name != "synthetic":
+        raise SystemExit("only --data-name synthetic is available in this build (dataset pipeline is out of scope)")
+    cls = SimCLRSkinV3 if args.arch_version in ("v3", "v311", "v312") else SimCLRSkinV32
+    model = cls(arch=args.arch, weights=args.arch_weights, proj_dim=args.proj_dim, temperature=args.temperature,
+                use_checkpoint=args.use_checkpoint)
+    model.sm3_dtype = torch.bfloat16 if args.amp else torch.float32
+    if world > 1:
+        model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    model = model.to(dev)
+    style = STYLE[args.arch_version]
+    start_epoch = 0
+
+    if args.engine == "fused":
+        from sm3hip.trainer import SM3Trainer
+        trainer = SM3Trainer(model, lr=args.base_lr, weight_decay=args.wd, eps=1e-5, style=style)
+    else:
+        wrapped = nn.parallel.DistributedDataParallel(model, device_ids=[local_rank]) if world > 1 else model
+        optimizer = torch.optim.AdamW(wrapped.parameters(), lr=args.base_lr, weight_decay=args.wd, eps=1e-5)
+        criterion = nn.CrossEntropyLoss()
+
+    if args.resume_path:
+        ckpt = torch.load(args.resume_path, map_location=dev)
+        model.load_state_dict(ckpt["state_dict"], strict=False)
+        start_epoch = ckpt.get("epoch", 0)
+        if args.engine == "fused" and "optimizer" in ckpt:
+            trainer.load_optimizer_state_dict(ckpt["optimizer"])
+        elif args.engine == "compat" and "optimizer" in ckpt:
+            optimizer.load_state_dict(ckpt["optimizer"])
+
+    gen = torch.Generator(device=dev).manual_seed(args.seed + local_rank)
+    os.makedirs(args.log_path, exist_ok=True)
+    for epoch in range(start_epoch, args.epochs):
+        model.train()
+        t0, seen, running = time.time(), 0, None
+        for it in range(args.steps_per_epoch):
+            derm, clinic = synthetic_batch(bs, args.img_sz, dev, gen)
+            if args.engine == "fused":
+                loss = trainer.step(derm, clinic)
+            else:
+                outputs = wrapped(derm, clinic, style)
+                w = 0.25 if style == 2 else 0.5
+                loss = criterion(*outputs[0]) + criterion(*outputs[1]) + sum(w * criterion(*o) for o in outputs[2])
+                optimizer.zero_grad(set_to_none=True)
+                loss.backward()
+                optimizer.step()
+            seen += bs * world
+            if local_rank == 0 and it % args.print_freq == 0:
+                running = float(loss)  # the only host sync, every print_freq steps
+                dt = time.time() - t0
+                print(f"Train epoch: [{epoch}][{it}/{args.steps_per_epoch}] Loss {running:.4f} "
+                      f"{seen / max(dt, 1e-9):.1f} pairs/s", flush=True)
+        if local_rank == 0:
+            state = {"epoch": epoch + 1, "state_dict": model.state_dict(),
+                     "optimizer": trainer.optimizer_state_dict() if args.engine == "fused" else optimizer.state_dict(),
+                     "scaler": {}}
+            path = os.path.join(args.log_path, "checkpoint.pth.tar")
+            torch.save(state, path)
+            if (epoch + 1) % args.save_freq == 0:
+                torch.save(state, os.path.join(args.log_path, f"ckp_{epoch + 1}.pth"))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    args = get_parser().parse_args()
+    args.world_size = int(os.environ.get("SM3_WORLD_SIZE", torch.cuda.device_count()))
+    try:
+        if args.world_size > 1:
+            mp.spawn(main, nprocs=args.world_size, args=(args,))
+        else:
+            main(0, args)
+    except Exception:
+        os.makedirs(args.log_path, exist_ok=True)
+        with open(os.path.join(args.log_path, "error.log"), "a") as f:
+            f.write(traceback.format_exc())
+        raise
