@@ -13,6 +13,8 @@
 // Reference call sites replaced: src/models/resnet.py:49-67 (conv3x3 / conv1x1) as used at
 // :144-148,:260; nn.Linear(bias=False) in src/models/simclr.py:17-27; and their autograd
 // data-gradients.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -32,6 +34,7 @@ struct ConvParams {
     FastDiv div_HoWo, div_Wo;
     int kchunks;  // K-steps per tap = Ci*sizeof(T)/128
     int tilesM, tilesN;
+    uint32_t x_bytes, w_bytes;  // buffer-descriptor extents (< 3 GB)
 };
 
 template <typename T>
@@ -56,8 +59,36 @@ __device__ __forceinline__ void mma_frag<float>(const uint4& a, const uint4& b, 
 // then hit 16 distinct 16-byte slots.
 __device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + (((c ^ (r >> 1)) & 7) << 4); }
 
+constexpr uint32_t kOOB = 0xC0000000u;  // voffset beyond any tensor (< 3 GB, checked on the host): reads zeros
+
+// LDS-DMA: buffer_load_dwordx4 ... lds.  One wave-instruction moves 8 tile rows x 128 B = 1 KiB straight from
+// global memory into LDS (destination = wave-uniform base + lane*16, source = per-lane offset), with no VGPR
+// staging and no ds_write (whose VGPR->LDS transfer, ~13 cycles per KiB, made the register-staged version of this
+// kernel LDS-bound: 830 write + 512 read LDS cycles against 1024 MFMA cycles per K-step pair).  The XOR swizzle
+// is applied on the SOURCE side: lane (row, pos) fetches chunk pos ^ key(row), so it lands where lds_off(row,
+// chunk) expects it.  Rows outside the image (padding), beyond M or beyond Cout use an out-of-range offset: the
+// buffer range check makes the DMA write zeros (verified on gfx950, scratch/glds_test.hip) -- no branches.
+//
+// The DMA is issued from inline asm on purpose: through the builtin, hipcc orders every later ds_read behind the
+// DMA with s_waitcnt vmcnt(0) (it cannot see that the DMA fills the OTHER stage), which serialises load and
+// compute.  In asm the compiler does not track it; we drain it ourselves (vmcnt(0)) right before the barrier that
+// publishes the stage.  M0 (LDS destination base) is saved/restored inside the statement (hipcc reserves it).
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t lds_wave_base, uint32_t voff, uint32_t soff) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_wave_base), "v"(voff), "s"(rsrc), "s"(soff)
+        : "memory");
+}
+__device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int RPP = NT / 8;  // rows covered per loader pass
     constexpr int AI = BM / RPP, BI = BN / RPP;
@@ -70,7 +101,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (LDS-DMA base goes to M0)
     const int wm = wave / WN, wn = wave % WN;
 
     // XCD-aware block remap (bijective): blocks that share an A row-panel run on one XCD's L2.
@@ -82,68 +114,60 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     const int bn = bid % p.tilesN, bm = bid / p.tilesN;
     const int m0 = bm * BM, n0 = bn * BN;
 
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
     // ---- loader state -------------------------------------------------------------------
-    const int c16 = tid & 7;
-    int a_n[AI], a_iy0[AI], a_ix0[AI];
+    // lane (row = (tid>>3) + i*RPP, pos = tid&7) of DMA instruction i; rows 8*wave + 32*i .. +7 per instruction
+    const int pos = tid & 7;
+    int a_pix[AI], a_iy0[AI], a_ix0[AI];  // pixel index of tap (0,0) and its coordinates; a_iy0 = -2^20 if row >= M
+    uint32_t a_ch[AI], a_off[AI], b_off[BI];
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-        const int m = m0 + (tid >> 3) + i * RPP;
+        const int r = (tid >> 3) + i * RPP;
+        a_ch[i] = (uint32_t)((pos ^ (r >> 1)) & 7) * 16u;  // source chunk of this lane (swizzle on the source side)
+        const int m = m0 + r;
         if (m < p.M) {
             const int n = fdiv(m, p.div_HoWo);
             const int rem = m - n * p.HoWo;
             const int oy = fdiv(rem, p.div_Wo);
             const int ox = rem - oy * p.Wo;
-            a_n[i] = n;
             a_iy0[i] = oy * p.sy;
             a_ix0[i] = ox * p.sx;
+            a_pix[i] = (n * p.Hi + a_iy0[i]) * p.Wi + a_ix0[i];
         } else {
-            a_n[i] = -1;
-            a_iy0[i] = 0;
+            a_iy0[i] = -(1 << 20);
             a_ix0[i] = 0;
+            a_pix[i] = 0;
         }
     }
-    const char* a_ptr[AI];
-    const char* b_ptr[BI];
-    uint4 ra[AI], rb[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int r = (tid >> 3) + i * RPP;
+        const int co = n0 + r;
+        b_off[i] = (co < p.Co) ? (uint32_t)co * (uint32_t)(p.w_row_stride * SZ) + (uint32_t)((pos ^ (r >> 1)) & 7) * 16u
+                               : kOOB;
+    }
+    const uint32_t row_bytes = (uint32_t)p.Ci * SZ;
 
     auto set_tap = [&](int t) {
         const int ddy = p.dy[t], ddx = p.dx[t];
+        const int dpix = ddy * p.Wi + ddx;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             const int iy = a_iy0[i] + ddy, ix = a_ix0[i] + ddx;
-            const bool ok = (a_n[i] >= 0) && ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi);
-            const long pix = ((long)a_n[i] * p.Hi + iy) * p.Wi + ix;
-            a_ptr[i] = ok ? p.x + pix * (long)p.Ci * SZ + c16 * 16 : nullptr;
-        }
-        const long woff = (long)p.wtap[t] * p.Ci * SZ + c16 * 16;
-#pragma unroll
-        for (int i = 0; i < BI; ++i) {
-            const int co = n0 + (tid >> 3) + i * RPP;
-            b_ptr[i] = (co < p.Co) ? p.w + (long)co * p.w_row_stride * SZ + woff : nullptr;
+            const bool ok = ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi);
+            a_off[i] = ok ? (uint32_t)(a_pix[i] + dpix) * row_bytes + a_ch[i] : kOOB;
         }
     };
-    auto load_regs = [&](int kc) {
-        const long koff = (long)kc * 128;
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+    auto dma_stage = [&](int stage, uint32_t soff_a, uint32_t soff_b) {
+        const uint32_t sA = smem_lds + (uint32_t)(stage * STAGE + wave * (8 * 128));
+        const uint32_t sB = sA + A_BYTES;
 #pragma unroll
-        for (int i = 0; i < AI; ++i)
-            ra[i] = a_ptr[i] ? *reinterpret_cast<const uint4*>(a_ptr[i] + koff) : make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < AI; ++i) dma16(rx, sA + i * (RPP * 128), a_off[i], soff_a);
 #pragma unroll
-        for (int i = 0; i < BI; ++i)
-            rb[i] = b_ptr[i] ? *reinterpret_cast<const uint4*>(b_ptr[i] + koff) : make_uint4(0, 0, 0, 0);
-    };
-    auto store_lds = [&](int stage) {
-        char* sA = smem + stage * STAGE;
-        char* sB = sA + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            const int r = (tid >> 3) + i * RPP;
-            *reinterpret_cast<uint4*>(sA + lds_off(r, c16)) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < BI; ++i) {
-            const int r = (tid >> 3) + i * RPP;
-            *reinterpret_cast<uint4*>(sB + lds_off(r, c16)) = rb[i];
-        }
+        for (int i = 0; i < BI; ++i) dma16(rw, sB + i * (RPP * 128), b_off[i], soff_b);
     };
 
     f32x16 acc[TM][TN];
@@ -154,47 +178,47 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // fragment read offsets: chunk (2*kk + fh) of row r sits at r*128 + (((2*kk+fh) ^ (r>>1)) & 7) * 16
+    //   = base(r, fh) ^ (kk << 5)   (bits 5-6 of the offset carry kk; r*128 leaves them clear)
+    const int frow = lane & 31, fh = lane >> 5;
+    uint32_t fa_base[TM], fb_base[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa_base[i] = lds_off(wm * WTM + i * 32 + frow, fh);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb_base[j] = A_BYTES + lds_off(wn * WTN + j * 32 + frow, fh);
+
     const int nsteps = p.ntaps * p.kchunks;
     int t = 0, kc = 0;
+    uint32_t wtap_off = (uint32_t)p.wtap[0] * row_bytes;
     set_tap(0);
-    load_regs(0);
-    store_lds(0);
-    __syncthreads();
-
-    const int frow = lane & 31, fh = lane >> 5;
+    dma_stage(0, 0, wtap_off);
+    dma_drain();
+    __syncthreads();  // publishes the stage
     for (int s = 0; s < nsteps; ++s) {
-        const bool more = (s + 1 < nsteps);
-        if (more) {
+        if (s + 1 < nsteps) {
             if (++kc == p.kchunks) {
                 kc = 0;
                 ++t;
                 set_tap(t);
+                wtap_off = (uint32_t)p.wtap[t] * row_bytes;
             }
-            load_regs(kc);
+            dma_stage((s + 1) & 1, (uint32_t)kc * 128u, wtap_off + (uint32_t)kc * 128u);
         }
-        const char* sA = smem + (s & 1) * STAGE;
-        const char* sB = sA + A_BYTES;
+        const char* sS = smem + (s & 1) * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const int cc = 2 * kk + fh;
             uint4 fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int r = wm * WTM + i * 32 + frow;
-                fa[i] = *reinterpret_cast<const uint4*>(sA + lds_off(r, cc));
-            }
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(sS + (fa_base[i] ^ (kk << 5)));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int r = wn * WTN + j * 32 + frow;
-                fb[j] = *reinterpret_cast<const uint4*>(sB + lds_off(r, cc));
-            }
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const uint4*>(sS + (fb_base[j] ^ (kk << 5)));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) mma_frag<T>(fa[i], fb[j], acc[i][j]);
         }
-        if (more) store_lds((s + 1) & 1);
-        __syncthreads();
+        dma_drain();      // this wave's part of stage s+1 has landed
+        __syncthreads();  // everyone's has; and everyone is done reading stage s
     }
 
     // ---- epilogue -----------------------------------------------------------------------
@@ -326,6 +350,14 @@ int fill_params(const sm3_conv_desc* d, ConvParams& p, int sz) {
     p.div_Wo = make_fastdiv((uint32_t)p.Wo);
     p.kchunks = d->Ci * sz / 128;
     if ((d->Ho - 1) * d->osy + d->ooy >= d->Hout || (d->Wo - 1) * d->osx + d->oox >= d->Wout) return SM3_EINVAL;
+    // buffer descriptors address each operand with a 32-bit offset; 0xC0000000 must stay out of range
+    const long xb = (long)d->N * d->Hi * d->Wi * d->Ci * sz;
+    long wmax = 0;
+    for (int t = 0; t < d->ntaps; ++t) wmax = d->wtap[t] > wmax ? d->wtap[t] : wmax;
+    const long wb = ((long)(d->Co - 1) * d->w_row_stride + (wmax + 1) * d->Ci) * sz;
+    if (xb >= 0xC0000000L || wb >= 0xC0000000L) return SM3_EINVAL;
+    p.x_bytes = (uint32_t)xb;
+    p.w_bytes = (uint32_t)wb;
     return 0;
 }
 

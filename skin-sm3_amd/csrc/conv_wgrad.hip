@@ -13,6 +13,8 @@
 //
 // Reference call sites replaced: autograd weight-gradients of nn.Conv2d (src/models/resnet.py:49-67)
 // and nn.Linear (src/models/simclr.py:17-27) inside loss.backward() (tools/backbone_train.py:125).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -27,80 +29,142 @@ struct WgradParams {
     int w_row_stride;
     int HoWo, Wo;
     FastDiv div_HoWo, div_Wo;
-    int tilesCo, tilesCi;   // grid.x = tilesCo * ntaps * tilesCi
-    int k_per_split;        // pixels per grid.y slice (multiple of KP)
+    int tilesCo, tilesCi;   // tiles per pixel slice: gx = tilesCo * ntaps * tilesCi
+    int k_per_split;        // pixels per slice (multiple of KP)
+    int gx, splits;         // grid = gx * round_up(splits, 8), see the block -> (tile, slice) map in the kernel
+    uint32_t x_bytes;
 };
 
-constexpr int KP = 32;  // pixels per K-step
+constexpr uint32_t kOOB = 0xC0000000u;  // voffset beyond any tensor (< 3 GB, checked on the host): reads zeros
 
-template <typename T, int BMW, int BNW>
+// LDS-DMA (buffer_load_dwordx4 ... lds) issued from inline asm: see conv_igemm.hip for why (no VGPR staging, no
+// ds_write, zero-fill by the buffer range check, and hipcc must not order the ds_reads behind it).
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t lds_wave_base, uint32_t voff, uint32_t soff) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_wave_base), "v"(voff), "s"(rsrc), "s"(soff)
+        : "memory");
+}
+__device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// bf16 tiles are read with ds_read_b64_tr_b16, whose 16-lane groups fetch 4 pixel rows x 32 bytes: with the
+// unpadded pitch LDS-DMA needs (a wave-instruction writes 1 KiB contiguously) those 4 rows would share banks, so
+// bits 6-7 (256-byte rows) or bit 6 (128-byte rows) of the byte offset are XORed with a key of the pixel row --
+// applied on the DMA *source* chunk and on the read address alike.  f32 tiles are read along the channel axis
+// with ds_read_b32 and need no swizzle.
+template <int ROW_BYTES, bool BF16>
+__device__ __forceinline__ uint32_t swz_bytes(int row) {
+    if constexpr (!BF16) return 0u;
+    else if constexpr (ROW_BYTES == 256) return (uint32_t)(row & 3) << 6;
+    else return (uint32_t)((row >> 1) & 1) << 6;
+}
+
+// DENSE: 1x1 / stride 1 / no offset forward conv (X row of output pixel m is simply row m): every DMA offset is
+// a per-lane constant plus a scalar that advances by one K-step -- no VALU at all in the loop.
+template <typename T, int BMW, int BNW, int KP, bool DENSE>  // KP = pixels per K-step
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int SZ = sizeof(T);
     constexpr bool kBf16 = (SZ == 2);
-    constexpr int PAD = kBf16 ? 64 : 0;
-    constexpr int PITCH_A = BMW * SZ + PAD, PITCH_B = BNW * SZ + PAD;
-    constexpr int A_BYTES = KP * PITCH_A, B_BYTES = KP * PITCH_B, STAGE = A_BYTES + B_BYTES;
-    constexpr int CPR_A = BMW * SZ / 16, CPR_B = BNW * SZ / 16;  // 16-byte chunks per tile row
-    constexpr int AI = KP * CPR_A / 256, BI = KP * CPR_B / 256;
+    constexpr int RA = BMW * SZ, RB = BNW * SZ;                 // bytes per tile row (one pixel)
+    constexpr int A_BYTES = KP * RA, B_BYTES = KP * RB, STAGE = A_BYTES + B_BYTES;
+    constexpr int RPI_A = 1024 / RA, RPI_B = 1024 / RB;        // pixel rows per DMA wave-instruction
+    constexpr int AI = A_BYTES / 4096, BI = B_BYTES / 4096;    // DMA instructions per wave per K-step
     constexpr int WTM = BMW / 2, WTN = BNW / 2, TM = WTM / 32, TN = WTN / 32;
-    static_assert(AI >= 1 && BI >= 1 && TM >= 1 && TN >= 1, "tile too small");
+    static_assert(AI >= 1 && BI >= 1 && TM >= 1 && TN >= 1 && RA <= 512 && RB <= 512, "unsupported tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
-    int bx = blockIdx.x;
+    // Block -> (tile, pixel slice).  Workgroups are dealt round-robin over the 8 XCDs, so id & 7 labels the
+    // XCD group; inside a group consecutive workgroups walk all gx tiles of ONE pixel slice before moving to the
+    // next slice: the tiles of a slice re-read the same dY / X rows (18x re-read for a 3x3 256->256 layer) and
+    // now find them in their XCD's L2 instead of fetching them once per XCD.  Speed only, never correctness.
+    // With fewer than 8 slices that map would idle XCDs, so tiles simply go round-robin.
+    int bx, slice;
+    if (p.splits >= 8) {
+        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+        bx = q % p.gx;
+        slice = (q / p.gx) * 8 + xcd;
+    } else {
+        bx = blockIdx.x % p.gx;
+        slice = blockIdx.x / p.gx;
+    }
+    if (slice >= p.splits) return;
     const int tci = bx % p.tilesCi;
     bx /= p.tilesCi;
     const int tap = bx % p.ntaps;
     const int tco = bx / p.ntaps;
     const int co0 = tco * BMW, ci0 = tci * BNW;
-    const int kbeg = blockIdx.y * p.k_per_split;
+    const int kbeg = slice * p.k_per_split;
     const int kend = min(p.M, kbeg + p.k_per_split);
     if (kbeg >= kend) return;
     const int ddy = p.dyt[tap], ddx = p.dxt[tap];
 
-    uint4 ra[AI], rb[BI];
-    const int a_c = tid % CPR_A, a_r0 = tid / CPR_A;
-    const int b_c = tid % CPR_B, b_r0 = tid / CPR_B;
-    constexpr int A_RPP = 256 / CPR_A, B_RPP = 256 / CPR_B;
-    const bool a_col_ok = (co0 + a_c * (16 / SZ)) < p.Co;
-    const bool b_col_ok = (ci0 + b_c * (16 / SZ)) < p.Ci;
+    // descriptors: dY rows end at kend (rows of the next slice must read as zero); X is the whole tensor
+    const __amdgpu_buffer_rsrc_t rdy =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (uint32_t)kend * (uint32_t)(p.Co * SZ), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.x, 0, DENSE ? (uint32_t)kend * (uint32_t)(p.Ci * SZ) : p.x_bytes, 0x00020000);
 
-    auto load_regs = [&](int k0) {
+    // lane -> (row inside the DMA instruction, 16-byte chunk inside the row)
+    const int a_rin = (lane * 16) / RA, a_pos = ((lane * 16) % RA) / 16;
+    const int b_rin = (lane * 16) / RB, b_pos = ((lane * 16) % RB) / 16;
+    uint32_t a_off[AI], b_off[BI];
+    int b_row[BI];
+    uint32_t b_cho[BI];
 #pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            const int m = k0 + a_r0 + i * A_RPP;
-            ra[i] = make_uint4(0, 0, 0, 0);
-            if (m < kend && a_col_ok)
-                ra[i] = *reinterpret_cast<const uint4*>(p.dy + ((long)m * p.Co + co0) * SZ + a_c * 16);
-        }
+    for (int i = 0; i < AI; ++i) {
+        const int r = (wave + 4 * i) * RPI_A + a_rin;  // pixel row inside the K-step
+        const uint32_t lchunk = ((uint32_t)a_pos * 16u) ^ swz_bytes<RA, kBf16>(r);
+        const bool col_ok = co0 + (int)(lchunk / SZ) < p.Co;
+        a_off[i] = col_ok ? (uint32_t)(kbeg + r) * (uint32_t)(p.Co * SZ) + (uint32_t)(co0 * SZ) + lchunk : kOOB;
+    }
 #pragma unroll
-        for (int i = 0; i < BI; ++i) {
-            const int m = k0 + b_r0 + i * B_RPP;
-            rb[i] = make_uint4(0, 0, 0, 0);
-            if (m < kend && b_col_ok) {
-                const int n = fdiv(m, p.div_HoWo);
-                const int rem = m - n * p.HoWo;
-                const int oy = fdiv(rem, p.div_Wo);
-                const int ox = rem - oy * p.Wo;
-                const int iy = oy * p.sy + ddy, ix = ox * p.sx + ddx;
-                if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) {
-                    const long pix = ((long)n * p.Hi + iy) * p.Wi + ix;
-                    rb[i] = *reinterpret_cast<const uint4*>(p.x + (pix * p.Ci + ci0) * SZ + b_c * 16);
+    for (int i = 0; i < BI; ++i) {
+        const int r = (wave + 4 * i) * RPI_B + b_rin;
+        const uint32_t lchunk = ((uint32_t)b_pos * 16u) ^ swz_bytes<RB, kBf16>(r);
+        const bool col_ok = ci0 + (int)(lchunk / SZ) < p.Ci;
+        b_row[i] = col_ok ? r : -(1 << 28);
+        b_cho[i] = (uint32_t)(ci0 * SZ) + lchunk;
+        b_off[i] = col_ok ? (uint32_t)(kbeg + r) * (uint32_t)(p.Ci * SZ) + b_cho[i] : kOOB;  // DENSE form
+    }
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+
+    auto dma_stage = [&](int stage, int step) {
+        const uint32_t sA = smem_lds + (uint32_t)(stage * STAGE) + (uint32_t)wave * 1024u;
+        const uint32_t sB = sA + A_BYTES;
+        const uint32_t soff_a = (uint32_t)(step * KP) * (uint32_t)(p.Co * SZ);
+#pragma unroll
+        for (int i = 0; i < AI; ++i) dma16(rdy, sA + i * 4096, a_off[i], soff_a);
+        if constexpr (DENSE) {
+            const uint32_t soff_b = (uint32_t)(step * KP) * (uint32_t)(p.Ci * SZ);
+#pragma unroll
+            for (int i = 0; i < BI; ++i) dma16(rx, sB + i * 4096, b_off[i], soff_b);
+        } else {
+#pragma unroll
+            for (int i = 0; i < BI; ++i) {
+                const int m = kbeg + step * KP + b_row[i];
+                uint32_t off = kOOB;
+                if (m >= 0 && m < kend) {
+                    const int n = fdiv(m, p.div_HoWo);
+                    const int rem = m - n * p.HoWo;
+                    const int oy = fdiv(rem, p.div_Wo);
+                    const int ox = rem - oy * p.Wo;
+                    const int iy = oy * p.sy + ddy, ix = ox * p.sx + ddx;
+                    if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+                        off = (uint32_t)((n * p.Hi + iy) * p.Wi + ix) * (uint32_t)(p.Ci * SZ) + b_cho[i];
                 }
+                dma16(rx, sB + i * 4096, off, 0u);
             }
         }
-    };
-    auto store_lds = [&](int stage) {
-        char* sA = smem + stage * STAGE;
-        char* sB = sA + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < AI; ++i)
-            *reinterpret_cast<uint4*>(sA + (a_r0 + i * A_RPP) * PITCH_A + a_c * 16) = ra[i];
-#pragma unroll
-        for (int i = 0; i < BI; ++i)
-            *reinterpret_cast<uint4*>(sB + (b_r0 + i * B_RPP) * PITCH_B + b_c * 16) = rb[i];
     };
 
     f32x16 acc[TM][TN];
@@ -111,44 +175,55 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // per-lane fragment read offsets
+    uint32_t ra_off[TM], rb_off[TN];
+    if constexpr (kBf16) {
+        // transposing read: 16-lane group g reads a 4(k) x 16(channel) block; lane 4q+pq supplies the address of
+        // k-row q, channels 4pq..4pq+3, and receives the 4 k values of channel (lane & 15).
+        const int g = lane >> 4, ii = lane & 15, q = ii >> 2, pq = ii & 3, h = g >> 1;
+        const int colsel = 16 * (g & 1) + 4 * pq;
+        const int krow0 = 8 * h + q;  // + 16*ks (+4 for the second half): the swizzle key of the row is that of q
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            ra_off[i] = (uint32_t)krow0 * RA + (((uint32_t)(wm * WTM + i * 32 + colsel) * 2u) ^ swz_bytes<RA, true>(q));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            rb_off[j] = A_BYTES + (uint32_t)krow0 * RB + (((uint32_t)(wn * WTN + j * 32 + colsel) * 2u) ^ swz_bytes<RB, true>(q));
+    } else {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ra_off[i] = (uint32_t)h * RA + (uint32_t)(wm * WTM + i * 32 + r) * 4u;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) rb_off[j] = A_BYTES + (uint32_t)h * RB + (uint32_t)(wn * WTN + j * 32 + r) * 4u;
+    }
+
     const int nsteps = (kend - kbeg + KP - 1) / KP;
-    load_regs(kbeg);
-    store_lds(0);
+    dma_stage(0, 0);
+    dma_drain();
     __syncthreads();
 
     for (int s = 0; s < nsteps; ++s) {
-        const bool more = (s + 1 < nsteps);
-        if (more) load_regs(kbeg + (s + 1) * KP);
-        const char* sA = smem + (s & 1) * STAGE;
-        const char* sB = sA + A_BYTES;
+        if (s + 1 < nsteps) dma_stage((s + 1) & 1, s + 1);
+        const char* sS = smem + (s & 1) * STAGE;
         if constexpr (kBf16) {
-            // transposing read: 16-lane group g reads a 4(k) x 16(channel) block; lane 4q+p supplies the
-            // address of k-row q, channels 4p..4p+3, and receives the 4 k values of channel (lane & 15).
-            const int g = lane >> 4, ii = lane & 15, q = ii >> 2, pq = ii & 3, h = g >> 1;
-            const int colsel = 16 * (g & 1) + 4 * pq;
 #pragma unroll
             for (int ks = 0; ks < KP / 16; ++ks) {
-                const int krow = ks * 16 + 8 * h + q;
                 uint4 fa[TM], fb[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    const int col = wm * WTM + i * 32 + colsel;
-                    const char* a0 = sA + krow * PITCH_A + col * 2;
-                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(a0));
+                    const char* a0 = sS + ra_off[i] + ks * 16 * RA;
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
                     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(a0 + 4 * PITCH_A));
+                        (__attribute__((address_space(3))) s16x4*)(a0 + 4 * RA));
                     uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
                     fa[i] = make_uint4(l2.x, l2.y, h2.x, h2.y);
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const int col = wn * WTN + j * 32 + colsel;
-                    const char* b0 = sB + krow * PITCH_B + col * 2;
-                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(b0));
+                    const char* b0 = sS + rb_off[j] + ks * 16 * RB;
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b0));
                     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(b0 + 4 * PITCH_B));
+                        (__attribute__((address_space(3))) s16x4*)(b0 + 4 * RB));
                     uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
                     fb[j] = make_uint4(l2.x, l2.y, h2.x, h2.y);
                 }
@@ -160,17 +235,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
                             __builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
             }
         } else {
-            const int r = lane & 31, h = lane >> 5;
 #pragma unroll 4
             for (int ks = 0; ks < KP / 2; ++ks) {
-                const int krow = ks * 2 + h;
                 float fa[TM], fb[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    fa[i] = *reinterpret_cast<const float*>(sA + krow * PITCH_A + (wm * WTM + i * 32 + r) * 4);
+                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float*>(sS + ra_off[i] + ks * 2 * RA);
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    fb[j] = *reinterpret_cast<const float*>(sB + krow * PITCH_B + (wn * WTN + j * 32 + r) * 4);
+                for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const float*>(sS + rb_off[j] + ks * 2 * RB);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -178,7 +249,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }
         }
-        if (more) store_lds((s + 1) & 1);
+        dma_drain();
         __syncthreads();
     }
 
@@ -197,16 +268,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
             }
 }
 
-template <typename T, int BMW, int BNW>
-int launch_wgrad(WgradParams p, hipStream_t st) {
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+template <typename T, int BMW, int BNW, int KP, bool DENSE>
+int launch_wgrad_kp(WgradParams p, hipStream_t st) {
     constexpr int SZ = sizeof(T);
-    constexpr int PAD = (SZ == 2) ? 64 : 0;
-    constexpr int LDS = 2 * KP * ((BMW * SZ + PAD) + (BNW * SZ + PAD));
+    constexpr int LDS = 2 * KP * (BMW * SZ + BNW * SZ);
     p.tilesCo = (p.Co + BMW - 1) / BMW;
     p.tilesCi = (p.Ci + BNW - 1) / BNW;
     const long gx = (long)p.tilesCo * p.ntaps * p.tilesCi;
-    // split the pixel axis so that ~1024 workgroups are in flight, >= 8 K-steps each
-    long splits = (1024 + gx - 1) / gx;
+    // split the pixel axis so that ~target workgroups are in flight, >= 8 K-steps each.  Every workgroup ends
+    // with BMW*BNW f32 atomics, so the atomic traffic of a launch is ~target * 64 KB whatever the layer: at the
+    // chip's ~1.3 TB/s atomic rate 1024 workgroups cost 51 us per launch (12 ms per step); 512 halves that.
+    const long target = env_int("SM3_WGRAD_TARGET_CTAS", 512);
+    long splits = (target + gx - 1) / gx;
     const long max_splits = (p.M + KP * 8 - 1) / (KP * 8);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -214,7 +292,7 @@ int launch_wgrad(WgradParams p, hipStream_t st) {
     kps = (kps + KP - 1) / KP * KP;
     splits = (p.M + kps - 1) / kps;
     p.k_per_split = (int)kps;
-    auto kern = conv_wgrad_kernel<T, BMW, BNW>;
+    auto kern = conv_wgrad_kernel<T, BMW, BNW, KP, DENSE>;
     static bool attr_set = false;
     if (!attr_set && LDS > 65536) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -222,10 +300,23 @@ int launch_wgrad(WgradParams p, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    if (gx > 0x7fffffffL || splits > 65535) return SM3_EINVAL;
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)splits), dim3(256), LDS, st, p);
+    p.gx = (int)gx;
+    p.splits = (int)splits;
+    const long nblocks = gx * (splits >= 8 ? (splits + 7) / 8 * 8 : splits);
+    if (gx > 0x7fffffffL || nblocks > 0x7fffffffL) return SM3_EINVAL;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), LDS, st, p);
     SM3_CHECK_LAUNCH();
     return 0;
+}
+
+template <typename T, int BMW, int BNW>
+int launch_wgrad(WgradParams p, hipStream_t st) {
+    // K-step: 64 pixels in bf16, 32 in f32 (same 16-32 KB of tile bytes per stage)
+    constexpr int KP = sizeof(T) == 2 ? 64 : 32;
+    const bool dense = p.ntaps == 1 && p.sy == 1 && p.sx == 1 && p.dyt[0] == 0 && p.dxt[0] == 0 &&
+                       p.HoWo == p.Hi * p.Wi;
+    if (dense) return launch_wgrad_kp<T, BMW, BNW, KP, true>(p, st);
+    return launch_wgrad_kp<T, BMW, BNW, KP, false>(p, st);
 }
 
 }  // namespace
@@ -250,6 +341,9 @@ extern "C" int sm3_conv_wgrad(const sm3_conv_desc* d, const void* x, const void*
     p.HoWo = d->Ho * d->Wo; p.Wo = d->Wo;
     p.div_HoWo = make_fastdiv((uint32_t)p.HoWo);
     p.div_Wo = make_fastdiv((uint32_t)p.Wo);
+    const long xb = (long)d->N * d->Hi * d->Wi * d->Ci * sz, yb = M * d->Co * sz;
+    if (xb >= 0xC0000000L || yb >= 0xC0000000L) return SM3_EINVAL;  // 32-bit buffer offsets
+    p.x_bytes = (uint32_t)xb;
     hipStream_t st = (hipStream_t)stream;
     const bool nco = d->Co <= 64, nci = d->Ci <= 64;
     if (d->dtype == SM3_BF16) {

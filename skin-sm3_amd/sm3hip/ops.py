@@ -153,7 +153,10 @@ def conv_gemm(desc, x, w, y, addend=None, partials=None):
     sz = _sz(desc.dtype)
     nbytes = sz * (min(x.numel(), M * desc.ntaps * desc.Ci) + M * desc.Co * (2 if addend is not None else 1)
                    + desc.Co * desc.ntaps * desc.Ci)
-    with _prof("conv_gemm_128x64" if desc.Co <= 64 else "conv_gemm_128x128", flops, nbytes):
+    tag = "conv_gemm_128x64" if desc.Co <= 64 else "conv_gemm_128x128"
+    if _PROFILER is not None and getattr(_PROFILER, "detail", False):
+        tag += f"|M{M}_K{desc.ntaps}x{desc.Ci}_N{desc.Co}_s{desc.osy}"
+    with _prof(tag, flops, nbytes):
         check(_lib.load().sm3_conv_gather_gemm(C.byref(desc), _ptr(x), _ptr(w), _ptr(y), _ptr(addend),
                                                _ptr(partials), _stream()), "sm3_conv_gather_gemm")
 
@@ -169,7 +172,10 @@ def conv_wgrad(desc, x, dy, dw):
         raise ValueError("dw too small")
     M = desc.N * desc.Ho * desc.Wo
     sz = _sz(desc.dtype)
-    with _prof("conv_wgrad", 2.0 * M * desc.Co * desc.ntaps * desc.Ci,
+    tag = "conv_wgrad"
+    if _PROFILER is not None and getattr(_PROFILER, "detail", False):
+        tag += f"|M{M}_K{desc.ntaps}x{desc.Ci}_N{desc.Co}"
+    with _prof(tag, 2.0 * M * desc.Co * desc.ntaps * desc.Ci,
                sz * (x.numel() + dy.numel()) + 4 * desc.Co * desc.w_row_stride):
         check(_lib.load().sm3_conv_wgrad(C.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _stream()), "sm3_conv_wgrad")
 

@@ -4,12 +4,13 @@ import torch
 
 
 class Profiler:
-    def __init__(self, only=None):
+    def __init__(self, only=None, detail=False):
         self.only = only
+        self.detail = detail  # conv tags carry the GEMM shape
         self.records = []  # (tag, flops, bytes, start, end)
 
     def wants(self, tag):
-        return self.only is None or tag in self.only
+        return self.only is None or tag.split("|")[0] in self.only
 
     def begin(self):
         e = torch.cuda.Event(enable_timing=True)
