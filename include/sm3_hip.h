@@ -67,6 +67,23 @@ int sm3_conv_partial_rows(const sm3_conv_desc* d);
 int sm3_conv_gather_gemm(const sm3_conv_desc* d, const void* x, const void* w, void* y,
                          const void* addend, float* stat_partials, void* stream);
 
+/* Data-gradient launch with the FIRST phase of the next BatchNorm backward fused into its epilogue.  The
+ * gather-GEMM result (+addend) is dy of a BatchNorm output y = relu?(bn(x)); instead of storing dy this stores
+ * dz = dy * (y > 0) (relu_mask NULL: no ReLU) and writes per-row-block partial sums of (dz, dz * xhat) for the
+ * channels of y -- exactly what sm3_bn_bwd_reduce would produce from a second pass over dy, y and x.
+ * partials: [partial_row_offset + sm3_conv_partial_rows(d)][2][Co]; parity launches of a stride-2 gradient use
+ * consecutive row offsets.  x / relu_mask are indexed like dz_out. */
+typedef struct sm3_bn_bwd_fuse {
+    const uint8_t* relu_mask;
+    const void* x;
+    const float* mean;
+    const float* invstd;
+    float* partials;
+    int32_t partial_row_offset;
+} sm3_bn_bwd_fuse;
+int sm3_conv_dgrad_bnfuse(const sm3_conv_desc* d, const void* dy_in, const void* w_dgrad, void* dz_out,
+                          const void* addend, const sm3_bn_bwd_fuse* fuse, void* stream);
+
 /* Weight gradient of the forward conv described by d (autograd of the same call sites):
  *   dw[co*w_row_stride + wtap[t]*Ci + ci] += sum_{n,oy,ox} dy[(n,oy,ox), co] * x[n, oy*sy+dy[t], ox*sx+dx[t], ci]
  * dy is dense [N*Ho*Wo, Co]; dw is fp32 and is accumulated into (float atomics, split over pixels).
@@ -80,11 +97,15 @@ int sm3_conv_wgrad(const sm3_conv_desc* d, const void* x, const void* dy, float*
 /* sums[0..C) = sum over partial rows of p[r][0][c]; sums[C..2C) likewise of p[r][1][c]  (fp64, deterministic
  * two-stage reduction).  workspace: SM3_BN_REDUCE_GROUPS * 2C doubles. */
 #define SM3_BN_REDUCE_GROUPS 64
+/* number of fp64 [2C] rows stage A leaves in workspace for `rows` partial rows */
+int sm3_bn_reduce_groups(int rows);
+/* sums == NULL: only stage A runs; pass (workspace, sm3_bn_reduce_groups(rows)) to sm3_bn_finalize */
 int sm3_bn_stats_reduce(const float* partials, int rows, int C, double* sums, double* workspace, void* stream);
 /* From (possibly all-reduced) sums and the global element count per channel: mean, biased var ->
  * scale = gamma*invstd, shift = beta - mean*scale; running stats momentum update with the unbiased
  * variance; saves mean / invstd for backward.  gamma/beta NULL => affine=False. */
-int sm3_bn_finalize(const double* sums, double count, int C, const float* gamma, const float* beta,
+int sm3_bn_finalize(const double* sums, int groups /* sums is [groups][2C], summed here */, double count, int C,
+                    const float* gamma, const float* beta,
                     float eps, float momentum, float* running_mean, float* running_var,
                     int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean,
                     float* save_invstd, void* stream);
@@ -93,14 +114,18 @@ int sm3_bn_eval_scale_shift(const float* gamma, const float* beta, const float* 
                             const float* running_var, float eps, int C, float* scale, float* shift,
                             void* stream);
 /* y = [relu]( x*scale + shift [+ residual] ), x,residual,y: [rows, C] of dtype; out_f32 != 0 stores y as fp32.
+ * relu_mask (nullable, with relu): one byte per 16-byte vector of y, bit e = (y[e] > 0) -- all that the backward
+ * pass needs of y, at 1/16 of its bytes.
  * replaces the bn->relu / bn->add->relu chains of Bottleneck.forward (resnet.py:154-174). */
 int sm3_bn_act(int dtype, const void* x, const float* scale, const float* shift, const void* residual,
-               int relu, int out_f32, void* y, int64_t rows, int C, void* stream);
-/* Backward, phase 1: dz = dy * (y > 0 if y != NULL); writes dz (may alias dy; NULL to skip) and
+               int relu, int out_f32, void* y, uint8_t* relu_mask, int64_t rows, int C, void* stream);
+/* Backward, phase 1: dz = dy * (y > 0), the mask taken from relu_mask if given, else from y if given, else all
+ * ones; writes dz (may alias dy; NULL to skip) and
  * per-block partial sums [bwd_partial_rows][2][C] of (dz, dz * xhat), xhat = (x-mean)*invstd. */
 int sm3_bn_bwd_partial_rows(int64_t rows, int C);
-int sm3_bn_bwd_reduce(int dtype, const void* dy, const void* y, const void* x, const float* mean,
-                      const float* invstd, void* dz, int64_t rows, int C, float* partials, void* stream);
+int sm3_bn_bwd_reduce(int dtype, const void* dy, const void* y, const uint8_t* relu_mask, const void* x,
+                      const float* mean, const float* invstd, void* dz, int64_t rows, int C, float* partials,
+                      void* stream);
 /* Backward, phase 2: dx = gamma*invstd*(dz - sum_dz/count - xhat*sum_dz_xhat/count) with the
  * (all-reduced) global sums; dgamma += local sum(dz*xhat), dbeta += local sum(dz) (NULL to skip). */
 int sm3_bn_bwd_apply(int dtype, const void* dz, const void* x, const float* mean, const float* invstd,
@@ -114,9 +139,11 @@ int sm3_bn_bwd_apply(int dtype, const void* dz, const void* x, const float* mean
 /* 7x7/2 pad-3 im2col of an NCHW fp32 image batch into rows [N*Ho*Wo, Kpad] of dtype,
  * k = (kh*7+kw)*3 + c for k < 147, zero for 147 <= k < Kpad. */
 int sm3_stem_im2col(int dtype, const float* x_nchw, void* cols, int N, int H, int W, int Kpad, void* stream);
-int sm3_maxpool3x3s2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream);
-/* dx[argmax window position] += dy, argmax recomputed from x (first maximum in (kh,kw) scan order) */
-int sm3_maxpool3x3s2_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int C, void* stream);
+/* argmax (nullable): [N,Ho,Wo,C] bytes, window position kh*3+kw of the first maximum in scan order (ATen's tie rule) */
+int sm3_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* argmax, int N, int H, int W, int C, void* stream);
+/* dx[n,iy,ix,c] = sum of dy over the windows whose recorded argmax is (iy,ix); gather form, no atomics */
+int sm3_maxpool3x3s2_bwd(int dtype, const uint8_t* argmax, const void* dy, void* dx, int N, int H, int W, int C,
+                         void* stream);
 /* feat[n,c] = mean over HW; feat_f32 and feat_t (dtype copy for the projector GEMM) both optional */
 int sm3_avgpool_fwd(int dtype, const void* x, float* feat_f32, void* feat_t, int N, int HW, int C, void* stream);
 int sm3_avgpool_bwd(int dtype, const void* dfeat, void* dx, int N, int HW, int C, void* stream);
@@ -128,6 +155,14 @@ int sm3_avgpool_bwd(int dtype, const void* dfeat, void* dx, int N, int HW, int C
  * ------------------------------------------------------------------------------------------ */
 int sm3_weight_prep(int dtype, const float* w, int Co, int taps, int Ci, void* w_fwd, int ld_fwd,
                     void* w_dgrad, void* stream);
+/* the same for n filter banks in ONE launch; items_device: device array of n descriptors */
+typedef struct sm3_wprep_item {
+    const float* w;
+    void* w_fwd;
+    void* w_dgrad;
+    int32_t Co, taps, Ci, ld_fwd;
+} sm3_wprep_item;
+int sm3_weight_prep_batch(int dtype, const sm3_wprep_item* items_device, int n, void* stream);
 /* elementwise cast fp32 -> dtype */
 int sm3_cast_from_f32(int dtype, const float* src, void* dst, int64_t n, void* stream);
 int sm3_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, void* stream);

@@ -27,7 +27,7 @@ static RowWalk make_walk(int64_t rows, int cvecs, int max_gy) {
     w.tby = 256 / w.tbx;
     if (w.tby < 1) w.tby = 1;
     w.gx = (cvecs + w.tbx - 1) / w.tbx;
-    int64_t gy = (rows + (int64_t)w.tby * 4 - 1) / ((int64_t)w.tby * 4);
+    int64_t gy = (rows + (int64_t)w.tby * 8 - 1) / ((int64_t)w.tby * 8);  // >= 8 rows per thread
     if (gy > max_gy) gy = max_gy;
     if (gy < 1) gy = 1;
     w.gy = (int)gy;
@@ -59,15 +59,20 @@ __global__ void bn_stats_reduce_b(const double* __restrict__ ws, int G, int C, d
     sums[col] = a;
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, int C, const float* gamma,
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int groups, double count, int C, const float* gamma,
                                    const float* beta, float eps, float momentum, float* running_mean,
                                    float* running_var, int64_t* nbt, float* scale, float* shift, float* save_mean,
                                    float* save_invstd) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && nbt) nbt[0] += 1;
     if (c >= C) return;
-    const double mean = sums[c] / count;
-    double var = sums[C + c] / count - mean * mean;
+    double s1 = 0.0, s2 = 0.0;
+    for (int g = 0; g < groups; ++g) {  // groups > 1: stage B of the statistics reduction folded in here
+        s1 += sums[(long)g * 2 * C + c];
+        s2 += sums[(long)g * 2 * C + C + c];
+    }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
     if (var < 0) var = 0;
     const double invstd = 1.0 / sqrt(var + (double)eps);
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -96,8 +101,8 @@ __global__ void bn_eval_kernel(const float* gamma, const float* beta, const floa
 template <typename T, bool OUT_F32>
 __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, const T* __restrict__ res,
-                                                     int relu, void* __restrict__ y, int64_t rows, int C, int tbx,
-                                                     int tby) {
+                                                     int relu, void* __restrict__ y, uint8_t* __restrict__ mask,
+                                                     int64_t rows, int C, int tbx, int tby) {
     constexpr int E = ElemTraits<T>::kPer16B;
     const int tx = threadIdx.x % tbx, ty = threadIdx.x / tbx;
     const int cv = blockIdx.x * tbx + tx;
@@ -122,6 +127,12 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x, co
             for (int e = 0; e < E; ++e) v[e] += q[e];
         }
         if (relu) {
+            if (mask) {  // one bit per element (y > 0), one byte per 16-byte vector: what backward needs of y
+                unsigned m = 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) m |= (v[e] > 0.f ? 1u : 0u) << e;
+                mask[r * (C / E) + cv] = (uint8_t)m;
+            }
 #pragma unroll
             for (int e = 0; e < E; ++e) v[e] = fmaxf(v[e], 0.f);
         }
@@ -139,6 +150,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x, co
 // phase 1 of backward: relu mask, optional dz write-back, partial sums of dz and dz*xhat
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                            const uint8_t* __restrict__ mask,
                                                             const T* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, T* __restrict__ dz,
                                                             int64_t rows, int C, float* __restrict__ partials,
@@ -164,7 +176,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             float g[E], xv[E];
             unpack16<T>(*reinterpret_cast<const uint4*>(dy + off), g);
             unpack16<T>(*reinterpret_cast<const uint4*>(x + off), xv);
-            if (y) {
+            if (mask) {
+                const unsigned m = mask[r * (C / E) + cv];
+#pragma unroll
+                for (int e = 0; e < E; ++e) g[e] = ((m >> e) & 1u) ? g[e] : 0.f;
+                if (dz) *reinterpret_cast<uint4*>(dz + off) = pack16<T>(g);
+            } else if (y) {
                 float yv[E];
                 unpack16<T>(*reinterpret_cast<const uint4*>(y + off), yv);
 #pragma unroll
@@ -212,8 +229,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma,
-                                                           const double* __restrict__ gsums, double count,
-                                                           T* __restrict__ dx, int64_t rows, int C, int tbx, int tby) {
+                                                           const double* __restrict__ gsums, double inv_count,
+                                                           const double* __restrict__ lsums, float* dgamma,
+                                                           float* dbeta, T* __restrict__ dx, int64_t rows, int C,
+                                                           int tbx, int tby) {
     constexpr int E = ElemTraits<T>::kPer16B;
     const int tx = threadIdx.x % tbx, ty = threadIdx.x / tbx;
     const int cv = blockIdx.x * tbx + tx;
@@ -226,8 +245,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         is[e] = invstd[c];
         const float g = gamma ? gamma[c] : 1.f;
         k0[e] = g * is[e];                                  // dx = k0 * (dz - k1 - xhat * k2)
-        k1[e] = (float)(gsums[c] / count);
-        k2[e] = (float)(gsums[C + c] / count);
+        k1[e] = (float)(gsums[c] * inv_count);              // (no fp64 divide per thread: 16 of them cost more
+        k2[e] = (float)(gsums[C + c] * inv_count);          //  than the rows a thread walks)
+    }
+    if (blockIdx.y == 0 && ty == 0 && lsums) {  // parameter gradients from the LOCAL sums, once per channel
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int c = cv * E + e;
+            if (dbeta) dbeta[c] += (float)lsums[c];
+            if (dgamma) dgamma[c] += (float)lsums[C + c];
+        }
     }
     const int64_t rstep = (int64_t)gridDim.y * tby;
     for (int64_t r = (int64_t)blockIdx.y * tby + ty; r < rows; r += rstep) {
@@ -244,34 +271,34 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
-__global__ void bn_param_grad_kernel(const double* __restrict__ lsums, int C, float* dgamma, float* dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    if (dbeta) dbeta[c] += (float)lsums[c];
-    if (dgamma) dgamma[c] += (float)lsums[C + c];
-}
-
 }  // namespace
+
+extern "C" int sm3_bn_reduce_groups(int rows) {
+    if (rows <= 0) return SM3_EINVAL;
+    int G = (rows + 31) / 32;
+    return G > SM3_BN_REDUCE_GROUPS ? SM3_BN_REDUCE_GROUPS : G;
+}
 
 extern "C" int sm3_bn_stats_reduce(const float* partials, int rows, int C, double* sums, double* workspace,
                                    void* stream) {
-    if (!partials || !sums || !workspace || rows <= 0 || C <= 0) return SM3_EINVAL;
-    int G = (rows + 31) / 32;
-    if (G > SM3_BN_REDUCE_GROUPS) G = SM3_BN_REDUCE_GROUPS;
+    if (!partials || !workspace || rows <= 0 || C <= 0) return SM3_EINVAL;
+    const int G = sm3_bn_reduce_groups(rows);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_stats_reduce_a, dim3((2 * C + 63) / 64, G), dim3(256), 0, st, partials, rows, C, workspace);
     SM3_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_stats_reduce_b, dim3((2 * C + 255) / 256), dim3(256), 0, st, workspace, G, C, sums);
-    SM3_CHECK_LAUNCH();
+    if (sums) {  // sums == NULL: the caller hands workspace + groups to sm3_bn_finalize instead (one launch fewer)
+        hipLaunchKernelGGL(bn_stats_reduce_b, dim3((2 * C + 255) / 256), dim3(256), 0, st, workspace, G, C, sums);
+        SM3_CHECK_LAUNCH();
+    }
     return 0;
 }
 
-extern "C" int sm3_bn_finalize(const double* sums, double count, int C, const float* gamma, const float* beta,
+extern "C" int sm3_bn_finalize(const double* sums, int groups, double count, int C, const float* gamma, const float* beta,
                                float eps, float momentum, float* running_mean, float* running_var,
                                int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean,
                                float* save_invstd, void* stream) {
-    if (!sums || !scale || !shift || C <= 0 || count <= 0) return SM3_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, C,
+    if (!sums || !scale || !shift || C <= 0 || count <= 0 || groups < 1) return SM3_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, groups, count, C,
                        gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift,
                        save_mean, save_invstd);
     SM3_CHECK_LAUNCH();
@@ -289,7 +316,7 @@ extern "C" int sm3_bn_eval_scale_shift(const float* gamma, const float* beta, co
 }
 
 extern "C" int sm3_bn_act(int dtype, const void* x, const float* scale, const float* shift, const void* residual,
-                          int relu, int out_f32, void* y, int64_t rows, int C, void* stream) {
+                          int relu, int out_f32, void* y, uint8_t* relu_mask, int64_t rows, int C, void* stream) {
     if (!x || !scale || !shift || !y || rows <= 0 || C <= 0) return SM3_EINVAL;
     if (dtype != SM3_F32 && dtype != SM3_BF16) return SM3_EDTYPE;
     const int E = dtype == SM3_F32 ? 4 : 8;
@@ -300,13 +327,13 @@ extern "C" int sm3_bn_act(int dtype, const void* x, const float* scale, const fl
     if (dtype == SM3_F32) {
         // f32 storage: the two output forms coincide
         hipLaunchKernelGGL((bn_act_kernel<float, false>), grid, block, 0, st, (const float*)x, scale, shift,
-                           (const float*)residual, relu, y, rows, C, w.tbx, w.tby);
+                           (const float*)residual, relu, y, relu_mask, rows, C, w.tbx, w.tby);
     } else if (out_f32) {
         hipLaunchKernelGGL((bn_act_kernel<bf16_t, true>), grid, block, 0, st, (const bf16_t*)x, scale, shift,
-                           (const bf16_t*)residual, relu, y, rows, C, w.tbx, w.tby);
+                           (const bf16_t*)residual, relu, y, relu_mask, rows, C, w.tbx, w.tby);
     } else {
         hipLaunchKernelGGL((bn_act_kernel<bf16_t, false>), grid, block, 0, st, (const bf16_t*)x, scale, shift,
-                           (const bf16_t*)residual, relu, y, rows, C, w.tbx, w.tby);
+                           (const bf16_t*)residual, relu, y, relu_mask, rows, C, w.tbx, w.tby);
     }
     SM3_CHECK_LAUNCH();
     return 0;
@@ -324,8 +351,9 @@ extern "C" int sm3_bn_bwd_partial_rows(int64_t rows, int C) {
     return rows > 0 ? bwd_gy(rows) : SM3_EINVAL;
 }
 
-extern "C" int sm3_bn_bwd_reduce(int dtype, const void* dy, const void* y, const void* x, const float* mean,
-                                 const float* invstd, void* dz, int64_t rows, int C, float* partials, void* stream) {
+extern "C" int sm3_bn_bwd_reduce(int dtype, const void* dy, const void* y, const uint8_t* relu_mask, const void* x,
+                                 const float* mean, const float* invstd, void* dz, int64_t rows, int C,
+                                 float* partials, void* stream) {
     if (!dy || !x || !mean || !invstd || !partials || rows <= 0 || C <= 0) return SM3_EINVAL;
     if (dtype != SM3_F32 && dtype != SM3_BF16) return SM3_EDTYPE;
     const int E = dtype == SM3_F32 ? 4 : 8;
@@ -336,10 +364,10 @@ extern "C" int sm3_bn_bwd_reduce(int dtype, const void* dy, const void* y, const
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SM3_F32)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, block, 0, st, (const float*)dy, (const float*)y,
-                           (const float*)x, mean, invstd, (float*)dz, rows, C, partials, w.tbx, w.tby);
+                           relu_mask, (const float*)x, mean, invstd, (float*)dz, rows, C, partials, w.tbx, w.tby);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)y,
-                           (const bf16_t*)x, mean, invstd, (bf16_t*)dz, rows, C, partials, w.tbx, w.tby);
+                           relu_mask, (const bf16_t*)x, mean, invstd, (bf16_t*)dz, rows, C, partials, w.tbx, w.tby);
     SM3_CHECK_LAUNCH();
     return 0;
 }
@@ -357,15 +385,12 @@ extern "C" int sm3_bn_bwd_apply(int dtype, const void* dz, const void* x, const 
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SM3_F32)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, block, 0, st, (const float*)dz, (const float*)x, mean,
-                           invstd, gamma, global_sums, count, (float*)dx, rows, C, w.tbx, w.tby);
+                           invstd, gamma, global_sums, 1.0 / count, local_sums, dgamma, dbeta, (float*)dx, rows, C,
+                           w.tbx, w.tby);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)dz, (const bf16_t*)x, mean,
-                           invstd, gamma, global_sums, count, (bf16_t*)dx, rows, C, w.tbx, w.tby);
+                           invstd, gamma, global_sums, 1.0 / count, local_sums, dgamma, dbeta, (bf16_t*)dx, rows, C,
+                           w.tbx, w.tby);
     SM3_CHECK_LAUNCH();
-    if ((dgamma || dbeta) && local_sums) {
-        hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, local_sums, C, dgamma,
-                           dbeta);
-        SM3_CHECK_LAUNCH();
-    }
     return 0;
 }

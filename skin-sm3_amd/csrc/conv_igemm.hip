@@ -35,6 +35,13 @@ struct ConvParams {
     int kchunks;  // K-steps per tap = Ci*sizeof(T)/128
     int tilesM, tilesN;
     uint32_t x_bytes, w_bytes;  // buffer-descriptor extents (< 3 GB)
+    // optional fusion of the NEXT BatchNorm-backward's first phase into this (data-gradient) epilogue
+    const uint8_t* fz_mask;     // relu bits of that BN's output (1 byte per 16-byte vector), or null
+    const char* fz_x;           // that BN's input (its conv's output), same indexing as y; null = fusion off
+    const float* fz_mean;
+    const float* fz_invstd;
+    float* fz_partials;         // [fz_row_off + tilesM][2][Co]
+    int fz_row_off;
 };
 
 template <typename T>
@@ -222,6 +229,50 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
     }
 
     // ---- epilogue -----------------------------------------------------------------------
+    constexpr int EPC = 16 / SZ;     // elements per 16-byte store
+    constexpr int CPR = BN / EPC;    // stores per tile row
+    constexpr int RSTEP = NT / CPR;  // rows between two stores of one thread
+    constexpr int NROW = BM / RSTEP; // stores per thread
+    static_assert(NT % CPR == 0 && BM % RSTEP == 0, "a thread must keep one channel vector across its rows");
+    const bool dense = (p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.HWout == p.HoWo);
+    const bool fz = p.fz_x != nullptr;
+    const int cc = tid % CPR;        // fixed per thread
+    const int ncol = n0 + cc * EPC;
+    // Output offsets of this thread's NROW vectors, and -- issued NOW, so that their latency hides under the
+    // accumulator -> LDS staging below -- the loads the store loop needs (addend; fused BN-backward operands).
+    constexpr bool PRE = (NROW <= 8);        // f32 tiles have 16 vectors per thread: too many registers to hold
+    constexpr int NPRE = PRE ? NROW : 1;
+    long e_off[NROW];
+    uint4 pre_add[NPRE], pre_x[NPRE];
+    unsigned pre_mk[NPRE];
+#pragma unroll
+    for (int k = 0; k < NROW; ++k) {
+        const int m = m0 + tid / CPR + k * RSTEP;
+        e_off[k] = -1;
+        if constexpr (PRE) {
+            pre_add[k] = make_uint4(0, 0, 0, 0);
+            pre_x[k] = make_uint4(0, 0, 0, 0);
+            pre_mk[k] = 0xffu;
+        }
+        if (m < p.M && ncol < p.Co) {
+            long opix = m;
+            if (!dense) {
+                const int nn = fdiv(m, p.div_HoWo);
+                const int rem = m - nn * p.HoWo;
+                const int oy = fdiv(rem, p.div_Wo);
+                const int ox = rem - oy * p.Wo;
+                opix = (long)nn * p.HWout + (long)(oy * p.osy + p.ooy) * p.Wout + (ox * p.osx + p.oox);
+            }
+            e_off[k] = opix * p.Co + ncol;
+            if constexpr (PRE) {
+                if (p.addend) pre_add[k] = *reinterpret_cast<const uint4*>(p.addend + e_off[k] * SZ);
+                if (fz) {
+                    pre_x[k] = *reinterpret_cast<const uint4*>(p.fz_x + e_off[k] * SZ);
+                    if (p.fz_mask) pre_mk[k] = p.fz_mask[e_off[k] / EPC];
+                }
+            }
+        }
+    }
     float* sC = reinterpret_cast<float*>(smem);
     float* sStat = reinterpret_cast<float*>(smem + MAIN_BYTES);  // [WM][BN][2]
     if (p.partials) {
@@ -268,21 +319,21 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
         p.partials[((long)bm * 2 + 1) * p.Co + n0 + tid] = s2;
     }
 
-    constexpr int EPC = 16 / SZ;     // elements per 16-byte store
-    constexpr int CPR = BN / EPC;    // stores per tile row
-    const bool dense = (p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.HWout == p.HoWo);
-    for (int idx = tid; idx < BM * CPR; idx += NT) {
-        const int r = idx / CPR, cc = idx % CPR;
-        const int m = m0 + r, n = n0 + cc * EPC;
-        if (m >= p.M || n >= p.Co) continue;
-        long opix = m;
-        if (!dense) {
-            const int nn = fdiv(m, p.div_HoWo);
-            const int rem = m - nn * p.HoWo;
-            const int oy = fdiv(rem, p.div_Wo);
-            const int ox = rem - oy * p.Wo;
-            opix = (long)nn * p.HWout + (long)(oy * p.osy + p.ooy) * p.Wout + (ox * p.osx + p.oox);
-        }
+    // BN-backward phase 1 fused here (data-gradient launches): the value just computed is dy of the producer
+    // BatchNorm's output; mask it with that BN's ReLU bits, store dz instead of dy, and accumulate this tile's
+    // sum(dz), sum(dz * xhat) per channel -- saves a full read of dy, a read of the mask source and a write of dz.
+    float f_mu[EPC], f_is[EPC], f_s1[EPC], f_s2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        f_s1[e] = 0.f;
+        f_s2[e] = 0.f;
+        f_mu[e] = (fz && ncol < p.Co) ? p.fz_mean[ncol + e] : 0.f;
+        f_is[e] = (fz && ncol < p.Co) ? p.fz_invstd[ncol + e] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NROW; ++k) {
+        if (e_off[k] < 0) continue;
+        const int r = tid / CPR + k * RSTEP;
         float v[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; e += 4) {
@@ -292,14 +343,47 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
             v[e + 2] = q.z;
             v[e + 3] = q.w;
         }
-        const long boff = (opix * p.Co + n) * SZ;
+        const long boff = e_off[k] * SZ;
         if (p.addend) {
             float a[EPC];
-            unpack16<T>(*reinterpret_cast<const uint4*>(p.addend + boff), a);
+            unpack16<T>(PRE ? pre_add[PRE ? k : 0] : *reinterpret_cast<const uint4*>(p.addend + boff), a);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) v[e] += a[e];
         }
-        *reinterpret_cast<uint4*>(p.y + boff) = pack16<T>(v);
+        if (fz) {
+            float xv[EPC];
+            unpack16<T>(PRE ? pre_x[PRE ? k : 0] : *reinterpret_cast<const uint4*>(p.fz_x + boff), xv);
+            const unsigned mk = PRE ? pre_mk[PRE ? k : 0] : (p.fz_mask ? (unsigned)p.fz_mask[e_off[k] / EPC] : 0xffu);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) v[e] = ((mk >> e) & 1u) ? v[e] : 0.f;
+            const uint4 packed = pack16<T>(v);
+            float dzr[EPC];
+            unpack16<T>(packed, dzr);  // sums are those of the STORED (rounded) dz, as the standalone kernel's
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                f_s1[e] += dzr[e];
+                f_s2[e] += dzr[e] * (xv[e] - f_mu[e]) * f_is[e];
+            }
+            *reinterpret_cast<uint4*>(p.y + boff) = packed;
+        } else {
+            *reinterpret_cast<uint4*>(p.y + boff) = pack16<T>(v);
+        }
+    }
+    if (fz) {
+        __syncthreads();  // everyone is done reading sC: reuse it for the cross-thread reduction
+        float* sRed = reinterpret_cast<float*>(smem);  // [NT][2*EPC]
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            sRed[tid * 2 * EPC + e] = f_s1[e];
+            sRed[tid * 2 * EPC + EPC + e] = f_s2[e];
+        }
+        __syncthreads();
+        for (int o = tid; o < 2 * BN; o += NT) {
+            const int stat = o / BN, col = o % BN;  // channel n0+col lives in threads with cc == col/EPC
+            float a = 0.f;
+            for (int rl = 0; rl < NT / CPR; ++rl) a += sRed[(rl * CPR + col / EPC) * 2 * EPC + stat * EPC + col % EPC];
+            if (n0 + col < p.Co) p.fz_partials[((long)(p.fz_row_off + bm) * 2 + stat) * p.Co + n0 + col] = a;
+        }
     }
 }
 
@@ -369,9 +453,11 @@ extern "C" int sm3_conv_partial_rows(const sm3_conv_desc* d) {
     return (int)((M + kBM - 1) / kBM);
 }
 
-extern "C" int sm3_conv_gather_gemm(const sm3_conv_desc* d, const void* x, const void* w, void* y,
-                                    const void* addend, float* stat_partials, void* stream) {
+static int conv_gather_gemm_impl(const sm3_conv_desc* d, const void* x, const void* w, void* y, const void* addend,
+                                 float* stat_partials, const sm3_bn_bwd_fuse* fuse, void* stream) {
     if (!d || !x || !w || !y) return SM3_EINVAL;
+    if (fuse && (!fuse->x || !fuse->mean || !fuse->invstd || !fuse->partials || fuse->partial_row_offset < 0))
+        return SM3_EINVAL;
     if (d->dtype != SM3_F32 && d->dtype != SM3_BF16) return SM3_EDTYPE;
     ConvParams p;
     const int sz = d->dtype == SM3_F32 ? 4 : 2;
@@ -379,9 +465,26 @@ extern "C" int sm3_conv_gather_gemm(const sm3_conv_desc* d, const void* x, const
     if (rc) return rc;
     p.x = (const char*)x; p.w = (const char*)w; p.y = (char*)y; p.addend = (const char*)addend;
     p.partials = stat_partials;
+    p.fz_mask = fuse ? fuse->relu_mask : nullptr;
+    p.fz_x = fuse ? (const char*)fuse->x : nullptr;
+    p.fz_mean = fuse ? fuse->mean : nullptr;
+    p.fz_invstd = fuse ? fuse->invstd : nullptr;
+    p.fz_partials = fuse ? fuse->partials : nullptr;
+    p.fz_row_off = fuse ? fuse->partial_row_offset : 0;
     hipStream_t st = (hipStream_t)stream;
     const bool narrow = d->Co <= 64;
     if (d->dtype == SM3_BF16)
         return narrow ? launch_conv<bf16_t, kBM, 64, 2, 2>(p, st) : launch_conv<bf16_t, kBM, 128, 2, 2>(p, st);
     return narrow ? launch_conv<float, kBM, 64, 2, 2>(p, st) : launch_conv<float, kBM, 128, 2, 2>(p, st);
+}
+
+extern "C" int sm3_conv_gather_gemm(const sm3_conv_desc* d, const void* x, const void* w, void* y,
+                                    const void* addend, float* stat_partials, void* stream) {
+    return conv_gather_gemm_impl(d, x, w, y, addend, stat_partials, nullptr, stream);
+}
+
+extern "C" int sm3_conv_dgrad_bnfuse(const sm3_conv_desc* d, const void* dy_in, const void* w_dgrad, void* dz_out,
+                                     const void* addend, const sm3_bn_bwd_fuse* fuse, void* stream) {
+    if (!fuse) return SM3_EINVAL;
+    return conv_gather_gemm_impl(d, dy_in, w_dgrad, dz_out, addend, nullptr, fuse, stream);
 }

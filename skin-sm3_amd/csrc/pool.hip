@@ -47,8 +47,9 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restric
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H,
-                                                          int W, int C, int Ho, int Wo) {
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                          uint8_t* __restrict__ argmax, int N, int H, int W, int C,
+                                                          int Ho, int Wo) {
     constexpr int E = ElemTraits<T>::kPer16B;
     const int cv = C / E;
     const int64_t total = (int64_t)N * Ho * Wo * cv;
@@ -60,8 +61,12 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
         const int oy = (int)((pix / Wo) % Ho);
         const int n = (int)(pix / ((int64_t)Wo * Ho));
         float best[E];
+        int arg[E];  // window position kh*3+kw of the FIRST maximum (strict '>' in scan order, as ATen)
 #pragma unroll
-        for (int e = 0; e < E; ++e) best[e] = -INFINITY;
+        for (int e = 0; e < E; ++e) {
+            best[e] = -INFINITY;
+            arg[e] = -1;
+        }
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int iy = oy * 2 - 1 + kh;
@@ -73,17 +78,33 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
                 float v[E];
                 unpack16<T>(*reinterpret_cast<const uint4*>(x + (((int64_t)n * H + iy) * W + ix) * C + (int64_t)c * E), v);
 #pragma unroll
-                for (int e = 0; e < E; ++e) best[e] = fmaxf(best[e], v[e]);
+                for (int e = 0; e < E; ++e)
+                    if (v[e] > best[e] || arg[e] < 0) {
+                        best[e] = v[e];
+                        arg[e] = kh * 3 + kw;
+                    }
             }
         }
         *reinterpret_cast<uint4*>(y + pix * C + (int64_t)c * E) = pack16<T>(best);
+        if (argmax) {
+            uint8_t* a = argmax + pix * C + (int64_t)c * E;
+            if constexpr (E == 8) {
+                *reinterpret_cast<uint2*>(a) = make_uint2(
+                    (unsigned)arg[0] | ((unsigned)arg[1] << 8) | ((unsigned)arg[2] << 16) | ((unsigned)arg[3] << 24),
+                    (unsigned)arg[4] | ((unsigned)arg[5] << 8) | ((unsigned)arg[6] << 16) | ((unsigned)arg[7] << 24));
+            } else {
+                *reinterpret_cast<unsigned*>(a) =
+                    (unsigned)arg[0] | ((unsigned)arg[1] << 8) | ((unsigned)arg[2] << 16) | ((unsigned)arg[3] << 24);
+            }
+        }
     }
 }
 
-// gather form of the backward: input pixel (iy,ix) receives dy of every window whose FIRST maximum
-// (scan order kh, then kw, strict '>' as ATen) sits on it.  No atomics, deterministic.
+// gather form of the backward: input pixel (iy,ix) receives dy of every window whose FIRST maximum (recorded by
+// the forward pass as a window position 0..8) sits on it.  No atomics, deterministic; per input vector at most
+// 4 windows x (8-byte argmax + 16-byte dy) instead of re-scanning 4 x 9 input vectors.
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restrict__ argmax, const T* __restrict__ dy,
                                                           T* __restrict__ dx, int N, int H, int W, int C, int Ho,
                                                           int Wo) {
     constexpr int E = ElemTraits<T>::kPer16B;
@@ -99,43 +120,26 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
         float g[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) g[e] = 0.f;
-        const int oy_lo = max(0, (iy) / 2), oy_hi = min(Ho - 1, (iy + 1) / 2);
-        const int ox_lo = max(0, (ix) / 2), ox_hi = min(Wo - 1, (ix + 1) / 2);
+        const int oy_lo = iy / 2, oy_hi = min(Ho - 1, (iy + 1) / 2);
+        const int ox_lo = ix / 2, ox_hi = min(Wo - 1, (ix + 1) / 2);
         for (int oy = oy_lo; oy <= oy_hi; ++oy)
             for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-                float best[E];
-                int arg[E];
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    best[e] = -INFINITY;
-                    arg[e] = -1;
-                }
-                int self = -2;
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh) {
-                    const int yy = oy * 2 - 1 + kh;
-                    if ((unsigned)yy >= (unsigned)H) continue;
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        const int xx = ox * 2 - 1 + kw;
-                        if ((unsigned)xx >= (unsigned)W) continue;
-                        const int pos = kh * 3 + kw;
-                        if (yy == iy && xx == ix) self = pos;
-                        float v[E];
-                        unpack16<T>(*reinterpret_cast<const uint4*>(x + (((int64_t)n * H + yy) * W + xx) * C + (int64_t)c * E), v);
-#pragma unroll
-                        for (int e = 0; e < E; ++e)
-                            if (v[e] > best[e] || arg[e] < 0) {
-                                best[e] = v[e];
-                                arg[e] = pos;
-                            }
-                    }
+                const int self = (iy - (oy * 2 - 1)) * 3 + (ix - (ox * 2 - 1));
+                const int64_t o = (((int64_t)n * Ho + oy) * Wo + ox) * C + (int64_t)c * E;
+                unsigned a[2];
+                if constexpr (E == 8) {
+                    const uint2 q = *reinterpret_cast<const uint2*>(argmax + o);
+                    a[0] = q.x;
+                    a[1] = q.y;
+                } else {
+                    a[0] = *reinterpret_cast<const unsigned*>(argmax + o);
+                    a[1] = 0;
                 }
                 float d[E];
-                unpack16<T>(*reinterpret_cast<const uint4*>(dy + (((int64_t)n * Ho + oy) * Wo + ox) * C + (int64_t)c * E), d);
+                unpack16<T>(*reinterpret_cast<const uint4*>(dy + o), d);
 #pragma unroll
                 for (int e = 0; e < E; ++e)
-                    if (arg[e] == self) g[e] += d[e];
+                    if ((int)((a[e >> 2] >> (8 * (e & 3))) & 0xff) == self) g[e] += d[e];
             }
         *reinterpret_cast<uint4*>(dx + pix * C + (int64_t)c * E) = pack16<T>(g);
     }
@@ -212,6 +216,31 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, int Co, int taps
     }
 }
 
+// all filter banks of a model in one launch: blockIdx.y = bank, grid-stride over its elements
+template <typename T>
+__global__ __launch_bounds__(256) void weight_prep_batch_kernel(const sm3_wprep_item* __restrict__ items) {
+    const sm3_wprep_item it = items[blockIdx.y];
+    const float* __restrict__ w = it.w;
+    T* __restrict__ wf = reinterpret_cast<T*>(it.w_fwd);
+    T* __restrict__ wd = reinterpret_cast<T*>(it.w_dgrad);
+    const int Co = it.Co, taps = it.taps, Ci = it.Ci, ld = it.ld_fwd, K = taps * Ci;
+    const int64_t nf = wf ? (int64_t)Co * ld : 0;
+    const int64_t nd = wd ? (int64_t)Co * K : 0;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nf + nd;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        if (idx < nf) {
+            const int co = (int)(idx / ld), k = (int)(idx % ld);
+            store_elem<T>(wf + idx, k < K ? w[(int64_t)co * K + k] : 0.f);
+        } else {
+            const int64_t j = idx - nf;
+            const int co = (int)(j % Co);
+            const int t = (int)((j / Co) % taps);
+            const int ci = (int)(j / ((int64_t)Co * taps));
+            store_elem<T>(wd + j, w[((int64_t)co * taps + t) * Ci + ci]);
+        }
+    }
+}
+
 template <typename T>
 __global__ void cast_from_f32_kernel(const float* __restrict__ s, T* __restrict__ d, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -253,7 +282,8 @@ extern "C" int sm3_stem_im2col(int dtype, const float* x_nchw, void* cols, int N
     return 0;
 }
 
-extern "C" int sm3_maxpool3x3s2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream) {
+extern "C" int sm3_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* argmax, int N, int H, int W, int C,
+                                    void* stream) {
     if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) return SM3_EINVAL;
     const int E = dtype == SM3_F32 ? 4 : 8;
     if (C % E) return SM3_EALIGN;
@@ -261,23 +291,23 @@ extern "C" int sm3_maxpool3x3s2_fwd(int dtype, const void* x, void* y, int N, in
     const unsigned g = grid_for((int64_t)N * Ho * Wo * (C / E), 256, 1 << 20);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, (float*)y, N, H, W, C, Ho, Wo),
-               hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, Ho, Wo));
+               hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, (float*)y, argmax, N, H, W, C, Ho, Wo),
+               hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, argmax, N, H, W, C, Ho, Wo));
     SM3_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int sm3_maxpool3x3s2_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int C,
-                                    void* stream) {
-    if (!x || !dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0) return SM3_EINVAL;
+extern "C" int sm3_maxpool3x3s2_bwd(int dtype, const uint8_t* argmax, const void* dy, void* dx, int N, int H, int W,
+                                    int C, void* stream) {
+    if (!argmax || !dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0) return SM3_EINVAL;
     const int E = dtype == SM3_F32 ? 4 : 8;
     if (C % E) return SM3_EALIGN;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const unsigned g = grid_for((int64_t)N * H * W * (C / E), 256, 1 << 20);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, (const float*)dy, (float*)dx, N, H, W, C, Ho, Wo),
-               hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo));
+               hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(g), dim3(256), 0, st, argmax, (const float*)dy, (float*)dx, N, H, W, C, Ho, Wo),
+               hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, argmax, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo));
     SM3_CHECK_LAUNCH();
     return 0;
 }
@@ -320,6 +350,16 @@ extern "C" int sm3_weight_prep(int dtype, const float* w, int Co, int taps, int 
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(weight_prep_kernel<float>, dim3(g), dim3(256), 0, st, w, Co, taps, Ci, (float*)w_fwd, ld_fwd, (float*)w_dgrad),
                hipLaunchKernelGGL(weight_prep_kernel<bf16_t>, dim3(g), dim3(256), 0, st, w, Co, taps, Ci, (bf16_t*)w_fwd, ld_fwd, (bf16_t*)w_dgrad));
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_weight_prep_batch(int dtype, const sm3_wprep_item* items_device, int n, void* stream) {
+    if (!items_device || n <= 0 || n > 65535) return SM3_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(weight_prep_batch_kernel<float>, dim3(96, n), dim3(256), 0, st, items_device),
+               hipLaunchKernelGGL(weight_prep_batch_kernel<bf16_t>, dim3(96, n), dim3(256), 0, st, items_device));
     SM3_CHECK_LAUNCH();
     return 0;
 }

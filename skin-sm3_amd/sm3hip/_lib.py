@@ -26,6 +26,16 @@ class ConvDesc(C.Structure):
     ]
 
 
+class BnBwdFuse(C.Structure):
+    _fields_ = [("relu_mask", C.c_void_p), ("x", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
+                ("partials", C.c_void_p), ("partial_row_offset", C.c_int32)]
+
+
+class WPrepItem(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("w_fwd", C.c_void_p), ("w_dgrad", C.c_void_p),
+                ("Co", C.c_int32), ("taps", C.c_int32), ("Ci", C.c_int32), ("ld_fwd", C.c_int32)]
+
+
 _P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 _DESC = C.POINTER(ConvDesc)
 
@@ -35,17 +45,20 @@ SIGNATURES = {
     "sm3_abi_version": [],
     "sm3_conv_partial_rows": [_DESC],
     "sm3_conv_gather_gemm": [_DESC, _P, _P, _P, _P, _P, _P],
+    "sm3_conv_dgrad_bnfuse": [_DESC, _P, _P, _P, _P, _P, _P],
     "sm3_conv_wgrad": [_DESC, _P, _P, _P, _P],
     "sm3_bn_stats_reduce": [_P, _I, _I, _P, _P, _P],
-    "sm3_bn_finalize": [_P, _D, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
+    "sm3_bn_reduce_groups": [_I],
+    "sm3_bn_finalize": [_P, _I, _D, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
     "sm3_bn_eval_scale_shift": [_P, _P, _P, _P, _F, _I, _P, _P, _P],
-    "sm3_bn_act": [_I, _P, _P, _P, _P, _I, _I, _P, _L, _I, _P],
+    "sm3_bn_act": [_I, _P, _P, _P, _P, _I, _I, _P, _P, _L, _I, _P],
     "sm3_bn_bwd_partial_rows": [_L, _I],
-    "sm3_bn_bwd_reduce": [_I, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P],
+    "sm3_bn_bwd_reduce": [_I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P],
     "sm3_bn_bwd_apply": [_I, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _P, _L, _I, _P],
     "sm3_stem_im2col": [_I, _P, _P, _I, _I, _I, _I, _P],
-    "sm3_maxpool3x3s2_fwd": [_I, _P, _P, _I, _I, _I, _I, _P],
+    "sm3_maxpool3x3s2_fwd": [_I, _P, _P, _P, _I, _I, _I, _I, _P],
     "sm3_maxpool3x3s2_bwd": [_I, _P, _P, _P, _I, _I, _I, _I, _P],
+    "sm3_weight_prep_batch": [_I, _P, _I, _P],
     "sm3_avgpool_fwd": [_I, _P, _P, _P, _I, _I, _I, _P],
     "sm3_avgpool_bwd": [_I, _P, _P, _I, _I, _I, _P],
     "sm3_weight_prep": [_I, _P, _I, _I, _I, _P, _I, _P, _P],

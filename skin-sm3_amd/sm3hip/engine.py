@@ -152,7 +152,7 @@ class BNUnit:
 
 class Rec:
     """What one conv+BN(+act) application saves for backward."""
-    __slots__ = ("cu", "bu", "N", "H", "W", "Ho", "Wo", "x_in", "xo", "mean", "invstd", "y", "relu")
+    __slots__ = ("cu", "bu", "N", "H", "W", "Ho", "Wo", "x_in", "xo", "mean", "invstd", "y", "relu", "mask")
 
 
 class EncoderPlan:
@@ -227,6 +227,7 @@ class SM3Engine:
         self.stat_sync = None
         self.world_size = 1
         self.grad_ready = None  # callback(first_param_name, last_param_name) for gradient-bucket overlap
+        self.fuse_bn_bwd = True  # BN-backward phase 1 inside the data-gradient epilogue (sm3_conv_dgrad_bnfuse)
         self.branches = OrderedDict()
         self.cross = None
         if kind in ("v32", "v3"):
@@ -279,12 +280,22 @@ class SM3Engine:
                 raise RuntimeError(f"buffer {name} is on {b.device}, expected {device}: call module.to(device) first")
 
     def refresh_weights(self):
-        """fp32 master -> `dtype` filter banks (forward and data-gradient order); once per step."""
-        for cu in self._all_conv_units():
-            wname = cu.name + ".weight"
-            if wname not in self.store.offsets:
-                continue  # projector dropped by the caller (mlc_train.py:344-346 sets them to None)
-            cu.refresh(self.dtype, self.store.flat2d(self.store.flat_p, wname))
+        """fp32 master -> `dtype` filter banks (forward and data-gradient order); once per step, one launch."""
+        key = (self.store.flat_p.data_ptr(), len(self.store.names))
+        if getattr(self, "_wprep_key", None) != key:
+            items = []
+            for cu in self._all_conv_units():
+                wname = cu.name + ".weight"
+                if wname not in self.store.offsets:
+                    continue  # projector dropped by the caller (mlc_train.py:344-346 sets them to None)
+                m = self.store.flat2d(self.store.flat_p, wname)
+                if cu.stem:
+                    items.append((m, cu.w_fwd, None, cu.Co, 1, 147, STEM_KPAD))
+                else:
+                    items.append((m, cu.w_fwd, cu.w_dgrad, cu.Co, cu.taps, cu.Ci, cu.taps * cu.Ci))
+            self._wprep_table = ops.weight_prep_table(items, self.store.flat_p.device)
+            self._wprep_key = key
+        ops.weight_prep_batch(self.dtype, self._wprep_table)
 
     def _work(self, key, numel, dtype=torch.float32):
         t = self._ws.get(key)
@@ -316,38 +327,48 @@ class SM3Engine:
             prow = ops.conv_partial_rows(d)
             partials = self._work("partials", prow * 2 * C)
             ops.conv_gemm(d, x, cu.w_fwd, xo, None, partials)
-            sums = self._work("sums", 2 * 2048, torch.float64)
-            ops.bn_stats_reduce(partials, prow, C, sums)
-            count = rows
+            count, groups = rows, 1
             if self.stat_sync is not None:
+                sums = self._work("sums", 2 * 2048, torch.float64)
+                ops.bn_stats_reduce(partials, prow, C, sums)
                 self.stat_sync(sums[: 2 * C])
                 count = rows * self.world_size
+            else:  # single rank: stage B of the reduction is folded into bn_finalize (one launch fewer per BN)
+                sums, groups = ops.bn_stats_reduce(partials, prow, C, None)
             mean = torch.empty(C, dtype=torch.float32, device=dev)
             invstd = torch.empty(C, dtype=torch.float32, device=dev)
             ops.bn_finalize(sums, count, C, gamma, beta, BN_EPS, BN_MOMENTUM, rm, rv,
-                            self.buffers[bu.name + ".num_batches_tracked"], scale, shift, mean, invstd)
+                            self.buffers[bu.name + ".num_batches_tracked"], scale, shift, mean, invstd, groups=groups)
         else:
             ops.conv_gemm(d, x, cu.w_fwd, xo, None, None)
             ops.bn_eval_scale_shift(gamma, beta, rm, rv, BN_EPS, C, scale, shift)
         if y_out is None:
             y_out = torch.empty(rows, C, dtype=torch.float32 if out_f32 else self.tdt, device=dev)
-        ops.bn_act(self.dtype, xo, scale, shift, residual, relu, y_out, rows, C, out_f32=out_f32)
+        mask = None
+        if save is not None and relu:  # 1 bit per element of (y > 0): what backward needs instead of re-reading y
+            mask = torch.empty(rows * C // (16 // ops._sz(self.dtype)), dtype=torch.uint8, device=dev)
+        ops.bn_act(self.dtype, xo, scale, shift, residual, relu, y_out, rows, C, out_f32=out_f32, mask=mask)
         if save is not None:
             r = Rec()
             r.cu, r.bu, r.N, r.H, r.W, r.Ho, r.Wo = cu, bu, N, H, W, Ho, Wo
-            r.x_in, r.xo, r.mean, r.invstd, r.y, r.relu = x, xo, mean, invstd, y_out, relu
+            r.x_in, r.xo, r.mean, r.invstd, r.y, r.relu, r.mask = x, xo, mean, invstd, y_out, relu, mask
             save.append(r)
         return y_out, Ho, Wo
 
-    def bn_backward(self, r, dy, keep_dz):
+    def bn_backward(self, r, dy, keep_dz, fused_rows=None):
         """dy: gradient w.r.t. the unit's output (post-activation).  Masks it in place when the unit has a
-        ReLU.  Returns (gradient w.r.t. the conv output, dz = masked dy)."""
+        ReLU.  Returns (gradient w.r.t. the conv output, dz = masked dy).  fused_rows: dy was produced by a
+        data-gradient launch that already masked it and left `fused_rows` rows of partial sums in the
+        "fz_partials" workspace (conv_backward(..., fuse=r)): phase 1 is skipped."""
         C = r.cu.Co
         rows = r.xo.shape[0]
-        prow = ops.bn_bwd_partial_rows(rows, C)
-        bpart = self._work("partials", prow * 2 * C)
-        ops.bn_bwd_reduce(self.dtype, dy, r.y if r.relu else None, r.xo, r.mean, r.invstd,
-                          dy if r.relu else None, rows, C, bpart)
+        if fused_rows is None:
+            prow = ops.bn_bwd_partial_rows(rows, C)
+            bpart = self._work("partials", prow * 2 * C)
+            ops.bn_bwd_reduce(self.dtype, dy, None, r.xo, r.mean, r.invstd, dy if r.relu else None, rows, C, bpart,
+                              mask=r.mask if r.relu else None)
+        else:
+            prow, bpart = fused_rows, self._ws["fz_partials"]
         lsums = self._work("lsums", 2 * 2048, torch.float64)
         ops.bn_stats_reduce(bpart, prow, C, lsums)
         gsums, count = lsums, rows
@@ -364,26 +385,38 @@ class SM3Engine:
                          rows, C)
         return dxo, dy
 
-    def conv_backward(self, r, dxo, need_dx=True, addend=None, into=None):
+    def conv_backward(self, r, dxo, need_dx=True, addend=None, into=None, fuse=None):
+        """Weight gradient (accumulated into the flat gradient buffer) and, if need_dx, the data gradient.
+        fuse: the Rec of the conv+BN unit whose OUTPUT this data gradient is the gradient of; its BN-backward
+        phase 1 (ReLU mask + partial sums) then runs inside the data-gradient epilogue.
+        Returns (dx, fused_rows) -- fused_rows is None when nothing was fused."""
         cu = r.cu
         ops.conv_wgrad(cu.wgrad_desc(self.dtype, r.N, r.H, r.W), r.x_in, dxo, self._g(cu.name + ".weight"))
         if not need_dx:
-            return None
+            return None, None
         descs, full = cu.dgrad_descs(self.dtype, r.N, r.H, r.W)
         if into is not None:  # accumulate into an existing gradient
             for dd in descs:
                 ops.conv_gemm(dd, dxo, cu.w_dgrad, into, into, None)
-            return into
+            return into, None
         if full:
             dx = torch.empty(r.N * r.H * r.W, cu.Ci, dtype=self.tdt, device=dxo.device)
+            if fuse is not None and self.fuse_bn_bwd:
+                total = sum(ops.conv_partial_rows(dd) for dd in descs)
+                part = self._work("fz_partials", total * 2 * cu.Ci)
+                off = 0
+                for dd in descs:
+                    off += ops.conv_dgrad_bnfuse(dd, dxo, cu.w_dgrad, dx, addend, fuse.mask if fuse.relu else None,
+                                                 fuse.xo, fuse.mean, fuse.invstd, part, off)
+                return dx, off
             for dd in descs:
                 ops.conv_gemm(dd, dxo, cu.w_dgrad, dx, addend, None)
-            return dx
+            return dx, None
         dx = addend.clone() if addend is not None else torch.zeros(r.N * r.H * r.W, cu.Ci, dtype=self.tdt,
                                                                    device=dxo.device)
         for dd in descs:
             ops.conv_gemm(dd, dxo, cu.w_dgrad, dx, dx, None)
-        return dx
+        return dx, None
 
     # ---- encoder -------------------------------------------------------------------------
     def encoder_forward(self, plan, x, train, feat_f32, feat_t, save=None):
@@ -400,7 +433,8 @@ class SM3Engine:
         y, _, _ = self.conv_bn(plan.stem, plan.stem_bn, cols, N * Ho * Wo, 1, 1, True, None, train, recs)
         Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
         p = torch.empty(N * Hp * Wp, 64, dtype=self.tdt, device=x.device)
-        ops.maxpool_fwd(self.dtype, y, p, N, Ho, Wo, 64)
+        amax = torch.empty(N * Hp * Wp * 64, dtype=torch.uint8, device=x.device) if save is not None else None
+        ops.maxpool_fwd(self.dtype, y, p, N, Ho, Wo, 64, amax)
         cur, h, w = p, Hp, Wp
         block_recs = []
         for blk in plan.blocks:
@@ -416,7 +450,7 @@ class SM3Engine:
             cur, h, w = y3, h3, w3
         ops.avgpool_fwd(self.dtype, cur, feat_f32, feat_t, N, h * w, plan.out_dim)
         if save is not None:
-            save.append({"plan": plan, "stem": recs[0], "stem_hw": (Ho, Wo), "pool_hw": (Hp, Wp),
+            save.append({"plan": plan, "stem": recs[0], "stem_hw": (Ho, Wo), "pool_hw": (Hp, Wp), "argmax": amax,
                          "blocks": block_recs, "N": N, "last_hw": (h, w)})
 
     def encoder_backward(self, ctx, dfeat, last_view=True):
@@ -427,25 +461,29 @@ class SM3Engine:
         h, w = ctx["last_hw"]
         dcur = torch.empty(N * h * w, plan.out_dim, dtype=self.tdt, device=dfeat.device)
         ops.avgpool_bwd(self.dtype, dfeat, dcur, N, h * w, plan.out_dim)
+        fr = None  # rows of fused BN-backward partials that came with dcur
         for bi in range(len(plan.blocks) - 1, -1, -1):
             blk, br = plan.blocks[bi], ctx["blocks"][bi]
             if "cd" in blk:
                 r1, r2, rd, r3 = br
             else:
                 (r1, r2, r3), rd = br, None
-            dx3, dz = self.bn_backward(r3, dcur, keep_dz=True)
-            dy2 = self.conv_backward(r3, dx3)
+            dx3, dz = self.bn_backward(r3, dcur, keep_dz=True, fused_rows=fr)
+            dy2, fr2 = self.conv_backward(r3, dx3, fuse=r2)
             del dx3
-            dx2, _ = self.bn_backward(r2, dy2, keep_dz=False)
-            dy1 = self.conv_backward(r2, dx2)
+            dx2, _ = self.bn_backward(r2, dy2, keep_dz=False, fused_rows=fr2)
+            dy1, fr1 = self.conv_backward(r2, dx2, fuse=r1)
             del dx2, dy2
-            dx1, _ = self.bn_backward(r1, dy1, keep_dz=False)
+            dx1, _ = self.bn_backward(r1, dy1, keep_dz=False, fused_rows=fr1)
             if rd is not None:
                 dxd, _ = self.bn_backward(rd, dz, keep_dz=False)
-                din = self.conv_backward(r1, dx1)
+                din, _ = self.conv_backward(r1, dx1)
                 self.conv_backward(rd, dxd, into=din)
+                fr = None
             else:
-                din = self.conv_backward(r1, dx1, addend=dz)
+                # din is the gradient of the previous block's output = of its bn3 (+residual, ReLU) unit
+                prev_r3 = ctx["blocks"][bi - 1][-1] if bi > 0 else None
+                din, fr = self.conv_backward(r1, dx1, addend=dz, fuse=prev_r3)
             dcur = din
             if last_view and "cd" in blk and bi > 0:  # first block of a stage: the stage is complete
                 stage = blk["c1"].name.rsplit(".", 2)[0]  # e.g. derm_backbone.encoder.layer4
@@ -454,7 +492,7 @@ class SM3Engine:
         Ho, Wo = ctx["stem_hw"]
         rs = ctx["stem"]
         dy = torch.empty(N * Ho * Wo, 64, dtype=self.tdt, device=dfeat.device)
-        ops.maxpool_bwd(self.dtype, rs.y, dcur, dy, N, Ho, Wo, 64)
+        ops.maxpool_bwd(self.dtype, ctx["argmax"], dcur, dy, N, Ho, Wo, 64)
         dxo, _ = self.bn_backward(rs, dy, keep_dz=False)
         self.conv_backward(rs, dxo, need_dx=False)
         if last_view:
@@ -474,13 +512,13 @@ class SM3Engine:
         """dz [M,proj_dim] `dtype` -> gradient w.r.t. the projector input [M,2048] (+addend)."""
         r0, r3, r6 = recs
         dx, _ = self.bn_backward(r6, dz, keep_dz=False)
-        d = self.conv_backward(r6, dx)
-        dx, _ = self.bn_backward(r3, d, keep_dz=False)
-        d = self.conv_backward(r3, dx)
-        dx, _ = self.bn_backward(r0, d, keep_dz=False)
+        d, fr = self.conv_backward(r6, dx, fuse=r3)
+        dx, _ = self.bn_backward(r3, d, keep_dz=False, fused_rows=fr)
+        d, fr = self.conv_backward(r3, dx, fuse=r0)
+        dx, _ = self.bn_backward(r0, d, keep_dz=False, fused_rows=fr)
         if into is not None:
-            return self.conv_backward(r0, dx, into=into)
-        return self.conv_backward(r0, dx, addend=addend)
+            return self.conv_backward(r0, dx, into=into)[0]
+        return self.conv_backward(r0, dx, addend=addend)[0]
 
     # ---- whole model ---------------------------------------------------------------------
     @staticmethod

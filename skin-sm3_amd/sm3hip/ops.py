@@ -161,6 +161,43 @@ def conv_gemm(desc, x, w, y, addend=None, partials=None):
                                                _ptr(partials), _stream()), "sm3_conv_gather_gemm")
 
 
+def conv_dgrad_bnfuse(desc, dy_in, w_dgrad, dz_out, addend, mask, bn_x, mean, invstd, partials, row_offset):
+    """Data-gradient launch that also masks with the producer BN's ReLU bits and emits its backward partial sums
+    (see sm3_conv_dgrad_bnfuse).  Returns the number of partial rows this launch wrote."""
+    tdt = TORCH_DTYPE[desc.dtype]
+    _chk(dy_in, tdt, "dy_in"); _chk(w_dgrad, tdt, "w"); _chk(dz_out, tdt, "dz_out"); _chk(addend, tdt, "addend")
+    _chk(bn_x, tdt, "bn_x"); _chk(mask, torch.uint8, "mask"); _chk(mean, torch.float32); _chk(invstd, torch.float32)
+    _chk(partials, torch.float32, "partials")
+    if dy_in.numel() != desc.N * desc.Hi * desc.Wi * desc.Ci:
+        raise ValueError("dy_in size does not match descriptor")
+    n_out = desc.N * desc.Hout * desc.Wout * desc.Co
+    if dz_out.numel() != n_out or bn_x.numel() != n_out or (addend is not None and addend.numel() != n_out):
+        raise ValueError("dz_out / bn_x / addend size does not match descriptor")
+    if mask is not None and mask.numel() != n_out // (16 // _sz(desc.dtype)):
+        raise ValueError("mask size mismatch")
+    if mean.numel() < desc.Co or invstd.numel() < desc.Co:
+        raise ValueError("mean/invstd too small")
+    prow = conv_partial_rows(desc)
+    if partials.numel() < (row_offset + prow) * 2 * desc.Co:
+        raise ValueError("partials workspace too small")
+    if desc.Ci % K_CHUNK[desc.dtype]:
+        raise ValueError(f"Ci={desc.Ci} is not a multiple of {K_CHUNK[desc.dtype]}")
+    f = _lib.BnBwdFuse()
+    f.relu_mask = mask.data_ptr() if mask is not None else None
+    f.x, f.mean, f.invstd, f.partials = bn_x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), partials.data_ptr()
+    f.partial_row_offset = row_offset
+    M = desc.N * desc.Ho * desc.Wo
+    sz = _sz(desc.dtype)
+    tag = "conv_gemm_128x64" if desc.Co <= 64 else "conv_gemm_128x128"
+    if _PROFILER is not None and getattr(_PROFILER, "detail", False):
+        tag += f"|M{M}_K{desc.ntaps}x{desc.Ci}_N{desc.Co}_s{desc.osy}_fz"
+    with _prof(tag, 2.0 * M * desc.Co * desc.ntaps * desc.Ci,
+               sz * (min(dy_in.numel(), M * desc.ntaps * desc.Ci) + M * desc.Co * (3 if addend is not None else 2))):
+        check(_lib.load().sm3_conv_dgrad_bnfuse(C.byref(desc), _ptr(dy_in), _ptr(w_dgrad), _ptr(dz_out), _ptr(addend),
+                                                C.byref(f), _stream()), "sm3_conv_dgrad_bnfuse")
+    return prow
+
+
 def conv_wgrad(desc, x, dy, dw):
     tdt = TORCH_DTYPE[desc.dtype]
     _chk(x, tdt, "x"); _chk(dy, tdt, "dy"); _chk(dw, torch.float32, "dw")
@@ -197,26 +234,34 @@ def _bn_workspace(device, Cn):
     return t
 
 
+def bn_reduce_groups(rows):
+    return min(BN_REDUCE_GROUPS, (rows + 31) // 32)
+
+
 def bn_stats_reduce(partials, rows, Cn, sums):
+    """sums: fp64 [2C] output, or None to run stage A only -- then returns (workspace, groups) for bn_finalize."""
     _chk(partials, torch.float32, "partials"); _chk(sums, torch.float64, "sums")
-    if partials.numel() < rows * 2 * Cn or sums.numel() < 2 * Cn:
+    if partials.numel() < rows * 2 * Cn or (sums is not None and sums.numel() < 2 * Cn):
         raise ValueError("bn_stats_reduce: buffer too small")
     ws = _bn_workspace(partials.device, Cn)
     with _prof("bn_stats_reduce", 0.0, 4.0 * rows * 2 * Cn):
         check(_lib.load().sm3_bn_stats_reduce(_ptr(partials), rows, Cn, _ptr(sums), _ptr(ws), _stream()),
               "sm3_bn_stats_reduce")
+    return ws, bn_reduce_groups(rows)
 
 
 def bn_finalize(sums, count, Cn, gamma, beta, eps, momentum, running_mean, running_var, nbt, scale, shift,
-                save_mean, save_invstd):
+                save_mean, save_invstd, groups=1):
     for t, n in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var"),
                  (scale, "scale"), (shift, "shift"), (save_mean, "save_mean"), (save_invstd, "save_invstd")):
         _chk(t, torch.float32, n)
         if t is not None and t.numel() < Cn:
             raise ValueError(f"{n} too small")
     _chk(sums, torch.float64, "sums"); _chk(nbt, torch.int64, "num_batches_tracked")
+    if sums.numel() < groups * 2 * Cn:
+        raise ValueError("bn_finalize: sums too small for groups")
     with _prof("bn_finalize", 0.0, 40.0 * Cn):
-        check(_lib.load().sm3_bn_finalize(_ptr(sums), float(count), Cn, _ptr(gamma), _ptr(beta), eps, momentum,
+        check(_lib.load().sm3_bn_finalize(_ptr(sums), groups, float(count), Cn, _ptr(gamma), _ptr(beta), eps, momentum,
                                           _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(scale), _ptr(shift),
                                           _ptr(save_mean), _ptr(save_invstd), _stream()), "sm3_bn_finalize")
 
@@ -228,23 +273,26 @@ def bn_eval_scale_shift(gamma, beta, running_mean, running_var, eps, Cn, scale, 
                                               Cn, _ptr(scale), _ptr(shift), _stream()), "sm3_bn_eval_scale_shift")
 
 
-def bn_act(dtype, x, scale, shift, residual, relu, y, rows, Cn, out_f32=False):
+def bn_act(dtype, x, scale, shift, residual, relu, y, rows, Cn, out_f32=False, mask=None):
     tdt = TORCH_DTYPE[dtype]
     _chk(x, tdt, "x"); _chk(residual, tdt, "residual"); _chk(scale, torch.float32); _chk(shift, torch.float32)
     _chk(y, torch.float32 if out_f32 else tdt, "y")
     if x.numel() != rows * Cn or y.numel() != rows * Cn or (residual is not None and residual.numel() != rows * Cn):
         raise ValueError("bn_act: size mismatch")
+    _chk(mask, torch.uint8, "mask")
+    if mask is not None and mask.numel() != rows * Cn // (16 // _sz(dtype)):
+        raise ValueError("bn_act: mask size mismatch")
     n = rows * Cn
     with _prof("bn_act", 0.0, _sz(dtype) * n * (2 if residual is None else 3)):
         check(_lib.load().sm3_bn_act(dtype, _ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), int(relu),
-                                     int(out_f32), _ptr(y), rows, Cn, _stream()), "sm3_bn_act")
+                                     int(out_f32), _ptr(y), _ptr(mask), rows, Cn, _stream()), "sm3_bn_act")
 
 
 def bn_bwd_partial_rows(rows, Cn):
     return _lib.load().sm3_bn_bwd_partial_rows(rows, Cn)
 
 
-def bn_bwd_reduce(dtype, dy, y, x, mean, invstd, dz, rows, Cn, partials):
+def bn_bwd_reduce(dtype, dy, y, x, mean, invstd, dz, rows, Cn, partials, mask=None):
     tdt = TORCH_DTYPE[dtype]
     for t, n in ((dy, "dy"), (y, "y"), (x, "x"), (dz, "dz")):
         _chk(t, tdt, n)
@@ -253,10 +301,14 @@ def bn_bwd_reduce(dtype, dy, y, x, mean, invstd, dz, rows, Cn, partials):
     _chk(partials, torch.float32)
     if partials.numel() < bn_bwd_partial_rows(rows, Cn) * 2 * Cn:
         raise ValueError("bn_bwd_reduce: partials too small")
+    _chk(mask, torch.uint8, "mask")
+    if mask is not None and mask.numel() != rows * Cn // (16 // _sz(dtype)):
+        raise ValueError("bn_bwd_reduce: mask size mismatch")
     n = rows * Cn
-    with _prof("bn_bwd_reduce", 0.0, _sz(dtype) * n * (2 + (1 if y is not None else 0) + (1 if dz is not None else 0))):
-        check(_lib.load().sm3_bn_bwd_reduce(dtype, _ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(dz),
-                                            rows, Cn, _ptr(partials), _stream()), "sm3_bn_bwd_reduce")
+    reads = 2 + (1 if (y is not None and mask is None) else 0) + (1 if dz is not None else 0)
+    with _prof("bn_bwd_reduce", 0.0, _sz(dtype) * n * reads + (n // 8 if mask is not None else 0)):
+        check(_lib.load().sm3_bn_bwd_reduce(dtype, _ptr(dy), _ptr(y), _ptr(mask), _ptr(x), _ptr(mean), _ptr(invstd),
+                                            _ptr(dz), rows, Cn, _ptr(partials), _stream()), "sm3_bn_bwd_reduce")
 
 
 def bn_bwd_apply(dtype, dz, x, mean, invstd, gamma, gsums, count, lsums, dgamma, dbeta, dx, rows, Cn):
@@ -288,23 +340,25 @@ def stem_im2col(dtype, x_nchw, cols, Kpad):
         check(_lib.load().sm3_stem_im2col(dtype, _ptr(x_nchw), _ptr(cols), N, H, W, Kpad, _stream()), "sm3_stem_im2col")
 
 
-def maxpool_fwd(dtype, x, y, N, H, W, Cn):
-    _chk(x, TORCH_DTYPE[dtype]); _chk(y, TORCH_DTYPE[dtype])
+def maxpool_fwd(dtype, x, y, N, H, W, Cn, argmax=None):
+    _chk(x, TORCH_DTYPE[dtype]); _chk(y, TORCH_DTYPE[dtype]); _chk(argmax, torch.uint8)
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     if x.numel() != N * H * W * Cn or y.numel() != N * Ho * Wo * Cn:
         raise ValueError("maxpool_fwd: size mismatch")
+    if argmax is not None and argmax.numel() != y.numel():
+        raise ValueError("maxpool_fwd: argmax size mismatch")
     with _prof("maxpool_fwd", 0.0, _sz(dtype) * (x.numel() + y.numel())):
-        check(_lib.load().sm3_maxpool3x3s2_fwd(dtype, _ptr(x), _ptr(y), N, H, W, Cn, _stream()), "sm3_maxpool3x3s2_fwd")
+        check(_lib.load().sm3_maxpool3x3s2_fwd(dtype, _ptr(x), _ptr(y), _ptr(argmax), N, H, W, Cn, _stream()),
+              "sm3_maxpool3x3s2_fwd")
 
 
-def maxpool_bwd(dtype, x, dy, dx, N, H, W, Cn):
-    for t in (x, dy, dx):
-        _chk(t, TORCH_DTYPE[dtype])
+def maxpool_bwd(dtype, argmax, dy, dx, N, H, W, Cn):
+    _chk(argmax, torch.uint8); _chk(dy, TORCH_DTYPE[dtype]); _chk(dx, TORCH_DTYPE[dtype])
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    if x.numel() != N * H * W * Cn or dx.numel() != x.numel() or dy.numel() != N * Ho * Wo * Cn:
+    if dx.numel() != N * H * W * Cn or dy.numel() != N * Ho * Wo * Cn or argmax.numel() != dy.numel():
         raise ValueError("maxpool_bwd: size mismatch")
-    with _prof("maxpool_bwd", 0.0, _sz(dtype) * (2 * x.numel() + dy.numel())):
-        check(_lib.load().sm3_maxpool3x3s2_bwd(dtype, _ptr(x), _ptr(dy), _ptr(dx), N, H, W, Cn, _stream()),
+    with _prof("maxpool_bwd", 0.0, _sz(dtype) * (dx.numel() + dy.numel()) + argmax.numel()):
+        check(_lib.load().sm3_maxpool3x3s2_bwd(dtype, _ptr(argmax), _ptr(dy), _ptr(dx), N, H, W, Cn, _stream()),
               "sm3_maxpool3x3s2_bwd")
 
 
@@ -339,6 +393,31 @@ def weight_prep(dtype, w, Co, taps, Ci, w_fwd, ld_fwd, w_dgrad):
     with _prof("weight_prep", 0.0, w.numel() * (4.0 + 2 * _sz(dtype))):
         check(_lib.load().sm3_weight_prep(dtype, _ptr(w), Co, taps, Ci, _ptr(w_fwd), ld_fwd, _ptr(w_dgrad), _stream()),
               "sm3_weight_prep")
+
+
+def weight_prep_table(items, device):
+    """items: list of (w_master fp32, w_fwd or None, w_dgrad or None, Co, taps, Ci, ld_fwd).  Returns the device
+    table (keep it alive, together with the tensors it points to) for weight_prep_batch."""
+    arr = (_lib.WPrepItem * len(items))()
+    total = 0
+    for a, (w, wf, wd, Co, taps, Ci, ld) in zip(arr, items):
+        _chk(w, torch.float32, "w")
+        if w.numel() != Co * taps * Ci or (wf is not None and wf.numel() != Co * ld) or \
+                (wd is not None and wd.numel() != Co * taps * Ci) or ld < taps * Ci:
+            raise ValueError("weight_prep_table: size mismatch")
+        a.w, a.w_fwd, a.w_dgrad = w.data_ptr(), (wf.data_ptr() if wf is not None else None), \
+            (wd.data_ptr() if wd is not None else None)
+        a.Co, a.taps, a.Ci, a.ld_fwd = Co, taps, Ci, ld
+        total += w.numel()
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return host.to(device), len(items), total
+
+
+def weight_prep_batch(dtype, table):
+    dev_table, n, total = table
+    _chk(dev_table, torch.uint8, "table")
+    with _prof("weight_prep", 0.0, total * (4.0 + 2 * _sz(dtype))):
+        check(_lib.load().sm3_weight_prep_batch(dtype, _ptr(dev_table), n, _stream()), "sm3_weight_prep_batch")
 
 
 def cast_from_f32(dtype, src, dst):

@@ -115,6 +115,49 @@ def test_conv_fwd_dgrad_wgrad(case, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 64, 128, 9, 11, 1, 1, 0), (3, 128, 64, 10, 8, 3, 1, 1), (2, 64, 192, 13, 11, 3, 2, 1)])
+def test_dgrad_with_fused_bn_backward_phase1(case, dt):
+    """sm3_conv_dgrad_bnfuse == sm3_conv_gather_gemm followed by sm3_bn_bwd_reduce (dz bit-exact, sums equal)."""
+    ops = _ops()
+    N, Ci, Co, H, W, k, s, p = case   # forward conv Ci -> Co; its data gradient has Ci output channels
+    code = ops.dtype_code(dt)
+    E = 4 if dt == torch.float32 else 8
+    g = torch.Generator().manual_seed(sum(case))
+    D = dev()
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dy = torch.randn(N, Ho, Wo, Co, generator=g).to(dt).to(D)
+    w_dg = (torch.randn(Ci, k * k, Co, generator=g) / math.sqrt(Co * k * k)).to(dt).to(D)
+    addend = torch.randn(N, H, W, Ci, generator=g).to(dt).to(D)
+    bn_x = torch.randn(N * H * W, Ci, generator=g).to(dt).to(D)             # producer BN's input
+    mask = torch.randint(0, 256, (N * H * W * Ci // E,), generator=g, dtype=torch.uint8).to(D)
+    if E == 4:
+        mask &= 0x0F
+    mean, invstd = torch.randn(Ci, generator=g).to(D), (torch.rand(Ci, generator=g) + 0.5).to(D)
+    descs, full = ops.dgrad_descs(code, N, H, W, Ci, Co, k, s, p)
+    assert full
+    rows = N * H * W
+    # reference: plain data gradient, then the standalone phase-1 kernel
+    ref = torch.empty(rows, Ci, dtype=dt, device=D)
+    for dd in descs:
+        ops.conv_gemm(dd, dy, w_dg, ref, addend, None)
+    prow_ref = ops.bn_bwd_partial_rows(rows, Ci)
+    part_ref = torch.zeros(prow_ref, 2, Ci, device=D)
+    ops.bn_bwd_reduce(code, ref, None, bn_x, mean, invstd, ref, rows, Ci, part_ref, mask=mask)
+    # fused
+    out = torch.empty(rows, Ci, dtype=dt, device=D)
+    total = sum(ops.conv_partial_rows(dd) for dd in descs)
+    part = torch.full((total, 2, Ci), float("nan"), device=D)
+    off = 0
+    for dd in descs:
+        off += ops.conv_dgrad_bnfuse(dd, dy, w_dg, out, addend, mask, bn_x, mean, invstd, part, off)
+    torch.cuda.synchronize()
+    assert off == total
+    assert torch.equal(out, ref)
+    a, b = part.double().sum(0).cpu(), part_ref.double().sum(0).cpu()
+    assert torch.allclose(a, b, rtol=1e-4, atol=1e-3 * float(b.abs().max()))
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
 def test_linear_as_conv(dt):
     ops = _ops()
     code = ops.dtype_code(dt)
@@ -166,8 +209,19 @@ def test_bn_train_forward_backward(shape, dt):
     nbt = torch.zeros((), dtype=torch.int64, device=D)
     ops.bn_finalize(sums, rows, Cn, gamma.to(D), beta.to(D), 1e-5, 0.1, rmd, rvd, nbt, scale, shift, mean, invstd)
     y = torch.empty(rows, Cn, dtype=dt, device=D)
-    ops.bn_act(code, xdv, scale, shift, res.to(dt).to(D), True, y, rows, Cn)
+    E = 4 if dt == torch.float32 else 8
+    mask = torch.empty(rows * Cn // E, dtype=torch.uint8, device=D)
+    ops.bn_act(code, xdv, scale, shift, res.to(dt).to(D), True, y, rows, Cn, mask=mask)
+    # same statistics through the folded path: stage A only, stage B inside bn_finalize
+    ws, groups = ops.bn_stats_reduce(partials, nblk, Cn, None)
+    scale2, shift2 = torch.empty(Cn, device=D), torch.empty(Cn, device=D)
+    ops.bn_finalize(ws, rows, Cn, gamma.to(D), beta.to(D), 1e-5, 0.1, None, None, None, scale2, shift2, None, None,
+                    groups=groups)
     torch.cuda.synchronize()
+    assert torch.equal(scale, scale2) and torch.equal(shift, shift2)
+    # the mask is exactly (y > 0), bit e of byte v = element 8v+e (4v+e in f32)
+    bits = ((mask.cpu().unsqueeze(1) >> torch.arange(E, dtype=torch.uint8)) & 1).reshape(rows, Cn).bool()
+    assert torch.equal(bits, y.float().cpu() > 0)
     assert int(nbt) == 1
     sc = ref_y.abs().max().item()
     assert (y.float().cpu().double() - ref_y.detach()).abs().max().item() < tol(dt, sc)
@@ -182,6 +236,16 @@ def test_bn_train_forward_backward(shape, dt):
     dz = dy.to(dt).to(D).clone()
     y_ref_dev = ref_y.detach().float().to(dt).to(D)  # mask source: exact reference activations
     ops.bn_bwd_reduce(code, dz, y_ref_dev, xdv, mean, invstd, dz, rows, Cn, bpart)
+    # mask-bit variant gives the same dz and partial sums
+    ref_mask = torch.zeros(rows * Cn // E, dtype=torch.uint8)
+    yb = (ref_y.detach() > 0).reshape(rows * Cn // E, E).to(torch.uint8)
+    for e in range(E):
+        ref_mask |= yb[:, e] << e
+    dz2 = dy.to(dt).to(D).clone()
+    bpart2 = torch.full((prow, 2, Cn), float("nan"), device=D)
+    ops.bn_bwd_reduce(code, dz2, None, xdv, mean, invstd, dz2, rows, Cn, bpart2, mask=ref_mask.to(D))
+    torch.cuda.synchronize()
+    assert torch.equal(dz, dz2) and torch.equal(bpart, bpart2)
     lsums = torch.empty(2 * Cn, dtype=torch.float64, device=D)
     ops.bn_stats_reduce(bpart, prow, Cn, lsums)
     dx = torch.empty(rows, Cn, dtype=dt, device=D)
@@ -258,11 +322,12 @@ def test_pools(dt):
     Ho, Wo = ref.shape[2:]
     xd = nhwc(x, dt)
     y = torch.empty(N, Ho, Wo, Cn, dtype=dt, device=dev())
-    ops.maxpool_fwd(code, xd, y, N, H, W, Cn)
+    amax = torch.empty(N * Ho * Wo * Cn, dtype=torch.uint8, device=dev())
+    ops.maxpool_fwd(code, xd, y, N, H, W, Cn, amax)
     dy = rnd(torch.randn(N, Cn, Ho, Wo, generator=g), dt)
     ref.backward(dy.double())
     dx = torch.empty_like(xd)
-    ops.maxpool_bwd(code, xd, nhwc(dy, dt), dx, N, H, W, Cn)
+    ops.maxpool_bwd(code, amax, nhwc(dy, dt), dx, N, H, W, Cn)
     torch.cuda.synchronize()
     assert torch.equal(from_nhwc(y).double(), ref.detach())
     assert (from_nhwc(dx).double() - xr.grad).abs().max().item() < tol(dt, 4.0)
