@@ -94,7 +94,11 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t lds_
 }
 __device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <typename T, int BM, int BN, int WM, int WN>
+// STAGES = 2: K-loop with the DMA of step s+1 in flight while step s is computed (LDS 64 KB + 2 KB, 2 workgroups
+// per CU).  STAGES = 1 (host picks it for <= 8 K-steps, the memory-bound 1x1 layers; measured: scratch/bench_kernels.py): one 32 KB stage, no
+// intra-workgroup overlap, but 34 KB of LDS lets 4 workgroups share a CU and overlap each other's load latency,
+// K-step and store tail -- which is what those short workgroups need.
+template <typename T, int BM, int BN, int WM, int WN, int STAGES>
 __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int RPP = NT / 8;  // rows covered per loader pass
@@ -102,8 +106,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
     constexpr int SZ = sizeof(T);
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    constexpr int C_BYTES = BM * BN * 4;
-    constexpr int MAIN_BYTES = (2 * STAGE > C_BYTES) ? 2 * STAGE : C_BYTES;
+    constexpr int C_BYTES = WTM * BN * 4;  // the epilogue stages one wave-row (WTM rows) of the tile at a time
+    constexpr int MAIN_BYTES = (STAGES * STAGE > C_BYTES) ? STAGES * STAGE : C_BYTES;
     static_assert(AI >= 1 && BI >= 1 && TM >= 1 && TN >= 1, "tile too small");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -194,24 +198,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
 #pragma unroll
     for (int j = 0; j < TN; ++j) fb_base[j] = A_BYTES + lds_off(wn * WTN + j * 32 + frow, fh);
 
-    const int nsteps = p.ntaps * p.kchunks;
-    int t = 0, kc = 0;
-    uint32_t wtap_off = (uint32_t)p.wtap[0] * row_bytes;
-    set_tap(0);
-    dma_stage(0, 0, wtap_off);
-    dma_drain();
-    __syncthreads();  // publishes the stage
-    for (int s = 0; s < nsteps; ++s) {
-        if (s + 1 < nsteps) {
-            if (++kc == p.kchunks) {
-                kc = 0;
-                ++t;
-                set_tap(t);
-                wtap_off = (uint32_t)p.wtap[t] * row_bytes;
-            }
-            dma_stage((s + 1) & 1, (uint32_t)kc * 128u, wtap_off + (uint32_t)kc * 128u);
-        }
-        const char* sS = smem + (s & 1) * STAGE;
+    auto compute = [&](int stage) {
+        const char* sS = smem + stage * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             uint4 fa[TM], fb[TN];
@@ -224,58 +212,64 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
 #pragma unroll
                 for (int j = 0; j < TN; ++j) mma_frag<T>(fa[i], fb[j], acc[i][j]);
         }
-        dma_drain();      // this wave's part of stage s+1 has landed
-        __syncthreads();  // everyone's has; and everyone is done reading stage s
+    };
+
+    const int nsteps = p.ntaps * p.kchunks;
+    int t = 0, kc = 0;
+    uint32_t wtap_off = (uint32_t)p.wtap[0] * row_bytes;
+    auto advance = [&]() {
+        if (++kc == p.kchunks) {
+            kc = 0;
+            ++t;
+            set_tap(t);
+            wtap_off = (uint32_t)p.wtap[t] * row_bytes;
+        }
+    };
+    set_tap(0);
+    dma_stage(0, 0, wtap_off);
+    dma_drain();
+    __syncthreads();  // publishes the stage
+    if constexpr (STAGES == 2) {
+        for (int s = 0; s < nsteps; ++s) {
+            if (s + 1 < nsteps) {
+                advance();
+                dma_stage((s + 1) & 1, (uint32_t)kc * 128u, wtap_off + (uint32_t)kc * 128u);
+            }
+            compute(s & 1);
+            dma_drain();      // this wave's part of stage s+1 has landed
+            __syncthreads();  // everyone's has; and everyone is done reading stage s
+        }
+    } else {
+        for (int s = 0; s < nsteps; ++s) {
+            compute(0);
+            __syncthreads();  // everyone is done reading the stage
+            if (s + 1 < nsteps) {
+                advance();
+                dma_stage(0, (uint32_t)kc * 128u, wtap_off + (uint32_t)kc * 128u);
+                dma_drain();
+                __syncthreads();
+            }
+        }
     }
 
     // ---- epilogue -----------------------------------------------------------------------
-    constexpr int EPC = 16 / SZ;     // elements per 16-byte store
-    constexpr int CPR = BN / EPC;    // stores per tile row
-    constexpr int RSTEP = NT / CPR;  // rows between two stores of one thread
-    constexpr int NROW = BM / RSTEP; // stores per thread
-    static_assert(NT % CPR == 0 && BM % RSTEP == 0, "a thread must keep one channel vector across its rows");
+    // One wave-row of the tile (WTM rows) at a time: its waves write their accumulators to LDS (f32), then all
+    // threads read rows back as 16-byte vectors (a thread keeps one channel vector for all its rows) and store
+    // NHWC.  Operands the store loop needs from global memory (addend; fused BN-backward x and ReLU bits) are
+    // requested BEFORE the staging so their latency hides under it.
+    constexpr int EPC = 16 / SZ;       // elements per 16-byte store
+    constexpr int CPR = BN / EPC;      // stores per tile row
+    constexpr int RSTEP = NT / CPR;    // rows between two stores of one thread
+    constexpr int NROW = WTM / RSTEP;  // stores per thread per wave-row
+    static_assert(NT % CPR == 0 && WTM % RSTEP == 0, "a thread must keep one channel vector across its rows");
     const bool dense = (p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.HWout == p.HoWo);
     const bool fz = p.fz_x != nullptr;
-    const int cc = tid % CPR;        // fixed per thread
+    const int cc = tid % CPR;  // fixed per thread
     const int ncol = n0 + cc * EPC;
-    // Output offsets of this thread's NROW vectors, and -- issued NOW, so that their latency hides under the
-    // accumulator -> LDS staging below -- the loads the store loop needs (addend; fused BN-backward operands).
-    constexpr bool PRE = (NROW <= 8);        // f32 tiles have 16 vectors per thread: too many registers to hold
-    constexpr int NPRE = PRE ? NROW : 1;
-    long e_off[NROW];
-    uint4 pre_add[NPRE], pre_x[NPRE];
-    unsigned pre_mk[NPRE];
-#pragma unroll
-    for (int k = 0; k < NROW; ++k) {
-        const int m = m0 + tid / CPR + k * RSTEP;
-        e_off[k] = -1;
-        if constexpr (PRE) {
-            pre_add[k] = make_uint4(0, 0, 0, 0);
-            pre_x[k] = make_uint4(0, 0, 0, 0);
-            pre_mk[k] = 0xffu;
-        }
-        if (m < p.M && ncol < p.Co) {
-            long opix = m;
-            if (!dense) {
-                const int nn = fdiv(m, p.div_HoWo);
-                const int rem = m - nn * p.HoWo;
-                const int oy = fdiv(rem, p.div_Wo);
-                const int ox = rem - oy * p.Wo;
-                opix = (long)nn * p.HWout + (long)(oy * p.osy + p.ooy) * p.Wout + (ox * p.osx + p.oox);
-            }
-            e_off[k] = opix * p.Co + ncol;
-            if constexpr (PRE) {
-                if (p.addend) pre_add[k] = *reinterpret_cast<const uint4*>(p.addend + e_off[k] * SZ);
-                if (fz) {
-                    pre_x[k] = *reinterpret_cast<const uint4*>(p.fz_x + e_off[k] * SZ);
-                    if (p.fz_mask) pre_mk[k] = p.fz_mask[e_off[k] / EPC];
-                }
-            }
-        }
-    }
     float* sC = reinterpret_cast<float*>(smem);
     float* sStat = reinterpret_cast<float*>(smem + MAIN_BYTES);  // [WM][BN][2]
-    if (p.partials) {
+
+    if (p.partials) {  // train-mode BN statistics of the stored (rounded) outputs
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float s1 = 0.f, s2 = 0.f;
@@ -296,32 +290,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
             }
         }
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                const int col = wn * WTN + j * 32 + frow;
-                sC[row * BN + col] = acc[i][j][r];
-            }
-    __syncthreads();
 
-    if (p.partials && tid < BN && n0 + tid < p.Co) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < WM; ++w) {
-            s1 += sStat[(w * BN + tid) * 2 + 0];
-            s2 += sStat[(w * BN + tid) * 2 + 1];
-        }
-        p.partials[((long)bm * 2 + 0) * p.Co + n0 + tid] = s1;
-        p.partials[((long)bm * 2 + 1) * p.Co + n0 + tid] = s2;
-    }
-
-    // BN-backward phase 1 fused here (data-gradient launches): the value just computed is dy of the producer
-    // BatchNorm's output; mask it with that BN's ReLU bits, store dz instead of dy, and accumulate this tile's
-    // sum(dz), sum(dz * xhat) per channel -- saves a full read of dy, a read of the mask source and a write of dz.
     float f_mu[EPC], f_is[EPC], f_s1[EPC], f_s2[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
@@ -330,48 +299,106 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
         f_mu[e] = (fz && ncol < p.Co) ? p.fz_mean[ncol + e] : 0.f;
         f_is[e] = (fz && ncol < p.Co) ? p.fz_invstd[ncol + e] : 0.f;
     }
+
 #pragma unroll
-    for (int k = 0; k < NROW; ++k) {
-        if (e_off[k] < 0) continue;
-        const int r = tid / CPR + k * RSTEP;
-        float v[EPC];
+    for (int hh = 0; hh < WM; ++hh) {
+        long e_off[NROW];
+        uint4 pre_add[NROW], pre_x[NROW];
+        unsigned pre_mk[NROW];
 #pragma unroll
-        for (int e = 0; e < EPC; e += 4) {
-            const float4 q = *reinterpret_cast<const float4*>(&sC[r * BN + cc * EPC + e]);
-            v[e] = q.x;
-            v[e + 1] = q.y;
-            v[e + 2] = q.z;
-            v[e + 3] = q.w;
-        }
-        const long boff = e_off[k] * SZ;
-        if (p.addend) {
-            float a[EPC];
-            unpack16<T>(PRE ? pre_add[PRE ? k : 0] : *reinterpret_cast<const uint4*>(p.addend + boff), a);
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) v[e] += a[e];
-        }
-        if (fz) {
-            float xv[EPC];
-            unpack16<T>(PRE ? pre_x[PRE ? k : 0] : *reinterpret_cast<const uint4*>(p.fz_x + boff), xv);
-            const unsigned mk = PRE ? pre_mk[PRE ? k : 0] : (p.fz_mask ? (unsigned)p.fz_mask[e_off[k] / EPC] : 0xffu);
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) v[e] = ((mk >> e) & 1u) ? v[e] : 0.f;
-            const uint4 packed = pack16<T>(v);
-            float dzr[EPC];
-            unpack16<T>(packed, dzr);  // sums are those of the STORED (rounded) dz, as the standalone kernel's
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                f_s1[e] += dzr[e];
-                f_s2[e] += dzr[e] * (xv[e] - f_mu[e]) * f_is[e];
+        for (int k = 0; k < NROW; ++k) {
+            const int m = m0 + hh * WTM + tid / CPR + k * RSTEP;
+            e_off[k] = -1;
+            pre_add[k] = make_uint4(0, 0, 0, 0);
+            pre_x[k] = make_uint4(0, 0, 0, 0);
+            pre_mk[k] = 0xffu;
+            if (m < p.M && ncol < p.Co) {
+                long opix = m;
+                if (!dense) {
+                    const int nn = fdiv(m, p.div_HoWo);
+                    const int rem = m - nn * p.HoWo;
+                    const int oy = fdiv(rem, p.div_Wo);
+                    const int ox = rem - oy * p.Wo;
+                    opix = (long)nn * p.HWout + (long)(oy * p.osy + p.ooy) * p.Wout + (ox * p.osx + p.oox);
+                }
+                e_off[k] = opix * p.Co + ncol;
+                if (p.addend) pre_add[k] = *reinterpret_cast<const uint4*>(p.addend + e_off[k] * SZ);
+                if (fz) {
+                    pre_x[k] = *reinterpret_cast<const uint4*>(p.fz_x + e_off[k] * SZ);
+                    if (p.fz_mask) pre_mk[k] = p.fz_mask[e_off[k] / EPC];
+                }
             }
-            *reinterpret_cast<uint4*>(p.y + boff) = packed;
-        } else {
-            *reinterpret_cast<uint4*>(p.y + boff) = pack16<T>(v);
+        }
+        if (hh > 0) __syncthreads();  // the previous wave-row has been read out of sC
+        if (wm == hh) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                        const int col = wn * WTN + j * 32 + frow;
+                        sC[row * BN + col] = acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+        if (hh == 0 && p.partials && tid < BN && n0 + tid < p.Co) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                s1 += sStat[(w * BN + tid) * 2 + 0];
+                s2 += sStat[(w * BN + tid) * 2 + 1];
+            }
+            p.partials[((long)bm * 2 + 0) * p.Co + n0 + tid] = s1;
+            p.partials[((long)bm * 2 + 1) * p.Co + n0 + tid] = s2;
+        }
+#pragma unroll
+        for (int k = 0; k < NROW; ++k) {
+            if (e_off[k] < 0) continue;
+            const int r = tid / CPR + k * RSTEP;  // row inside this wave-row
+            float v[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; e += 4) {
+                const float4 q = *reinterpret_cast<const float4*>(&sC[r * BN + cc * EPC + e]);
+                v[e] = q.x;
+                v[e + 1] = q.y;
+                v[e + 2] = q.z;
+                v[e + 3] = q.w;
+            }
+            const long boff = e_off[k] * SZ;
+            if (p.addend) {
+                float a[EPC];
+                unpack16<T>(pre_add[k], a);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] += a[e];
+            }
+            if (fz) {
+                // BN-backward phase 1 fused here (data-gradient launches): the value just computed is dy of the
+                // producer BatchNorm's output; mask it with that BN's ReLU bits, store dz instead of dy, and
+                // accumulate this tile's sum(dz), sum(dz * xhat) per channel.
+                float xv[EPC];
+                unpack16<T>(pre_x[k], xv);
+                const unsigned mk = pre_mk[k];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = ((mk >> e) & 1u) ? v[e] : 0.f;
+                const uint4 packed = pack16<T>(v);
+                float dzr[EPC];
+                unpack16<T>(packed, dzr);  // sums are those of the STORED (rounded) dz, as the standalone kernel's
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    f_s1[e] += dzr[e];
+                    f_s2[e] += dzr[e] * (xv[e] - f_mu[e]) * f_is[e];
+                }
+                *reinterpret_cast<uint4*>(p.y + boff) = packed;
+            } else {
+                *reinterpret_cast<uint4*>(p.y + boff) = pack16<T>(v);
+            }
         }
     }
     if (fz) {
         __syncthreads();  // everyone is done reading sC: reuse it for the cross-thread reduction
-        float* sRed = reinterpret_cast<float*>(smem);  // [NT][2*EPC]
+        float* sRed = reinterpret_cast<float*>(smem);  // [NT][2*EPC] floats = 16 KB
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             sRed[tid * 2 * EPC + e] = f_s1[e];
@@ -387,16 +414,17 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
-int launch_conv(const ConvParams& p0, hipStream_t st) {
+template <typename T, int BM, int BN, int WM, int WN, int STAGES>
+int launch_conv_st(const ConvParams& p0, hipStream_t st) {
     ConvParams p = p0;
     constexpr int STAGE = (BM + BN) * 128;
-    constexpr int C_BYTES = BM * BN * 4;
-    constexpr int MAIN = (2 * STAGE > C_BYTES) ? 2 * STAGE : C_BYTES;
+    constexpr int C_BYTES = (BM / WM) * BN * 4;
+    constexpr int MAIN = (STAGES * STAGE > C_BYTES) ? STAGES * STAGE : C_BYTES;
     constexpr int LDS = MAIN + WM * BN * 2 * 4;
+    static_assert(MAIN >= 256 * 2 * 8 * 4, "reduction scratch of the fused BN-backward epilogue must fit");
     p.tilesM = (p.M + BM - 1) / BM;
     p.tilesN = (p.Co + BN - 1) / BN;
-    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN>;
+    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, STAGES>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -409,6 +437,14 @@ int launch_conv(const ConvParams& p0, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(WM * WN * 64), LDS, st, p);
     SM3_CHECK_LAUNCH();
     return 0;
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_conv(const ConvParams& p, hipStream_t st) {
+    const char* v = getenv("SM3_CONV_SINGLE_STAGE_MAX");
+    const int single_max = v ? atoi(v) : 8;
+    if (p.ntaps * p.kchunks <= single_max) return launch_conv_st<T, BM, BN, WM, WN, 1>(p, st);
+    return launch_conv_st<T, BM, BN, WM, WN, 2>(p, st);
 }
 
 constexpr int kBM = 128;
