@@ -23,6 +23,8 @@ import torch
 from . import ops
 from ._lib import SM3_BF16, SM3_F32
 
+import os as _os
+_APPLY_OUT_OF_PLACE = _os.environ.get("SM3_BN_APPLY_OOP", "0") == "1"
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 STEM_KPAD = 192  # 7*7*3 = 147 padded to a multiple of the 128-byte K chunk for both dtypes
@@ -251,6 +253,9 @@ class SM3Engine:
             raise ValueError(kind)
         self._ws = {}
         self._allocated = False
+        self._lane = "main"
+        self.two_streams = True
+        self._streams, self._streams_dev = None, None
 
     # ---- setup ---------------------------------------------------------------------------
     def _all_conv_units(self):
@@ -298,10 +303,62 @@ class SM3Engine:
         ops.weight_prep_batch(self.dtype, self._wprep_table)
 
     def _work(self, key, numel, dtype=torch.float32):
+        """Stream-ordered scratch; one set per execution lane (branch stream) so concurrent branches never share."""
+        key = (self._lane, key)
         t = self._ws.get(key)
         if t is None or t.numel() < numel or t.dtype != dtype:
             t = torch.empty(max(numel, 1), dtype=dtype, device=self.store.flat_p.device)
             self._ws[key] = t
+        return t
+
+    # ---- two-lane execution: the derm and clinic branches are independent until the cross-modal projectors, so
+    # they run on two HIP streams: while one lane is in an HBM-bound BatchNorm pass the other can be in an
+    # MFMA-bound convolution, and short kernels of one lane fill the launch gaps of the other.
+    def _lane_streams(self, device):
+        if not self.two_streams or len(self.branches) < 2 or device.type != "cuda":
+            return None
+        if self._streams is None or self._streams_dev != device:
+            self._streams = {k: torch.cuda.Stream(device=device) for k in self.branches}
+            self._streams_dev = device
+        return self._streams
+
+    class _Lane:
+        def __init__(self, eng, key, stream):
+            self.eng, self.key, self.stream, self.ctx = eng, key, stream, None
+
+        def __enter__(self):
+            self.prev = self.eng._lane
+            self.eng._lane = self.key
+            if self.stream is not None:
+                self.stream.wait_stream(torch.cuda.current_stream())  # everything enqueued so far is visible
+                self.ctx = torch.cuda.stream(self.stream)
+                self.ctx.__enter__()
+            return self
+
+        def __exit__(self, *exc):
+            if self.ctx is not None:
+                self.ctx.__exit__(*exc)
+            self.eng._lane = self.prev
+            return False
+
+    def lane(self, key, streams):
+        return SM3Engine._Lane(self, key, streams[key] if streams else None)
+
+    @staticmethod
+    def _join(streams):
+        """Main stream waits for every lane."""
+        if streams:
+            cur = torch.cuda.current_stream()
+            for st in streams.values():
+                cur.wait_stream(st)
+
+    @staticmethod
+    def _share(t, streams):
+        """Tensor allocated on one stream, also used on others: tell the caching allocator."""
+        if streams and t is not None and t.is_cuda:
+            t.record_stream(torch.cuda.current_stream())
+            for st in streams.values():
+                t.record_stream(st)
         return t
 
     def _p(self, name):
@@ -368,7 +425,7 @@ class SM3Engine:
             ops.bn_bwd_reduce(self.dtype, dy, None, r.xo, r.mean, r.invstd, dy if r.relu else None, rows, C, bpart,
                               mask=r.mask if r.relu else None)
         else:
-            prow, bpart = fused_rows, self._ws["fz_partials"]
+            prow, bpart = fused_rows, self._ws[(self._lane, "fz_partials")]
         lsums = self._work("lsums", 2 * 2048, torch.float64)
         ops.bn_stats_reduce(bpart, prow, C, lsums)
         gsums, count = lsums, rows
@@ -377,7 +434,7 @@ class SM3Engine:
             gsums[: 2 * C].copy_(lsums[: 2 * C])
             self.stat_sync(gsums[: 2 * C])
             count = rows * self.world_size
-        dxo = torch.empty_like(r.xo) if keep_dz else dy
+        dxo = torch.empty_like(r.xo) if (keep_dz or _APPLY_OUT_OF_PLACE) else dy
         gamma = self._p(r.bu.name + ".weight") if r.bu.affine else None
         dgamma = self._g(r.bu.name + ".weight") if r.bu.affine else None
         dbeta = self._g(r.bu.name + ".bias") if r.bu.affine else None
@@ -537,21 +594,26 @@ class SM3Engine:
         saved = {"B": B, "style": style} if want_grad else None
         sv = (lambda: []) if want_grad else (lambda: None)
         zs, feats = OrderedDict(), {}
+        streams = self._lane_streams(dev)
         for key, (plan, proj) in self.branches.items():
             imgs = views[key]
-            f32 = torch.empty(2 * B, plan.out_dim, dtype=torch.float32, device=dev)
-            ft = torch.empty(2 * B, plan.out_dim, dtype=self.tdt, device=dev)
-            ctxs = sv()
-            for v in (0, 1):  # the two views go through the encoder separately: BN statistics per view (simclr.py:58-59)
-                self.encoder_forward(plan, imgs[v], train, f32[v * B:(v + 1) * B], ft[v * B:(v + 1) * B], ctxs)
-            feats[key] = (f32, ft)
-            precs = sv()
-            if proj is not None:  # in-modal projector on cat([f1, f2])  (simclr.py:61)
-                z = torch.empty(2 * B, self.module.proj_dim, dtype=torch.float32, device=dev)
-                self.projector_forward(proj, ft, 2 * B, train, z, precs)
-                zs[key] = z
+            for im in imgs:
+                self._share(im, streams)
+            with self.lane(key, streams):
+                f32 = torch.empty(2 * B, plan.out_dim, dtype=torch.float32, device=dev)
+                ft = torch.empty(2 * B, plan.out_dim, dtype=self.tdt, device=dev)
+                ctxs = sv()
+                for v in (0, 1):  # the two views go through the encoder separately: BN statistics per view (simclr.py:58-59)
+                    self.encoder_forward(plan, imgs[v], train, f32[v * B:(v + 1) * B], ft[v * B:(v + 1) * B], ctxs)
+                feats[key] = (self._share(f32, streams), self._share(ft, streams))
+                precs = sv()
+                if proj is not None:  # in-modal projector on cat([f1, f2])  (simclr.py:61)
+                    z = torch.empty(2 * B, self.module.proj_dim, dtype=torch.float32, device=dev)
+                    self.projector_forward(proj, ft, 2 * B, train, z, precs)
+                    zs[key] = self._share(z, streams)
             if want_grad:
                 saved[key] = {"enc": ctxs, "proj": precs[0] if proj is not None else None}
+        self._join(streams)
         cross_saved = []
         if self.cross is not None:  # cross-modal: each projector sees its own B rows (simclr.py:293)
             for ci, (a, b) in enumerate(self.cross_pairs(style)):
@@ -576,14 +638,22 @@ class SM3Engine:
         into the flat gradient buffer (self.store.flat_g)."""
         B = saved["B"]
         dfe = {}
+        dev = self.store.flat_p.device
+        streams = self._lane_streams(dev)
+        for t in dz.values():
+            self._share(t, streams)
         for key, (plan, proj) in self.branches.items():
             extra = dfeat.get(key) if dfeat is not None else None
-            if proj is not None and key in dz:
-                dfe[key] = self.projector_backward(saved[key]["proj"], dz[key], addend=extra)  # [2B,2048]
-            elif extra is not None:
-                dfe[key] = extra.clone()
-            else:
-                dfe[key] = torch.zeros(2 * B, plan.out_dim, dtype=self.tdt, device=self.store.flat_p.device)
+            self._share(extra, streams)
+            with self.lane(key, streams):
+                if proj is not None and key in dz:
+                    dfe[key] = self.projector_backward(saved[key]["proj"], dz[key], addend=extra)  # [2B,2048]
+                elif extra is not None:
+                    dfe[key] = extra.clone()
+                else:
+                    dfe[key] = torch.zeros(2 * B, plan.out_dim, dtype=self.tdt, device=dev)
+                self._share(dfe[key], streams)
+        self._join(streams)
         for ci, (a, b, pa, pb) in enumerate(saved["cross"]):
             d = dz[f"cross{ci}"]
             self.projector_backward(pa, d[:B], into=dfe["derm"][a * B:(a + 1) * B])
@@ -595,9 +665,11 @@ class SM3Engine:
         if self.cross is not None:
             self._notify(self.cross[0].prefix, self.cross[-1].prefix)
         for key, (plan, proj) in self.branches.items():
-            for v in (1, 0):
-                self.encoder_backward(saved[key]["enc"][v], dfe[key][v * B:(v + 1) * B], last_view=(v == 0))
-                saved[key]["enc"][v] = None  # free the view's activations as soon as it is done
+            with self.lane(key, streams):
+                for v in (1, 0):
+                    self.encoder_backward(saved[key]["enc"][v], dfe[key][v * B:(v + 1) * B], last_view=(v == 0))
+                    saved[key]["enc"][v] = None  # free the view's activations as soon as it is done
+        self._join(streams)
 
     def encoder_only(self, branch, x, train, want_grad):
         """One encoder call (SimCLRSkinV3.extract / a bare ResNet forward): fp32 features [N,2048] and the

@@ -225,11 +225,12 @@ _bn_ws = {}
 
 
 def _bn_workspace(device, Cn):
-    """fp64 scratch of the two-stage statistics reduction (stream-ordered reuse, like any other workspace)."""
+    """fp64 scratch of the two-stage statistics reduction (stream-ordered reuse: one per device AND stream)."""
+    device = (device, torch.cuda.current_stream().cuda_stream if device.type == "cuda" else 0)
     t = _bn_ws.get(device)
     need = BN_REDUCE_GROUPS * 2 * Cn
     if t is None or t.numel() < need:
-        t = torch.empty(max(need, BN_REDUCE_GROUPS * 2 * 2048), dtype=torch.float64, device=device)
+        t = torch.empty(max(need, BN_REDUCE_GROUPS * 2 * 2048), dtype=torch.float64, device=device[0])
         _bn_ws[device] = t
     return t
 

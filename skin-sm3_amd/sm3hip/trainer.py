@@ -41,9 +41,15 @@ class SM3Trainer:
 
     def _engine(self):
         eng = sm3_engine_for(self.model, self.kind)
-        if self.dp and self.sync_bn:
+        if self.dp and getattr(self, "_groups", None) is None:
+            # One communicator per execution lane (derm / clinic run on two streams): collectives of one
+            # communicator execute in enqueue order, so with a single one the clinic lane's first statistics
+            # all-reduce would queue behind ALL of the derm lane's and the lanes would serialise.  Every rank
+            # creates the groups in the same order; each lane's call sequence is identical on every rank.
+            self._groups = {k: dist.new_group() for k in list(eng.branches) + ["main"]}
+        if self.dp and self.sync_bn and eng.__dict__.get("_explicit_sync") is None:
             eng.world_size = self.world
-            eng.stat_sync = lambda t: dist.all_reduce(t)
+            eng.stat_sync = lambda t: dist.all_reduce(t, group=self._groups[eng._lane])
             eng.__dict__["_explicit_sync"] = True
         return eng
 
@@ -56,7 +62,7 @@ class SM3Trainer:
         hi = max(i for i, n in enumerate(names) if n.startswith(last))
         a = st.offsets[names[lo]]
         b = st.offsets[names[hi]] + (st._view(st.flat_g, names[hi]).numel() + 15) // 16 * 16
-        self._handles.append(dist.all_reduce(st.flat_g[a:b], async_op=True))
+        self._handles.append(dist.all_reduce(st.flat_g[a:b], async_op=True, group=self._groups[eng._lane]))
 
     def step(self, derm_imgs, clinic_imgs):
         """One optimizer step on this rank's batch; returns the (device, fp32, 1-element) loss tensor."""
