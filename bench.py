@@ -157,9 +157,18 @@ def main():
     dom = table.get("conv_gemm_128x128", {"flops": 0.0, "ms": 0.0, "launches": 0})
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
     peak = MFMA_PEAK_TFLOPS[args.dtype]
+    # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    # runs of this same command, FETCH_SIZE doubled per the gfx950 correction; scratch/collect_traffic.py):
+    # counters cannot be read from inside the process, so the committed measurement is reported, for the workload
+    # it was taken on only.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01b_pmc_traffic_conv_igemm_b256_bf16.json")
+    if args.dtype == "bf16" and B == 256 and S == 224 and os.path.exists(tpath):
+        traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": None,
-                "kernel": f"conv_igemm_kernel<{'bf16_t' if args.dtype == 'bf16' else 'float'},128,128,2,2>",
+                "frac": round(achieved / peak, 4), "traffic": traffic,
+                "kernel": f"conv_igemm_kernel<{'bf16_t' if args.dtype == 'bf16' else 'float'},128,128,2,2,*>",
+                "algorithmic_bytes_per_launch": round(dom["bytes"] / max(dom["launches"], 1)),
                 "launches_per_step": dom["launches"] // max(args.steps, 1),
                 "avg_launch_us": round(1e3 * dom["ms"] / max(dom["launches"], 1), 2),
                 "avg_launch_gflop": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 3),

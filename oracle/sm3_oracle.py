@@ -191,7 +191,8 @@ def cal_logits(f1, f2, P, B, proj1, proj2, temperature, training, stat_reduce=No
     return ntxent_logits(z, temperature)
 
 
-def sm3_v32_projections(P, B, derm_imgs, clinic_imgs, style, training=True, stat_reduce=None):
+def sm3_v32_projections(P, B, derm_imgs, clinic_imgs, style, training=True, stat_reduce=None,
+                        cross=("cross_proj.0.", "cross_proj.1.")):
     """Projector outputs of every loss term of SimCLRSkinV32.forward, in order derm, clinic, cross...;
     each [2B, proj_dim] (rows: first half = first projector's B rows)."""
     zd, df = simclr_projections(derm_imgs[0], derm_imgs[1], P, B, "derm_backbone.", training, stat_reduce)
@@ -199,21 +200,22 @@ def sm3_v32_projections(P, B, derm_imgs, clinic_imgs, style, training=True, stat
     pairs = {0: [(0, 0), (1, 1)], 1: [(0, 1), (1, 0)], 2: [(0, 0), (0, 1), (1, 0), (1, 1)]}[style]
     zs = [zd, zc]
     for a, b in pairs:
-        zs.append(torch.cat([projector(df[a], P, B, "cross_proj.0.", training, stat_reduce),
-                             projector(cf[b], P, B, "cross_proj.1.", training, stat_reduce)], dim=0))
+        zs.append(torch.cat([projector(df[a], P, B, cross[0], training, stat_reduce),
+                             projector(cf[b], P, B, cross[1], training, stat_reduce)], dim=0))
     return zs
 
 
 def sm3_v32_forward(P, B, derm_imgs, clinic_imgs, style, temperature, training=True,
-                    stat_reduce=None, taps=None):
-    """SimCLRSkinV32.forward, src/models/simclr.py:415-482."""
+                    stat_reduce=None, taps=None, cross=("cross_proj.0.", "cross_proj.1.")):
+    """SimCLRSkinV32.forward, src/models/simclr.py:415-482.  cross=("cross_proj.", "cross_proj.") gives
+    SimCLRSkinV3.forward (one shared cross projector, :324-391)."""
     derm_outs, df = simclr_forward(derm_imgs[0], derm_imgs[1], P, B, "derm_backbone.", temperature,
                                    training, stat_reduce, taps)
     clinic_outs, cf = simclr_forward(clinic_imgs[0], clinic_imgs[1], P, B, "clinic_backbone.",
                                      temperature, training, stat_reduce)
     pairs = {0: [(0, 0), (1, 1)], 1: [(0, 1), (1, 0)], 2: [(0, 0), (0, 1), (1, 0), (1, 1)]}[style]
     cross = tuple(
-        cal_logits(df[a], cf[b], P, B, "cross_proj.0.", "cross_proj.1.", temperature, training, stat_reduce)
+        cal_logits(df[a], cf[b], P, B, cross[0], cross[1], temperature, training, stat_reduce)
         for a, b in pairs
     )
     return derm_outs, clinic_outs, cross, (df, cf)

@@ -9,6 +9,7 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 model = SimCLRSkinV32("resnet50", None, 128, 0.1); model.sm3_dtype = torch.bfloat16; model.to(dev)
 tr = SM3Trainer(model, lr=1e-6)
+tr._engine().two_streams = False
 g = torch.Generator(device=dev).manual_seed(1)
 derm = [torch.randn(B, 3, 224, 224, device=dev, generator=g) for _ in range(2)]
 clinic = [torch.randn(B, 3, 224, 224, device=dev, generator=g) for _ in range(2)]

@@ -58,6 +58,7 @@ def _scratch_backward(eng, fn):
     eng.store.flat_g = scratch
     try:
         fn()
+        eng._sync_side()  # weight-gradient kernels run on a side stream
     finally:
         eng.store.flat_g = old
     return eng.store.grad_views(scratch)

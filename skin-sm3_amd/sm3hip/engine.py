@@ -254,6 +254,8 @@ class SM3Engine:
         self._ws = {}
         self._allocated = False
         self._lane = "main"
+        self.side_wgrad = False  # measured slower (2600 vs 2790 pairs/s): weight-gradient kernels fight the HBM-bound chain for L2/HBM
+        self._side = {}
         self.two_streams = True
         self._streams, self._streams_dev = None, None
 
@@ -442,13 +444,44 @@ class SM3Engine:
                          rows, C)
         return dxo, dy
 
+    def _wgrad(self, cu, r, dxo):
+        """Weight gradient on the lane's side stream: nothing on the critical path (data gradient -> BN backward ->
+        ...) depends on it, so it overlaps with those HBM-bound kernels and fills their tails."""
+        side = self._side_stream()
+        desc = cu.wgrad_desc(self.dtype, r.N, r.H, r.W)
+        gw = self._g(cu.name + ".weight")
+        if side is None:
+            ops.conv_wgrad(desc, r.x_in, dxo, gw)
+            return
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)  # dxo is ready
+        for t in (dxo, r.x_in):
+            t.record_stream(side)  # keep the allocator from recycling them while the side stream still reads
+        with torch.cuda.stream(side):
+            ops.conv_wgrad(desc, r.x_in, dxo, gw)
+
+    def _side_stream(self):
+        if not self.side_wgrad or self.store.flat_p.device.type != "cuda":
+            return None
+        st = self._side.get(self._lane)
+        if st is None:
+            st = torch.cuda.Stream(device=self.store.flat_p.device)
+            self._side[self._lane] = st
+        return st
+
+    def _sync_side(self):
+        """Current lane waits for its weight-gradient stream (before gradients are declared final)."""
+        st = self._side.get(self._lane)
+        if st is not None:
+            torch.cuda.current_stream().wait_stream(st)
+
     def conv_backward(self, r, dxo, need_dx=True, addend=None, into=None, fuse=None):
         """Weight gradient (accumulated into the flat gradient buffer) and, if need_dx, the data gradient.
         fuse: the Rec of the conv+BN unit whose OUTPUT this data gradient is the gradient of; its BN-backward
         phase 1 (ReLU mask + partial sums) then runs inside the data-gradient epilogue.
         Returns (dx, fused_rows) -- fused_rows is None when nothing was fused."""
         cu = r.cu
-        ops.conv_wgrad(cu.wgrad_desc(self.dtype, r.N, r.H, r.W), r.x_in, dxo, self._g(cu.name + ".weight"))
+        self._wgrad(cu, r, dxo)
         if not need_dx:
             return None, None
         descs, full = cu.dgrad_descs(self.dtype, r.N, r.H, r.W)
@@ -630,6 +663,7 @@ class SM3Engine:
 
     def _notify(self, plan_prefix_first, plan_prefix_last):
         if self.grad_ready is not None:
+            self._sync_side()
             self.grad_ready(plan_prefix_first, plan_prefix_last)
 
     def backward(self, saved, dz, dfeat=None):
@@ -653,6 +687,7 @@ class SM3Engine:
                 else:
                     dfe[key] = torch.zeros(2 * B, plan.out_dim, dtype=self.tdt, device=dev)
                 self._share(dfe[key], streams)
+                self._sync_side()
         self._join(streams)
         for ci, (a, b, pa, pb) in enumerate(saved["cross"]):
             d = dz[f"cross{ci}"]
@@ -669,6 +704,8 @@ class SM3Engine:
                 for v in (1, 0):
                     self.encoder_backward(saved[key]["enc"][v], dfe[key][v * B:(v + 1) * B], last_view=(v == 0))
                     saved[key]["enc"][v] = None  # free the view's activations as soon as it is done
+                self._sync_side()
+        self._sync_side()
         self._join(streams)
 
     def encoder_only(self, branch, x, train, want_grad):

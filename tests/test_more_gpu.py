@@ -1,0 +1,135 @@
+"""More GPU parity cases against the CPU oracle (f32-MFMA mode, T0 tolerances of tests/test_e2e_gpu.py):
+edge shapes (odd batch, non-square images, the 448x448 size of BASELINE config 5), SimCLRSkinV3's shared cross
+projector, eval-mode forward, a bare ResNet-50 with autograd, SimCLR alone, fp16-style loss scaling in AdamW."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _state(seed, spec=None):
+    from oracle import procedural
+    return procedural.make_state_dict(spec, seed=seed)
+
+
+def _imgs(B, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    mk = lambda: (torch.randn(B, 3, H, W, generator=g) * 0.7 + torch.randn(B, 3, 1, 1, generator=g))
+    return [mk(), mk()], [mk(), mk()]
+
+
+def _run_pair(cls_name, B, H, W, style, seed, cross):
+    from oracle import sm3_oracle as O
+    import src.models.simclr as M
+    state = _state(seed)
+    if cls_name == "SimCLRSkinV3":  # shared projector: rename cross_proj.0.* -> cross_proj.*, drop cross_proj.1.*
+        state = {k.replace("cross_proj.0.", "cross_proj."): v for k, v in state.items() if not k.startswith("cross_proj.1.")}
+    derm, clinic = _imgs(B, H, W, seed)
+    P, Bf = O.split_state(state, torch.float64)
+    outs = O.sm3_v32_forward(P, Bf, [d.double() for d in derm], [c.double() for c in clinic], style, 0.1, True,
+                             cross=cross)
+    loss = O.sm3_loss(outs, style)
+    loss.backward()
+    model = getattr(M, cls_name)("resnet50", None, 128, 0.1)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    model.sm3_dtype = torch.float32
+    model.cuda().train()
+    o = model([d.cuda() for d in derm], [c.cuda() for c in clinic], style)
+    crit = torch.nn.CrossEntropyLoss()
+    w = 0.25 if style == 2 else 0.5
+    l = crit(*o[0]) + crit(*o[1]) + sum(w * crit(*x) for x in o[2])
+    l.backward()
+    torch.cuda.synchronize()
+    assert abs(float(l.detach()) - float(loss.detach())) < 1e-3
+    for got, ref in [(o[0], outs[0]), (o[1], outs[1])] + list(zip(o[2], outs[2])):
+        assert (got[0].detach().cpu().double() - ref[0].detach()).abs().max().item() < 2e-3
+    gn = {k: p.grad.double().norm().item() for k, p in model.named_parameters()}
+    rn = {k: p.grad.norm().item() for k, p in P.items()}
+    tot_g = np.sqrt(sum(v * v for v in gn.values()))
+    tot_r = np.sqrt(sum(v * v for v in rn.values()))
+    assert abs(tot_g - tot_r) < 3e-2 * tot_r
+    bad = [k for k in gn if abs(gn[k] - rn[k]) > 6e-2 * rn[k] + 1e-6]
+    assert len(bad) <= 3, bad[:5]
+
+
+@pytest.mark.parametrize("B,H,W,style", [(5, 64, 96, 1), (2, 448, 448, 0)], ids=["odd-batch-nonsquare", "448"])
+def test_edge_shapes_v32(B, H, W, style):
+    _run_pair("SimCLRSkinV32", B, H, W, style, seed=11, cross=("cross_proj.0.", "cross_proj.1."))
+
+
+def test_v3_shared_cross_projector():
+    _run_pair("SimCLRSkinV3", 6, 64, 64, 2, seed=12, cross=("cross_proj.", "cross_proj."))
+
+
+def test_eval_mode_forward_uses_running_statistics():
+    from oracle import sm3_oracle as O
+    from src.models.simclr import SimCLRSkinV32
+    state = _state(13)
+    derm, clinic = _imgs(4, 64, 64, 13)
+    P, Bf = O.split_state(state, torch.float64, requires_grad=False)
+    outs = O.sm3_v32_forward(P, Bf, [d.double() for d in derm], [c.double() for c in clinic], 0, 0.1, False)
+    model = SimCLRSkinV32("resnet50", None, 128, 0.1)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model.sm3_dtype = torch.float32
+    model.cuda().eval()
+    with torch.no_grad():
+        o = model([d.cuda() for d in derm], [c.cuda() for c in clinic], 0)
+    for got, ref in [(o[0], outs[0]), (o[1], outs[1])] + list(zip(o[2], outs[2])):
+        assert (got[0].cpu().double() - ref[0]).abs().max().item() < 2e-3
+    sd = model.state_dict()
+    assert int(sd["derm_backbone.encoder.bn1.num_batches_tracked"]) == 0  # eval: buffers untouched
+    assert torch.equal(sd["derm_backbone.encoder.bn1.running_mean"].cpu(), torch.from_numpy(state["derm_backbone.encoder.bn1.running_mean"]))
+
+
+def test_bare_resnet50_forward_backward():
+    """resnet.__dict__['resnet50'](weights=None) as used by inference.py / Baseline: features + autograd."""
+    from oracle import procedural, sm3_oracle as O
+    import resnet
+    spec = procedural.resnet50_spec("")
+    state = procedural.make_state_dict(spec, seed=14)
+    x = _imgs(3, 64, 64, 14)[0][0]
+    P, Bf = O.split_state(state, torch.float64)
+    f_ref = O.resnet50_features(x.double(), P, Bf, "", True)
+    (f_ref ** 2).sum().backward()
+    m = resnet.resnet50(weights=None)
+    m.fc = torch.nn.Identity()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    m.sm3_dtype = torch.float32
+    m.cuda().train()
+    f = m(x.cuda())
+    (f ** 2).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.allclose(f.detach().cpu().double(), f_ref.detach(), rtol=1e-3, atol=1e-3)
+    for k in ("conv1.weight", "layer4.2.bn3.weight", "layer2.0.downsample.0.weight", "layer1.0.conv2.weight"):
+        g, r = dict(m.named_parameters())[k].grad.cpu().double(), P[k].grad
+        assert (g - r).norm() <= 3e-2 * r.norm(), k
+
+
+def test_simclr_alone():
+    from oracle import procedural, sm3_oracle as O
+    from src.models.simclr import SimCLR
+    spec = procedural.resnet50_spec("encoder.") + procedural.projector_spec("projector.")
+    state = procedural.make_state_dict(spec, seed=15)
+    x1, x2 = _imgs(4, 64, 64, 15)[0]
+    P, Bf = O.split_state(state, torch.float64)
+    (lg_ref, _), _ = O.simclr_forward(x1.double(), x2.double(), P, Bf, "", 0.5, True)
+    m = SimCLR("resnet50", None, 128, 0.5)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    m.sm3_dtype = torch.float32
+    m.cuda().train()
+    lg, lab = m(x1.cuda(), x2.cuda())
+    torch.cuda.synchronize()
+    assert lab.dtype == torch.long and tuple(lg.shape) == (8, 7)
+    assert (lg.detach().cpu().double() - lg_ref.detach()).abs().max().item() < 2e-3
+
+
+def test_adamw_grad_scale_and_overflow_skip_in_trainer_units():
+    """GradScaler semantics folded into sm3_adamw: g*grad_scale, whole step skipped when found_inf is set."""
+    from sm3hip import ops
+    D = torch.device("cuda:0")
+    p = torch.ones(1024, device=D); g = torch.full((1024,), 8.0, device=D)
+    m, v = torch.zeros(1024, device=D), torch.zeros(1024, device=D)
+    ops.adamw(p, g, m, v, 1e-2, 0.9, 0.999, 1e-5, 0.0, 1, grad_scale=1.0 / 8)
+    torch.cuda.synchronize()
+    assert torch.allclose(m, torch.full_like(m, 0.1)) and torch.allclose(p, torch.full_like(p, 1 - 1e-2), atol=1e-6)
