@@ -28,6 +28,9 @@ static RowWalk make_walk(int64_t rows, int cvecs, int max_gy) {
     if (w.tby < 1) w.tby = 1;
     w.gx = (cvecs + w.tbx - 1) / w.tbx;
     int64_t gy = (rows + (int64_t)w.tby * 8 - 1) / ((int64_t)w.tby * 8);  // >= 8 rows per thread
+    // at most 2048 blocks (8 per CU, all resident at once): a grid of 1.5 x that runs a half-empty second round
+    const int64_t cap = 2048 / w.gx > 0 ? 2048 / w.gx : 1;
+    if (gy > cap) gy = cap;
     if (gy > max_gy) gy = max_gy;
     if (gy < 1) gy = 1;
     w.gy = (int)gy;

@@ -284,7 +284,10 @@ def bn_act(dtype, x, scale, shift, residual, relu, y, rows, Cn, out_f32=False, m
     if mask is not None and mask.numel() != rows * Cn // (16 // _sz(dtype)):
         raise ValueError("bn_act: mask size mismatch")
     n = rows * Cn
-    with _prof("bn_act", 0.0, _sz(dtype) * n * (2 if residual is None else 3)):
+    tag = "bn_act"
+    if _PROFILER is not None and getattr(_PROFILER, "detail", False):
+        tag += f"|rows{rows}_C{Cn}_res{int(residual is not None)}"
+    with _prof(tag, 0.0, _sz(dtype) * n * (2 if residual is None else 3)):
         check(_lib.load().sm3_bn_act(dtype, _ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), int(relu),
                                      int(out_f32), _ptr(y), _ptr(mask), rows, Cn, _stream()), "sm3_bn_act")
 
@@ -320,7 +323,10 @@ def bn_bwd_apply(dtype, dz, x, mean, invstd, gamma, gsums, count, lsums, dgamma,
             raise ValueError(f"bn_bwd_apply: {n} size mismatch")
     _chk(gsums, torch.float64); _chk(lsums, torch.float64)
     _chk(dgamma, torch.float32); _chk(dbeta, torch.float32); _chk(gamma, torch.float32)
-    with _prof("bn_bwd_apply", 0.0, _sz(dtype) * rows * Cn * 3):
+    tag = "bn_bwd_apply"
+    if _PROFILER is not None and getattr(_PROFILER, "detail", False):
+        tag += f"|rows{rows}_C{Cn}"
+    with _prof(tag, 0.0, _sz(dtype) * rows * Cn * 3):
         check(_lib.load().sm3_bn_bwd_apply(dtype, _ptr(dz), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma),
                                            _ptr(gsums), float(count), _ptr(lsums), _ptr(dgamma), _ptr(dbeta), _ptr(dx),
                                            rows, Cn, _stream()), "sm3_bn_bwd_apply")
