@@ -255,8 +255,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int c = cv * E + e;
-            if (dbeta) dbeta[c] += (float)lsums[c];
-            if (dgamma) dgamma[c] += (float)lsums[C + c];
+            // atomics: the two views of an encoder may run their backward on two streams at once
+            if (dbeta) atomicAdd(&dbeta[c], (float)lsums[c]);
+            if (dgamma) atomicAdd(&dgamma[c], (float)lsums[C + c]);
         }
     }
     const int64_t rstep = (int64_t)gridDim.y * tby;

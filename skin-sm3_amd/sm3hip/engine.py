@@ -254,6 +254,13 @@ class SM3Engine:
         self._ws = {}
         self._allocated = False
         self._lane = "main"
+        self._view = 0
+        # the two views of a branch on two more streams (BN running statistics stay ordered through events): correct
+        # (GPU test suite passes with it on) but measured slower -- 2 700 vs 2 780 pairs/s -- so off: two lanes
+        # already keep HBM and MFMA busy, four only add contention
+        self.view_lanes = False
+        self._bn_ev = {}
+        self._ordered_bn = False  # set while the two views of a branch run on two lanes
         self.side_wgrad = False  # measured slower (2600 vs 2790 pairs/s): weight-gradient kernels fight the HBM-bound chain for L2/HBM
         self._side = {}
         self.two_streams = True
@@ -321,6 +328,8 @@ class SM3Engine:
             return None
         if self._streams is None or self._streams_dev != device:
             self._streams = {k: torch.cuda.Stream(device=device) for k in self.branches}
+            if self.view_lanes:  # second view of every branch on a lane of its own
+                self._streams.update({k + "#1": torch.cuda.Stream(device=device) for k in self.branches})
             self._streams_dev = device
         return self._streams
 
@@ -331,6 +340,8 @@ class SM3Engine:
         def __enter__(self):
             self.prev = self.eng._lane
             self.eng._lane = self.key
+            self.prev_view = self.eng._view
+            self.eng._view = 1 if self.key.endswith("#1") else 0
             if self.stream is not None:
                 self.stream.wait_stream(torch.cuda.current_stream())  # everything enqueued so far is visible
                 self.ctx = torch.cuda.stream(self.stream)
@@ -341,6 +352,7 @@ class SM3Engine:
             if self.ctx is not None:
                 self.ctx.__exit__(*exc)
             self.eng._lane = self.prev
+            self.eng._view = self.prev_view
             return False
 
     def lane(self, key, streams):
@@ -396,8 +408,18 @@ class SM3Engine:
                 sums, groups = ops.bn_stats_reduce(partials, prow, C, None)
             mean = torch.empty(C, dtype=torch.float32, device=dev)
             invstd = torch.empty(C, dtype=torch.float32, device=dev)
+            ordered = self._ordered_bn and dev.type == "cuda"
+            if ordered and self._view == 1:
+                # running_mean/var/num_batches_tracked are updated view 0 first, then view 1, as in the reference's
+                # sequential encoder(x1); encoder(x2): the view-1 lane waits for view 0's update of THIS BatchNorm
+                torch.cuda.current_stream().wait_event(self._bn_ev[bu.name])
             ops.bn_finalize(sums, count, C, gamma, beta, BN_EPS, BN_MOMENTUM, rm, rv,
                             self.buffers[bu.name + ".num_batches_tracked"], scale, shift, mean, invstd, groups=groups)
+            if ordered and self._view == 0:
+                ev = self._bn_ev.get(bu.name)
+                if ev is None:
+                    ev = self._bn_ev[bu.name] = torch.cuda.Event()
+                ev.record()
         else:
             ops.conv_gemm(d, x, cu.w_fwd, xo, None, None)
             ops.bn_eval_scale_shift(gamma, beta, rm, rv, BN_EPS, C, scale, shift)
@@ -632,14 +654,24 @@ class SM3Engine:
             imgs = views[key]
             for im in imgs:
                 self._share(im, streams)
+            f32 = self._share(torch.empty(2 * B, plan.out_dim, dtype=torch.float32, device=dev), streams)
+            ft = self._share(torch.empty(2 * B, plan.out_dim, dtype=self.tdt, device=dev), streams)
+            ctxs = [None, None] if want_grad else None
+            split = bool(streams) and self.view_lanes
+            self._ordered_bn = split and train
+            # the two views go through the encoder separately: BN statistics per view (simclr.py:58-59)
+            for v in (0, 1):
+                with self.lane(key + "#1" if (split and v == 1) else key, streams):
+                    tmp = [] if want_grad else None
+                    self.encoder_forward(plan, imgs[v], train, f32[v * B:(v + 1) * B], ft[v * B:(v + 1) * B], tmp)
+                    if want_grad:
+                        ctxs[v] = tmp[0]
+            self._ordered_bn = False
+            feats[key] = (f32, ft)
+            precs = sv()
             with self.lane(key, streams):
-                f32 = torch.empty(2 * B, plan.out_dim, dtype=torch.float32, device=dev)
-                ft = torch.empty(2 * B, plan.out_dim, dtype=self.tdt, device=dev)
-                ctxs = sv()
-                for v in (0, 1):  # the two views go through the encoder separately: BN statistics per view (simclr.py:58-59)
-                    self.encoder_forward(plan, imgs[v], train, f32[v * B:(v + 1) * B], ft[v * B:(v + 1) * B], ctxs)
-                feats[key] = (self._share(f32, streams), self._share(ft, streams))
-                precs = sv()
+                if split:
+                    torch.cuda.current_stream().wait_stream(streams[key + "#1"])
                 if proj is not None:  # in-modal projector on cat([f1, f2])  (simclr.py:61)
                     z = torch.empty(2 * B, self.module.proj_dim, dtype=torch.float32, device=dev)
                     self.projector_forward(proj, ft, 2 * B, train, z, precs)
@@ -699,12 +731,22 @@ class SM3Engine:
                 self._notify(proj.prefix, proj.prefix)
         if self.cross is not None:
             self._notify(self.cross[0].prefix, self.cross[-1].prefix)
+        split = bool(streams) and self.view_lanes
         for key, (plan, proj) in self.branches.items():
-            with self.lane(key, streams):
-                for v in (1, 0):
-                    self.encoder_backward(saved[key]["enc"][v], dfe[key][v * B:(v + 1) * B], last_view=(v == 0))
+            for v in (1, 0):
+                with self.lane(key + "#1" if (split and v == 1) else key, streams):
+                    # with the views on two lanes a stage's gradients are final only when BOTH are done: the
+                    # per-stage notifications of the last view are replaced by one round after the join below
+                    self.encoder_backward(saved[key]["enc"][v], dfe[key][v * B:(v + 1) * B],
+                                          last_view=(v == 0 and not split))
                     saved[key]["enc"][v] = None  # free the view's activations as soon as it is done
-                self._sync_side()
+                    self._sync_side()
+            if split:
+                with self.lane(key, streams):
+                    torch.cuda.current_stream().wait_stream(streams[key + "#1"])
+                    for li in (4, 3, 2):
+                        self._notify(f"{plan.prefix}layer{li}.", f"{plan.prefix}layer{li}.")
+                    self._notify(plan.prefix + "conv1", plan.prefix + "layer1.")
         self._sync_side()
         self._join(streams)
 

@@ -46,7 +46,8 @@ class SM3Trainer:
             # communicator execute in enqueue order, so with a single one the clinic lane's first statistics
             # all-reduce would queue behind ALL of the derm lane's and the lanes would serialise.  Every rank
             # creates the groups in the same order; each lane's call sequence is identical on every rank.
-            self._groups = {k: dist.new_group() for k in list(eng.branches) + ["main"]}
+            lanes = list(eng.branches) + [k + "#1" for k in eng.branches] + ["main"]
+            self._groups = {k: dist.new_group() for k in lanes}
         if self.dp and self.sync_bn and eng.__dict__.get("_explicit_sync") is None:
             eng.world_size = self.world
             eng.stat_sync = lambda t: dist.all_reduce(t, group=self._groups[eng._lane])
