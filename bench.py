@@ -108,11 +108,18 @@ def main():
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    # test knobs (a 2-rank rehearsal of this file on a one-GPU box: both ranks on device 0 over gloo)
+    backend = os.environ.get("SM3_DIST_BACKEND", "nccl")
+    if "SM3_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["SM3_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from sm3hip import ops, profiler
     from sm3hip.trainer import SM3Trainer
