@@ -84,6 +84,14 @@ typedef struct sm3_bn_bwd_fuse {
 int sm3_conv_dgrad_bnfuse(const sm3_conv_desc* d, const void* dy_in, const void* w_dgrad, void* dz_out,
                           const void* addend, const sm3_bn_bwd_fuse* fuse, void* stream);
 
+/* Inference: conv + eval-mode BatchNorm (+ residual) (+ ReLU) in one launch,
+ *   y = relu?( conv(x, w) * scale[co] + shift[co] (+ residual) ),
+ * scale/shift from sm3_bn_eval_scale_shift.  Replaces the conv->bn->(add)->relu chains of Bottleneck.forward
+ * (src/models/resnet.py:154-174) under model.eval(): frozen-encoder feature extraction (simclr.py:393-396,
+ * tools/backbone_eval.py --finetune fc, inference.py) never writes or re-reads a pre-BN tensor. */
+int sm3_conv_bn_act_eval(const sm3_conv_desc* d, const void* x, const void* w, const float* scale,
+                         const float* shift, const void* residual, int relu, void* y, void* stream);
+
 /* Weight gradient of the forward conv described by d (autograd of the same call sites):
  *   dw[co*w_row_stride + wtap[t]*Ci + ci] += sum_{n,oy,ox} dy[(n,oy,ox), co] * x[n, oy*sy+dy[t], ox*sx+dx[t], ci]
  * dy is dense [N*Ho*Wo, Co]; dw is fp32 and is accumulated into (float atomics, split over pixels).

@@ -139,6 +139,40 @@ def run_case(SimCLRSkinV32, batch, size, seed, dtype, style, lr, tag):
     return names
 
 
+def run_baseline_case(batch, size, seed, dtype, tag):
+    """The linear-probe model of tools/backbone_eval.py (reference src/models/baseline.py): eval-mode forward and
+    one weighted-CE backward through the heads (frozen encoders, --finetune fc)."""
+    from src.models.baseline import Baseline  # the reference's class (timm stubbed)
+    torch.manual_seed(0)
+    model = Baseline("resnet50", None)
+    state = procedural.make_state_dict(procedural.baseline_spec(), seed=seed)
+    assert list(state.keys()) == list(model.state_dict().keys()), "Baseline state_dict key order differs"
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    model = model.to(dtype).eval()
+    for p in list(model.derm_backbone.parameters()) + list(model.clinic_backbone.parameters()):
+        p.requires_grad = False
+    derm_np, clinic_np = procedural.make_pair_batch(batch, size, seed)
+    derm, clinic = torch.from_numpy(derm_np[0]).to(dtype), torch.from_numpy(clinic_np[0]).to(dtype)
+    r = np.random.RandomState(seed)
+    labels = torch.from_numpy(np.stack([r.randint(0, n, size=batch) for n in (5, 3, 2, 3, 3, 3, 3, 2)], axis=1)).long()
+    weights = [1.0, 0.5, 2.0, 1.0, 1.0, 1.5, 1.0, 1.0]
+    outputs = model([derm, clinic])
+    crit = torch.nn.CrossEntropyLoss()
+    loss = sum(w * crit(o, labels[:, i]) for i, (o, w) in enumerate(zip(outputs, weights))) / 8
+    loss.backward()
+    out = {"meta": np.array([batch, size, seed], dtype=np.int64), "labels": labels.numpy(),
+           "label_weights": np.array(weights), "loss": np.array(loss.item())}
+    for i, o in enumerate(outputs):
+        out[f"logits_{i}"] = o.detach().double().numpy()
+        out[f"grad_w_{i}"] = _subsample(model.classifier[i].weight.grad, 512)
+        out[f"grad_b_{i}"] = model.classifier[i].bias.grad.double().numpy()
+    path = os.path.join(OUT, f"baseline_{tag}.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: loss={loss.item():.8f} ({os.path.getsize(path)/1024:.0f} KiB)")
+    with open(os.path.join(OUT, "baseline_state_dict_keys.txt"), "w") as f:
+        f.write("\n".join(model.state_dict().keys()) + "\n")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -147,6 +181,7 @@ def main():
     run_case(cls, batch=4, size=64, seed=1, dtype=torch.float64, style=0, lr=1e-3, tag="b4_s64_f64")
     run_case(cls, batch=3, size=96, seed=2, dtype=torch.float64, style=2, lr=1e-3, tag="b3_s96_style2_f64")
     run_case(cls, batch=8, size=64, seed=3, dtype=torch.float64, style=1, lr=1e-3, tag="b8_s64_style1_f64")
+    run_baseline_case(batch=6, size=64, seed=4, dtype=torch.float64, tag="b6_s64_f64")
     with open(os.path.join(OUT, "param_names.txt"), "w") as f:
         f.write("\n".join(names) + "\n")
     # the 700 state_dict keys = checkpoint wire format (tools/backbone_train.py:578-587)

@@ -62,6 +62,16 @@ def sm3_v32_spec(proj_dim=128):
     return spec
 
 
+def baseline_spec():
+    """state_dict layout of the linear-probe model Baseline('resnet50') (src/models/baseline.py:60-96)."""
+    spec = []
+    for bb in ("derm_backbone.", "clinic_backbone."):
+        spec += resnet50_spec(bb)
+    for i, n in enumerate((5, 3, 2, 3, 3, 3, 3, 2)):
+        spec += [(f"classifier.{i}.weight", (n, 4096)), (f"classifier.{i}.bias", (n,))]
+    return spec
+
+
 def _rng(key, seed):
     return np.random.RandomState((zlib.crc32(key.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
 

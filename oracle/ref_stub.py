@@ -70,3 +70,5 @@ def install():
     utils._ovewrite_named_param = _ovewrite_named_param
     utils.handle_legacy_interface = lambda **weights: (lambda fn: fn)
     utils._ModelURLs = type("_ModelURLs", (dict,), {})
+    if "timm" not in sys.modules:  # src/models/baseline.py:4 imports timm for an arch family the path never uses
+        _mod("timm").create_model = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("timm is not installed"))

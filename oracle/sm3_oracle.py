@@ -237,6 +237,34 @@ def extract(P, B, derm, clinic):
 
 
 # --------------------------------------------------------------------------------------
+# Linear probe (tools/backbone_eval.py)
+# --------------------------------------------------------------------------------------
+def baseline_forward(P, B, derm, clinic, training=False):
+    """Baseline.forward, src/models/baseline.py:98-102: two encoders, concatenated features, 8 Linear heads."""
+    fd = resnet50_features(derm, P, B, "derm_backbone.", training)
+    fc = resnet50_features(clinic, P, B, "clinic_backbone.", training)
+    feats = torch.cat([fd, fc], dim=1)
+    return [F.linear(feats, P[f"classifier.{i}.weight"], P[f"classifier.{i}.bias"]) for i in range(8)]
+
+
+def linear_probe_loss(outputs, labels, label_weights=(1.0,) * 8):
+    """tools/backbone_eval.py:101-105: sum_i w_i * CE(out_i, labels[:, i]) / num_labels."""
+    return sum(w * F.cross_entropy(o, labels[:, i]) for i, (o, w) in enumerate(zip(outputs, label_weights))) / len(outputs)
+
+
+def auroc_selected(preds, targets, num_classes=(5, 3, 2, 3, 3, 3, 3, 2), cls_weights=(2, 2, 1, 2, 2, 2, 2, 1)):
+    """src/utils/misc.py:299-327 with torchmetrics' multiclass_auroc(average=None) restated through
+    sklearn.metrics.roc_auc_score on softmax probabilities (one-vs-rest, the class index CLS_WEIGHTS[i]);
+    returns (per-label values, their mean = AUC_AVG)."""
+    from sklearn.metrics import roc_auc_score
+    per = []
+    for i, (n, c) in enumerate(zip(num_classes, cls_weights)):
+        prob = torch.softmax(preds[i].double(), dim=1)[:, c].numpy()
+        per.append(float(roc_auc_score((targets[:, i].numpy() == c).astype(int), prob)))
+    return per, sum(per) / len(per)
+
+
+# --------------------------------------------------------------------------------------
 # AdamW
 # --------------------------------------------------------------------------------------
 def adamw_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-5, weight_decay=5e-2):

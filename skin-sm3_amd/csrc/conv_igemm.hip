@@ -42,6 +42,10 @@ struct ConvParams {
     const float* fz_invstd;
     float* fz_partials;         // [fz_row_off + tilesM][2][Co]
     int fz_row_off;
+    // optional inference epilogue: y = relu?(acc * ep_scale[co] + ep_shift[co] (+ addend))  (eval-mode BatchNorm)
+    const float* ep_scale;
+    const float* ep_shift;
+    int ep_relu;
 };
 
 template <typename T>
@@ -291,13 +295,15 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
         }
     }
 
+    // f_mu/f_is double as the inference epilogue's per-channel scale/shift (the two modes are exclusive)
+    const bool ep = p.ep_scale != nullptr;
     float f_mu[EPC], f_is[EPC], f_s1[EPC], f_s2[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
         f_s1[e] = 0.f;
         f_s2[e] = 0.f;
-        f_mu[e] = (fz && ncol < p.Co) ? p.fz_mean[ncol + e] : 0.f;
-        f_is[e] = (fz && ncol < p.Co) ? p.fz_invstd[ncol + e] : 0.f;
+        f_mu[e] = (ncol < p.Co) ? (fz ? p.fz_mean[ncol + e] : (ep ? p.ep_shift[ncol + e] : 0.f)) : 0.f;
+        f_is[e] = (ncol < p.Co) ? (fz ? p.fz_invstd[ncol + e] : (ep ? p.ep_scale[ncol + e] : 0.f)) : 0.f;
     }
 
 #pragma unroll
@@ -367,11 +373,19 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
                 v[e + 3] = q.w;
             }
             const long boff = e_off[k] * SZ;
+            if (ep) {  // eval-mode BatchNorm folded into the epilogue (f32, before the residual add)
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = v[e] * f_is[e] + f_mu[e];
+            }
             if (p.addend) {
                 float a[EPC];
                 unpack16<T>(pre_add[k], a);
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) v[e] += a[e];
+            }
+            if (ep && p.ep_relu) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = fmaxf(v[e], 0.f);
             }
             if (fz) {
                 // BN-backward phase 1 fused here (data-gradient launches): the value just computed is dy of the
@@ -490,7 +504,8 @@ extern "C" int sm3_conv_partial_rows(const sm3_conv_desc* d) {
 }
 
 static int conv_gather_gemm_impl(const sm3_conv_desc* d, const void* x, const void* w, void* y, const void* addend,
-                                 float* stat_partials, const sm3_bn_bwd_fuse* fuse, void* stream) {
+                                 float* stat_partials, const sm3_bn_bwd_fuse* fuse, void* stream,
+                                 const float* ep_scale = nullptr, const float* ep_shift = nullptr, int ep_relu = 0) {
     if (!d || !x || !w || !y) return SM3_EINVAL;
     if (fuse && (!fuse->x || !fuse->mean || !fuse->invstd || !fuse->partials || fuse->partial_row_offset < 0))
         return SM3_EINVAL;
@@ -507,6 +522,9 @@ static int conv_gather_gemm_impl(const sm3_conv_desc* d, const void* x, const vo
     p.fz_invstd = fuse ? fuse->invstd : nullptr;
     p.fz_partials = fuse ? fuse->partials : nullptr;
     p.fz_row_off = fuse ? fuse->partial_row_offset : 0;
+    p.ep_scale = ep_scale;
+    p.ep_shift = ep_shift;
+    p.ep_relu = ep_relu;
     hipStream_t st = (hipStream_t)stream;
     const bool narrow = d->Co <= 64;
     if (d->dtype == SM3_BF16)
@@ -523,4 +541,10 @@ extern "C" int sm3_conv_dgrad_bnfuse(const sm3_conv_desc* d, const void* dy_in, 
                                      const void* addend, const sm3_bn_bwd_fuse* fuse, void* stream) {
     if (!fuse) return SM3_EINVAL;
     return conv_gather_gemm_impl(d, dy_in, w_dgrad, dz_out, addend, nullptr, fuse, stream);
+}
+
+extern "C" int sm3_conv_bn_act_eval(const sm3_conv_desc* d, const void* x, const void* w, const float* scale,
+                                    const float* shift, const void* residual, int relu, void* y, void* stream) {
+    if (!scale || !shift) return SM3_EINVAL;
+    return conv_gather_gemm_impl(d, x, w, y, residual, nullptr, nullptr, stream, scale, shift, relu);
 }

@@ -46,6 +46,7 @@ SIGNATURES = {
     "sm3_conv_partial_rows": [_DESC],
     "sm3_conv_gather_gemm": [_DESC, _P, _P, _P, _P, _P, _P],
     "sm3_conv_dgrad_bnfuse": [_DESC, _P, _P, _P, _P, _P, _P],
+    "sm3_conv_bn_act_eval": [_DESC, _P, _P, _P, _P, _P, _I, _P, _P],
     "sm3_conv_wgrad": [_DESC, _P, _P, _P, _P],
     "sm3_bn_stats_reduce": [_P, _I, _I, _P, _P, _P],
     "sm3_bn_reduce_groups": [_I],

@@ -420,6 +420,13 @@ class SM3Engine:
                 if ev is None:
                     ev = self._bn_ev[bu.name] = torch.cuda.Event()
                 ev.record()
+        elif save is None and not out_f32:
+            # inference: conv + running-statistics BN (+residual) (+ReLU) in ONE launch, no pre-BN tensor in HBM
+            ops.bn_eval_scale_shift(gamma, beta, rm, rv, BN_EPS, C, scale, shift)
+            if y_out is None:
+                y_out = xo
+            ops.conv_bn_act_eval(d, x, cu.w_fwd, scale, shift, residual, relu, y_out)
+            return y_out, Ho, Wo
         else:
             ops.conv_gemm(d, x, cu.w_fwd, xo, None, None)
             ops.bn_eval_scale_shift(gamma, beta, rm, rv, BN_EPS, C, scale, shift)

@@ -198,6 +198,28 @@ def conv_dgrad_bnfuse(desc, dy_in, w_dgrad, dz_out, addend, mask, bn_x, mean, in
     return prow
 
 
+def conv_bn_act_eval(desc, x, w, scale, shift, residual, relu, y):
+    """conv + eval-mode BN (+residual) (+ReLU) in one launch (sm3_conv_bn_act_eval)."""
+    tdt = TORCH_DTYPE[desc.dtype]
+    _chk(x, tdt, "x"); _chk(w, tdt, "w"); _chk(y, tdt, "y"); _chk(residual, tdt, "residual")
+    _chk(scale, torch.float32, "scale"); _chk(shift, torch.float32, "shift")
+    if x.numel() != desc.N * desc.Hi * desc.Wi * desc.Ci:
+        raise ValueError("x size does not match descriptor")
+    n_out = desc.N * desc.Hout * desc.Wout * desc.Co
+    if y.numel() != n_out or (residual is not None and residual.numel() != n_out):
+        raise ValueError("y / residual size does not match descriptor")
+    if scale.numel() < desc.Co or shift.numel() < desc.Co:
+        raise ValueError("scale/shift too small")
+    if desc.Ci % K_CHUNK[desc.dtype]:
+        raise ValueError(f"Ci={desc.Ci} is not a multiple of {K_CHUNK[desc.dtype]}")
+    M = desc.N * desc.Ho * desc.Wo
+    sz = _sz(desc.dtype)
+    with _prof("conv_gemm_128x64" if desc.Co <= 64 else "conv_gemm_128x128", 2.0 * M * desc.Co * desc.ntaps * desc.Ci,
+               sz * (min(x.numel(), M * desc.ntaps * desc.Ci) + M * desc.Co * (2 if residual is not None else 1))):
+        check(_lib.load().sm3_conv_bn_act_eval(C.byref(desc), _ptr(x), _ptr(w), _ptr(scale), _ptr(shift),
+                                               _ptr(residual), int(relu), _ptr(y), _stream()), "sm3_conv_bn_act_eval")
+
+
 def conv_wgrad(desc, x, dy, dw):
     tdt = TORCH_DTYPE[desc.dtype]
     _chk(x, tdt, "x"); _chk(dy, tdt, "dy"); _chk(dw, torch.float32, "dw")
