@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--workload", default="pretrain", choices=["pretrain", "linear_probe"],
+                    help="pretrain = BASELINE.json's metric (default); linear_probe = SURVEY.md 8f-1 (tools/backbone_eval.py "
+                         "--finetune fc step at run.sh's batch 128: frozen eval-mode encoders + 8 trained heads)")
     ap.add_argument("--breakdown", default=None, help="write a per-kernel-class time/FLOP/byte table (one extra, "
                                                        "untimed, fully instrumented step) to this file")
     return ap.parse_args()
@@ -96,8 +99,63 @@ def cpu_baseline(batch, img, steps):
                       f"{steps} timed steps, median {med:.2f} s/step"}
 
 
+def linear_probe_bench(args):
+    """Secondary line: the linear-probe step of tools/backbone_eval.py:98-112 (--finetune fc), single GPU."""
+    from sm3hip import ops, profiler
+    from src.models.baseline import Baseline, NUM_CLASSES
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3407)
+    B, S = (128 if args.batch == 256 else args.batch), args.img
+    m = Baseline("resnet50", None)
+    m.freeze_backbone()
+    for bb in (m.derm_backbone, m.clinic_backbone):
+        bb.sm3_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    m.to(dev).eval()
+    opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3, weight_decay=5e-2)
+    crit = torch.nn.CrossEntropyLoss()
+    g = torch.Generator(device=dev).manual_seed(3407)
+    derm = torch.randn(B, 3, S, S, device=dev, generator=g)
+    clinic = torch.randn(B, 3, S, S, device=dev, generator=g)
+    labels = torch.stack([torch.randint(0, n, (B,), device=dev, generator=g) for n in NUM_CLASSES], dim=1)
+
+    def step():
+        outs = m([derm, clinic])
+        loss = sum(crit(o, labels[:, i]) for i, o in enumerate(outs)) / 8
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    prof = profiler.Profiler(only={"conv_gemm_128x128"})
+    torch.cuda.synchronize()
+    ops.set_profiler(prof)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.set_profiler(None)
+    dom = prof.summary().get("conv_gemm_128x128", {"flops": 0.0, "ms": 0.0, "launches": 0})
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+    peak = MFMA_PEAK_TFLOPS[args.dtype]
+    print(json.dumps({
+        "metric": "SM3 linear-probe pairs/sec (224x224, frozen ResNet-50 x2 + 8 heads)", "value": round(B * args.steps / elapsed, 2),
+        "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"tools/backbone_eval.py --finetune fc step, Baseline(resnet50 x2), batch {B}, {S}x{S}",
+                   "global_batch": B, "parallelism": "dp1", "loss": round(float(loss), 5)},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                     "frac": round(achieved / peak, 4), "traffic": None,
+                     "kernel": "conv_igemm_kernel<bf16_t,128,128,2,2,*> with the conv+evalBN+ReLU epilogue"}}), flush=True)
+
+
 def main():
     args = parse()
+    if args.workload == "linear_probe":
+        return linear_probe_bench(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -188,6 +188,11 @@ def main():
     keys = [k for k, _ in procedural.sm3_v32_spec()]
     with open(os.path.join(OUT, "state_dict_keys.txt"), "w") as f:
         f.write("\n".join(keys) + "\n")
+    # ... and each entry's shape / dtype as the REFERENCE's model reports them
+    import json
+    ref_sd = cls("resnet50", None, 128, 0.1).state_dict()
+    with open(os.path.join(OUT, "state_dict_shapes.json"), "w") as f:
+        json.dump({k: [list(v.shape), str(v.dtype)] for k, v in ref_sd.items()}, f)
 
 
 if __name__ == "__main__":

@@ -134,3 +134,26 @@ def test_loss_weights_follow_reference():
         names = ["derm", "clinic"] + [f"cross{i}" for i in range(4 if style == 2 else 2)]
         ws = tr._weights(names)
         assert ws["derm"] == 1.0 and ws["clinic"] == 1.0 and all(ws[n] == w for n in names[2:])
+
+
+def test_checkpoint_wire_format_round_trip(model, golden_dir, tmp_path):
+    """tools/backbone_train.py:575-592 / src/utils/misc.py:462-494: what this build saves has the reference's keys,
+    shapes and dtypes (conv weights OIHW), survives torch.save/torch.load, and loads back (strict) after the
+    parameters were re-bound to the flat channels_last store."""
+    import json
+    from sm3hip.engine import ParamStore
+    shapes = json.load(open(os.path.join(golden_dir, "state_dict_shapes.json")))
+    ParamStore(model, torch.device("cpu"))  # parameters become views into the flat buffer
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())
+    for k, (shape, dtype) in shapes.items():
+        assert list(sd[k].shape) == shape and str(sd[k].dtype) == dtype, k
+    path = tmp_path / "checkpoint.pth.tar"
+    torch.save({"epoch": 3, "state_dict": sd, "optimizer": {}, "scaler": {}}, path)
+    ck = torch.load(path, map_location="cpu")
+    from src.models.simclr import SimCLRSkinV32
+    fresh = SimCLRSkinV32("resnet50", None, 128, 0.1)
+    fresh.load_state_dict(ck["state_dict"], strict=True)
+    for (k, a), (_, b) in zip(fresh.state_dict().items(), sd.items()):
+        assert torch.equal(a, b), k
+    assert ck["epoch"] == 3
