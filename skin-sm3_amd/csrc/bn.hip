@@ -9,6 +9,7 @@
 // cross-rank reductions (tools/backbone_train.py:510) -- the reductions themselves are done by
 // the host between sm3_bn_stats_reduce and sm3_bn_finalize / sm3_bn_bwd_apply.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -101,7 +102,10 @@ __global__ void bn_eval_kernel(const float* gamma, const float* beta, const floa
     shift[c] = b - rm[c] * g * invstd;
 }
 
-template <typename T, bool OUT_F32>
+// The three row-walk kernels below keep U rows in flight per thread (all loads issued before the first use) and
+// mark their accesses non-temporal: every byte is touched once.  U=1 -> 5.05, U=8+nt -> 5.97 TB/s on a cold
+// 1.2 GB working set (scratch/stream_bench.hip).
+template <typename T, bool OUT_F32, int U, bool NT>
 __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, const T* __restrict__ res,
                                                      int relu, void* __restrict__ y, uint8_t* __restrict__ mask,
@@ -117,15 +121,15 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x, co
         sh[e] = shift[cv * E + e];
     }
     const int64_t rstep = (int64_t)gridDim.y * tby;
-    for (int64_t r = (int64_t)blockIdx.y * tby + ty; r < rows; r += rstep) {
+    auto finish = [&](int64_t r, const uint4& xu, const uint4& ru) {
         const int64_t off = r * C + (int64_t)cv * E;
         float v[E];
-        unpack16<T>(*reinterpret_cast<const uint4*>(x + off), v);
+        unpack16<T>(xu, v);
 #pragma unroll
         for (int e = 0; e < E; ++e) v[e] = v[e] * sc[e] + sh[e];
         if (res) {
             float q[E];
-            unpack16<T>(*reinterpret_cast<const uint4*>(res + off), q);
+            unpack16<T>(ru, q);
 #pragma unroll
             for (int e = 0; e < E; ++e) v[e] += q[e];
         }
@@ -145,13 +149,29 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x, co
             for (int e = 0; e < E; e += 4)
                 *reinterpret_cast<float4*>(yo + e) = make_float4(v[e], v[e + 1], v[e + 2], v[e + 3]);
         } else {
-            *reinterpret_cast<uint4*>(reinterpret_cast<T*>(y) + off) = pack16<T>(v);
+            stg16<NT>(reinterpret_cast<T*>(y) + off, pack16<T>(v));
         }
+    };
+    int64_t r = (int64_t)blockIdx.y * tby + ty;
+    for (; r + (U - 1) * rstep < rows; r += U * rstep) {
+        uint4 xu[U], ru[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t off = (r + u * rstep) * C + (int64_t)cv * E;
+            xu[u] = ldg16<NT>(x + off);
+            ru[u] = res ? ldg16<NT>(res + off) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) finish(r + u * rstep, xu[u], ru[u]);
+    }
+    for (; r < rows; r += rstep) {
+        const int64_t off = r * C + (int64_t)cv * E;
+        finish(r, ldg16<false>(x + off), res ? ldg16<false>(res + off) : make_uint4(0, 0, 0, 0));
     }
 }
 
 // phase 1 of backward: relu mask, optional dz write-back, partial sums of dz and dz*xhat
-template <typename T>
+template <typename T, int U, bool NT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                                                             const uint8_t* __restrict__ mask,
                                                             const T* __restrict__ x, const float* __restrict__ mean,
@@ -174,30 +194,49 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             is[e] = invstd[cv * E + e];
         }
         const int64_t rstep = (int64_t)gridDim.y * tby;
-        for (int64_t r = (int64_t)blockIdx.y * tby + ty; r < rows; r += rstep) {
+        auto finish = [&](int64_t r, const uint4& gu, const uint4& xu, const uint4& yu, unsigned m) {
             const int64_t off = r * C + (int64_t)cv * E;
             float g[E], xv[E];
-            unpack16<T>(*reinterpret_cast<const uint4*>(dy + off), g);
-            unpack16<T>(*reinterpret_cast<const uint4*>(x + off), xv);
+            unpack16<T>(gu, g);
+            unpack16<T>(xu, xv);
             if (mask) {
-                const unsigned m = mask[r * (C / E) + cv];
 #pragma unroll
                 for (int e = 0; e < E; ++e) g[e] = ((m >> e) & 1u) ? g[e] : 0.f;
-                if (dz) *reinterpret_cast<uint4*>(dz + off) = pack16<T>(g);
+                if (dz) stg16<NT>(dz + off, pack16<T>(g));
             } else if (y) {
                 float yv[E];
-                unpack16<T>(*reinterpret_cast<const uint4*>(y + off), yv);
+                unpack16<T>(yu, yv);
 #pragma unroll
                 for (int e = 0; e < E; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
-                if (dz) *reinterpret_cast<uint4*>(dz + off) = pack16<T>(g);
+                if (dz) stg16<NT>(dz + off, pack16<T>(g));
             } else if (dz && dz != dy) {
-                *reinterpret_cast<uint4*>(dz + off) = pack16<T>(g);
+                stg16<NT>(dz + off, pack16<T>(g));
             }
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 s1[e] += g[e];
                 s2[e] += g[e] * (xv[e] - mu[e]) * is[e];
             }
+        };
+        int64_t r = (int64_t)blockIdx.y * tby + ty;
+        for (; r + (U - 1) * rstep < rows; r += U * rstep) {
+            uint4 gu[U], xu[U], yu[U];
+            unsigned m[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t rr = r + u * rstep, off = rr * C + (int64_t)cv * E;
+                gu[u] = ldg16<NT>(dy + off);
+                xu[u] = ldg16<NT>(x + off);
+                m[u] = mask ? mask[rr * (C / E) + cv] : 0u;
+                yu[u] = (!mask && y) ? ldg16<NT>(y + off) : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) finish(r + u * rstep, gu[u], xu[u], yu[u], m[u]);
+        }
+        for (; r < rows; r += rstep) {
+            const int64_t off = r * C + (int64_t)cv * E;
+            finish(r, ldg16<false>(dy + off), ldg16<false>(x + off),
+                   (!mask && y) ? ldg16<false>(y + off) : make_uint4(0, 0, 0, 0), mask ? mask[r * (C / E) + cv] : 0u);
         }
     }
     // reduce over ty within the block
@@ -227,7 +266,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     }
 }
 
-template <typename T>
+template <typename T, int U, bool NT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ x,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
@@ -240,16 +279,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     const int tx = threadIdx.x % tbx, ty = threadIdx.x / tbx;
     const int cv = blockIdx.x * tbx + tx;
     if (cv * E >= C || ty >= tby) return;
-    float mu[E], is[E], k0[E], k1[E], k2[E];
+    // dx = g*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)) = k0*(dz - k1) - (x - mu)*q
+    float mu[E], k0[E], k1[E], q[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int c = cv * E + e;
         mu[e] = mean[c];
-        is[e] = invstd[c];
+        const float is = invstd[c];
         const float g = gamma ? gamma[c] : 1.f;
-        k0[e] = g * is[e];                                  // dx = k0 * (dz - k1 - xhat * k2)
+        k0[e] = g * is;
         k1[e] = (float)(gsums[c] * inv_count);              // (no fp64 divide per thread: 16 of them cost more
-        k2[e] = (float)(gsums[C + c] * inv_count);          //  than the rows a thread walks)
+        q[e] = k0[e] * is * (float)(gsums[C + c] * inv_count);  //  than the rows a thread walks)
     }
     if (blockIdx.y == 0 && ty == 0 && lsums) {  // parameter gradients from the LOCAL sums, once per channel
 #pragma unroll
@@ -261,19 +301,63 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         }
     }
     const int64_t rstep = (int64_t)gridDim.y * tby;
-    for (int64_t r = (int64_t)blockIdx.y * tby + ty; r < rows; r += rstep) {
-        const int64_t off = r * C + (int64_t)cv * E;
+    auto finish = [&](int64_t r, const uint4& gu, const uint4& xu) {
         float g[E], xv[E];
-        unpack16<T>(*reinterpret_cast<const uint4*>(dz + off), g);
-        unpack16<T>(*reinterpret_cast<const uint4*>(x + off), xv);
+        unpack16<T>(gu, g);
+        unpack16<T>(xu, xv);
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const float xh = (xv[e] - mu[e]) * is[e];
-            g[e] = k0[e] * (g[e] - k1[e] - xh * k2[e]);
+        for (int e = 0; e < E; ++e) g[e] = k0[e] * (g[e] - k1[e]) - (xv[e] - mu[e]) * q[e];
+        stg16<NT>(dx + r * C + (int64_t)cv * E, pack16<T>(g));
+    };
+    int64_t r = (int64_t)blockIdx.y * tby + ty;
+    for (; r + (U - 1) * rstep < rows; r += U * rstep) {
+        uint4 gu[U], xu[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t off = (r + u * rstep) * C + (int64_t)cv * E;
+            gu[u] = ldg16<NT>(dz + off);
+            xu[u] = ldg16<NT>(x + off);
         }
-        *reinterpret_cast<uint4*>(dx + off) = pack16<T>(g);
+#pragma unroll
+        for (int u = 0; u < U; ++u) finish(r + u * rstep, gu[u], xu[u]);
+    }
+    for (; r < rows; r += rstep) {
+        const int64_t off = r * C + (int64_t)cv * E;
+        finish(r, ldg16<false>(dz + off), ldg16<false>(x + off));
     }
 }
+
+// Row-walk tuning knobs (environment, read once): SM3_BN_UNROLL[_ACT|_RED|_APP] in {1,2,4,8}, SM3_BN_NT in {0,1}.
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+static int bn_unroll(int kind) {  // 0 apply-forward, 1 backward reduce, 2 backward apply
+    static const int u[3] = {env_int("SM3_BN_UNROLL_ACT", env_int("SM3_BN_UNROLL", 4)),
+                             env_int("SM3_BN_UNROLL_RED", env_int("SM3_BN_UNROLL", 4)),
+                             env_int("SM3_BN_UNROLL_APP", env_int("SM3_BN_UNROLL", 8))};
+    return u[kind];
+}
+static bool bn_nt() {
+    static const bool nt = env_int("SM3_BN_NT", 1) != 0;
+    return nt;
+}
+// expands CALL(U, NT) for the configured (unroll, non-temporal) pair
+#define SM3_BN_DISPATCH(KIND, CALL)                 \
+    do {                                            \
+        const int u_ = bn_unroll(KIND);             \
+        if (bn_nt()) {                              \
+            if (u_ >= 8) { CALL(8, true); }         \
+            else if (u_ >= 4) { CALL(4, true); }    \
+            else if (u_ >= 2) { CALL(2, true); }    \
+            else { CALL(1, true); }                 \
+        } else {                                    \
+            if (u_ >= 8) { CALL(8, false); }        \
+            else if (u_ >= 4) { CALL(4, false); }   \
+            else if (u_ >= 2) { CALL(2, false); }   \
+            else { CALL(1, false); }                \
+        }                                           \
+    } while (0)
 
 }  // namespace
 
@@ -328,17 +412,18 @@ extern "C" int sm3_bn_act(int dtype, const void* x, const float* scale, const fl
     const RowWalk w = make_walk(rows, C / E, 8192);
     dim3 grid(w.gx, w.gy), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == SM3_F32) {
-        // f32 storage: the two output forms coincide
-        hipLaunchKernelGGL((bn_act_kernel<float, false>), grid, block, 0, st, (const float*)x, scale, shift,
-                           (const float*)residual, relu, y, relu_mask, rows, C, w.tbx, w.tby);
-    } else if (out_f32) {
-        hipLaunchKernelGGL((bn_act_kernel<bf16_t, true>), grid, block, 0, st, (const bf16_t*)x, scale, shift,
-                           (const bf16_t*)residual, relu, y, relu_mask, rows, C, w.tbx, w.tby);
-    } else {
-        hipLaunchKernelGGL((bn_act_kernel<bf16_t, false>), grid, block, 0, st, (const bf16_t*)x, scale, shift,
-                           (const bf16_t*)residual, relu, y, relu_mask, rows, C, w.tbx, w.tby);
-    }
+#define SM3_ACT(U, NT)                                                                                            \
+    if (dtype == SM3_F32) /* f32 storage: the two output forms coincide */                                        \
+        hipLaunchKernelGGL((bn_act_kernel<float, false, U, NT>), grid, block, 0, st, (const float*)x, scale, shift, \
+                           (const float*)residual, relu, y, relu_mask, rows, C, w.tbx, w.tby);                    \
+    else if (out_f32)                                                                                             \
+        hipLaunchKernelGGL((bn_act_kernel<bf16_t, true, U, NT>), grid, block, 0, st, (const bf16_t*)x, scale,     \
+                           shift, (const bf16_t*)residual, relu, y, relu_mask, rows, C, w.tbx, w.tby);            \
+    else                                                                                                          \
+        hipLaunchKernelGGL((bn_act_kernel<bf16_t, false, U, NT>), grid, block, 0, st, (const bf16_t*)x, scale,    \
+                           shift, (const bf16_t*)residual, relu, y, relu_mask, rows, C, w.tbx, w.tby)
+    SM3_BN_DISPATCH(0, SM3_ACT);
+#undef SM3_ACT
     SM3_CHECK_LAUNCH();
     return 0;
 }
@@ -366,12 +451,17 @@ extern "C" int sm3_bn_bwd_reduce(int dtype, const void* dy, const void* y, const
     w.gy = bwd_gy(rows);
     dim3 grid(w.gx, w.gy), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == SM3_F32)
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, block, 0, st, (const float*)dy, (const float*)y,
-                           relu_mask, (const float*)x, mean, invstd, (float*)dz, rows, C, partials, w.tbx, w.tby);
-    else
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)y,
-                           relu_mask, (const bf16_t*)x, mean, invstd, (bf16_t*)dz, rows, C, partials, w.tbx, w.tby);
+#define SM3_RED(U, NT)                                                                                              \
+    if (dtype == SM3_F32)                                                                                           \
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, U, NT>), grid, block, 0, st, (const float*)dy,              \
+                           (const float*)y, relu_mask, (const float*)x, mean, invstd, (float*)dz, rows, C, partials, \
+                           w.tbx, w.tby);                                                                           \
+    else                                                                                                            \
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, U, NT>), grid, block, 0, st, (const bf16_t*)dy,            \
+                           (const bf16_t*)y, relu_mask, (const bf16_t*)x, mean, invstd, (bf16_t*)dz, rows, C,       \
+                           partials, w.tbx, w.tby)
+    SM3_BN_DISPATCH(1, SM3_RED);
+#undef SM3_RED
     SM3_CHECK_LAUNCH();
     return 0;
 }
@@ -387,14 +477,17 @@ extern "C" int sm3_bn_bwd_apply(int dtype, const void* dz, const void* x, const 
     const RowWalk w = make_walk(rows, C / E, 8192);
     dim3 grid(w.gx, w.gy), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == SM3_F32)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, block, 0, st, (const float*)dz, (const float*)x, mean,
-                           invstd, gamma, global_sums, 1.0 / count, local_sums, dgamma, dbeta, (float*)dx, rows, C,
-                           w.tbx, w.tby);
-    else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)dz, (const bf16_t*)x, mean,
-                           invstd, gamma, global_sums, 1.0 / count, local_sums, dgamma, dbeta, (bf16_t*)dx, rows, C,
-                           w.tbx, w.tby);
+#define SM3_APP(U, NT)                                                                                             \
+    if (dtype == SM3_F32)                                                                                          \
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<float, U, NT>), grid, block, 0, st, (const float*)dz,              \
+                           (const float*)x, mean, invstd, gamma, global_sums, 1.0 / count, local_sums, dgamma,     \
+                           dbeta, (float*)dx, rows, C, w.tbx, w.tby);                                              \
+    else                                                                                                           \
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, U, NT>), grid, block, 0, st, (const bf16_t*)dz,            \
+                           (const bf16_t*)x, mean, invstd, gamma, global_sums, 1.0 / count, local_sums, dgamma,    \
+                           dbeta, (bf16_t*)dx, rows, C, w.tbx, w.tby)
+    SM3_BN_DISPATCH(2, SM3_APP);
+#undef SM3_APP
     SM3_CHECK_LAUNCH();
     return 0;
 }

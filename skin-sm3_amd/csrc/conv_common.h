@@ -1,0 +1,95 @@
+// Pieces shared by the gather-GEMM convolution kernels (conv_igemm.hip: 128-row tiles, 4 waves;
+// conv_igemm_v2.hip: persistent 256x128 tiles, 8 waves, 3-stage LDS-DMA ring).
+#pragma once
+#include "common.h"
+
+namespace sm3conv {
+
+struct ConvParams {
+    const char* x;
+    const char* w;
+    char* y;
+    const char* addend;
+    float* partials;
+    int M, Hi, Wi, Ci, Co;
+    int sy, sx, ntaps;
+    int dy[SM3_MAX_TAPS], dx[SM3_MAX_TAPS], wtap[SM3_MAX_TAPS];
+    int w_row_stride;
+    int Wout, HWout, osy, osx, ooy, oox;
+    int HoWo, Wo;
+    FastDiv div_HoWo, div_Wo;
+    int kchunks;  // K-steps per tap = Ci*sizeof(T)/128
+    int tilesM, tilesN;
+    FastDiv div_tilesN;  // conv_igemm_v2 only
+    uint32_t x_bytes, w_bytes;  // buffer-descriptor extents (< 3 GB)
+    // optional fusion of the NEXT BatchNorm-backward's first phase into this (data-gradient) epilogue
+    const uint8_t* fz_mask;     // relu bits of that BN's output (1 byte per 16-byte vector), or null
+    const char* fz_x;           // that BN's input (its conv's output), same indexing as y; null = fusion off
+    const float* fz_mean;
+    const float* fz_invstd;
+    float* fz_partials;         // [fz_row_off + tilesM][2][Co]
+    int fz_row_off;
+    // optional inference epilogue: y = relu?(acc * ep_scale[co] + ep_shift[co] (+ addend))  (eval-mode BatchNorm)
+    const float* ep_scale;
+    const float* ep_shift;
+    int ep_relu;
+};
+
+template <typename T>
+__device__ __forceinline__ void mma_frag(const uint4& a, const uint4& b, f32x16& c);
+
+template <>
+__device__ __forceinline__ void mma_frag<bf16_t>(const uint4& a, const uint4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_frag<float>(const uint4& a, const uint4& b, f32x16& c) {
+    // lane (r, h) holds k = 8*kk + 4*h + {0,1,2,3}: the j-th MFMA uses element j of both fragments,
+    // so A and B agree on k and the four instructions together cover 8 consecutive k.
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+}
+
+// byte offset of 16-byte chunk `c` of row `r` inside a [rows][128 B] LDS tile.  Two rows share a
+// 256-byte bank row, so the swizzle key is the row pair: the 16 lanes of every ds_read_b128 group
+// then hit 16 distinct 16-byte slots.
+__device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + (((c ^ (r >> 1)) & 7) << 4); }
+
+constexpr uint32_t kOOB = 0xC0000000u;  // voffset beyond any tensor (< 3 GB, checked on the host): reads zeros
+
+// LDS-DMA: buffer_load_dwordx4 ... lds.  One wave-instruction moves 8 tile rows x 128 B = 1 KiB straight from
+// global memory into LDS (destination = wave-uniform base + lane*16, source = per-lane offset), with no VGPR
+// staging and no ds_write (whose VGPR->LDS transfer, ~13 cycles per KiB, made the register-staged version of this
+// kernel LDS-bound: 830 write + 512 read LDS cycles against 1024 MFMA cycles per K-step pair).  The XOR swizzle
+// is applied on the SOURCE side: lane (row, pos) fetches chunk pos ^ key(row), so it lands where lds_off(row,
+// chunk) expects it.  Rows outside the image (padding), beyond M or beyond Cout use an out-of-range offset: the
+// buffer range check makes the DMA write zeros (verified on gfx950, scratch/glds_test.hip) -- no branches.
+//
+// The DMA is issued from inline asm on purpose: through the builtin, hipcc orders every later ds_read behind the
+// DMA with s_waitcnt vmcnt(0) (it cannot see that the DMA fills the OTHER stage), which serialises load and
+// compute.  In asm the compiler does not track it; we drain it ourselves (vmcnt(0)) right before the barrier that
+// publishes the stage.  M0 (LDS destination base) is saved/restored inside the statement (hipcc reserves it).
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t lds_wave_base, uint32_t voff, uint32_t soff) {
+    uint32_t keep;
+    soff = __builtin_amdgcn_readfirstlane(soff);                    // wave-uniform by construction: keep them in
+    lds_wave_base = __builtin_amdgcn_readfirstlane(lds_wave_base);  // SGPRs whatever the divergence analysis thinks
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_wave_base), "v"(voff), "s"(rsrc), "s"(soff)
+        : "memory");
+}
+__device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+
+// conv_igemm_v2.hip
+bool conv_v2_eligible(const sm3_conv_desc* d);
+int launch_conv_v2(const ConvParams& p, hipStream_t st);
+
+}  // namespace sm3conv

@@ -15,94 +15,17 @@
 // data-gradients.
 #include <stdlib.h>
 
-#include "common.h"
+#include "conv_common.h"
+
+using namespace sm3conv;
 
 namespace {
-
-struct ConvParams {
-    const char* x;
-    const char* w;
-    char* y;
-    const char* addend;
-    float* partials;
-    int M, Hi, Wi, Ci, Co;
-    int sy, sx, ntaps;
-    int dy[SM3_MAX_TAPS], dx[SM3_MAX_TAPS], wtap[SM3_MAX_TAPS];
-    int w_row_stride;
-    int Wout, HWout, osy, osx, ooy, oox;
-    int HoWo, Wo;
-    FastDiv div_HoWo, div_Wo;
-    int kchunks;  // K-steps per tap = Ci*sizeof(T)/128
-    int tilesM, tilesN;
-    uint32_t x_bytes, w_bytes;  // buffer-descriptor extents (< 3 GB)
-    // optional fusion of the NEXT BatchNorm-backward's first phase into this (data-gradient) epilogue
-    const uint8_t* fz_mask;     // relu bits of that BN's output (1 byte per 16-byte vector), or null
-    const char* fz_x;           // that BN's input (its conv's output), same indexing as y; null = fusion off
-    const float* fz_mean;
-    const float* fz_invstd;
-    float* fz_partials;         // [fz_row_off + tilesM][2][Co]
-    int fz_row_off;
-    // optional inference epilogue: y = relu?(acc * ep_scale[co] + ep_shift[co] (+ addend))  (eval-mode BatchNorm)
-    const float* ep_scale;
-    const float* ep_shift;
-    int ep_relu;
-};
-
-template <typename T>
-__device__ __forceinline__ void mma_frag(const uint4& a, const uint4& b, f32x16& c);
-
-template <>
-__device__ __forceinline__ void mma_frag<bf16_t>(const uint4& a, const uint4& b, f32x16& c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-template <>
-__device__ __forceinline__ void mma_frag<float>(const uint4& a, const uint4& b, f32x16& c) {
-    // lane (r, h) holds k = 8*kk + 4*h + {0,1,2,3}: the j-th MFMA uses element j of both fragments,
-    // so A and B agree on k and the four instructions together cover 8 consecutive k.
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
-}
-
-// byte offset of 16-byte chunk `c` of row `r` inside a [rows][128 B] LDS tile.  Two rows share a
-// 256-byte bank row, so the swizzle key is the row pair: the 16 lanes of every ds_read_b128 group
-// then hit 16 distinct 16-byte slots.
-__device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + (((c ^ (r >> 1)) & 7) << 4); }
-
-constexpr uint32_t kOOB = 0xC0000000u;  // voffset beyond any tensor (< 3 GB, checked on the host): reads zeros
-
-// LDS-DMA: buffer_load_dwordx4 ... lds.  One wave-instruction moves 8 tile rows x 128 B = 1 KiB straight from
-// global memory into LDS (destination = wave-uniform base + lane*16, source = per-lane offset), with no VGPR
-// staging and no ds_write (whose VGPR->LDS transfer, ~13 cycles per KiB, made the register-staged version of this
-// kernel LDS-bound: 830 write + 512 read LDS cycles against 1024 MFMA cycles per K-step pair).  The XOR swizzle
-// is applied on the SOURCE side: lane (row, pos) fetches chunk pos ^ key(row), so it lands where lds_off(row,
-// chunk) expects it.  Rows outside the image (padding), beyond M or beyond Cout use an out-of-range offset: the
-// buffer range check makes the DMA write zeros (verified on gfx950, scratch/glds_test.hip) -- no branches.
-//
-// The DMA is issued from inline asm on purpose: through the builtin, hipcc orders every later ds_read behind the
-// DMA with s_waitcnt vmcnt(0) (it cannot see that the DMA fills the OTHER stage), which serialises load and
-// compute.  In asm the compiler does not track it; we drain it ourselves (vmcnt(0)) right before the barrier that
-// publishes the stage.  M0 (LDS destination base) is saved/restored inside the statement (hipcc reserves it).
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t lds_wave_base, uint32_t voff, uint32_t soff) {
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %1\n\t"
-        "s_nop 0\n\t"
-        "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "s"(lds_wave_base), "v"(voff), "s"(rsrc), "s"(soff)
-        : "memory");
-}
-__device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // STAGES = 2: K-loop with the DMA of step s+1 in flight while step s is computed (LDS 64 KB + 2 KB, 2 workgroups
 // per CU).  STAGES = 1 (host picks it for <= 8 K-steps, the memory-bound 1x1 layers; measured: scratch/bench_kernels.py): one 32 KB stage, no
 // intra-workgroup overlap, but 34 KB of LDS lets 4 workgroups share a CU and overlap each other's load latency,
 // K-step and store tail -- which is what those short workgroups need.
-template <typename T, int BM, int BN, int WM, int WN, int STAGES>
+template <typename T, int BM, int BN, int WM, int WN, int STAGES, bool LEAN>
 __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int RPP = NT / 8;  // rows covered per loader pass
@@ -110,7 +33,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
     constexpr int SZ = sizeof(T);
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    constexpr int C_BYTES = WTM * BN * 4;  // the epilogue stages one wave-row (WTM rows) of the tile at a time
+    // general epilogue: one wave-row (WTM rows) of the tile at a time in f32; lean epilogue: the whole tile in bf16
+    constexpr int LEAN_PITCH = BN * 2 + 16;  // bytes; +16 puts rows r and r+4 (the lane halves of a C register) on different banks
+    constexpr int C_BYTES = LEAN ? BM * LEAN_PITCH : WTM * BN * 4;
     constexpr int MAIN_BYTES = (STAGES * STAGE > C_BYTES) ? STAGES * STAGE : C_BYTES;
     static_assert(AI >= 1 && BI >= 1 && TM >= 1 && TN >= 1, "tile too small");
 
@@ -254,6 +179,69 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
                 __syncthreads();
             }
         }
+    }
+
+    // ---- lean epilogue: plain bf16 forward convolution (dense output, no addend / fusion) --------------------
+    // What the train-mode forward launches need, at a quarter of the general epilogue's VALU work (which, with 3-4
+    // workgroups per CU, was as long as the HBM time of a K<=256 tile): accumulators -> bf16 pairs in registers
+    // (v_cvt_pk_bf16_f32); BatchNorm sums of the ROUNDED values with two v_dot2c_f32_bf16 per pair; the whole
+    // tile staged once in LDS as bf16; read back as 16-byte vectors and stored with no arithmetic in between.
+    if constexpr (LEAN) {
+        static_assert(sizeof(T) == 2, "lean epilogue is bf16 only");
+        constexpr int CPR = BN / 8, RSTEP = NT / CPR, NPASS = BM / RSTEP;
+        char* sC = smem;
+        float* sStat = reinterpret_cast<float*>(smem + MAIN_BYTES);  // [WM][BN][2]
+        const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s1 = 0.f, s2 = 0.f;
+            char* colp = sC + (wn * WTN + j * 32 + frow) * 2 + (wm * WTM + 4 * fh) * LEAN_PITCH;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {  // registers 2q, 2q+1 = rows R, R+1 of this lane's column
+                    const uint32_t pk = pack_bf16x2(acc[i][j][2 * q], acc[i][j][2 * q + 1]);
+                    const bf16x2_t pv = __builtin_bit_cast(bf16x2_t, pk);
+                    s1 = __builtin_amdgcn_fdot2_f32_bf16(pv, ones, s1, false);
+                    s2 = __builtin_amdgcn_fdot2_f32_bf16(pv, pv, s2, false);
+                    const int R = i * 32 + (q & 1) * 2 + 8 * (q >> 1);
+                    *reinterpret_cast<uint16_t*>(colp + R * LEAN_PITCH) = (uint16_t)pk;
+                    *reinterpret_cast<uint16_t*>(colp + (R + 1) * LEAN_PITCH) = (uint16_t)(pk >> 16);
+                }
+            if (p.partials) {
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (lane < 32) {
+                    const int col = wn * WTN + j * 32 + lane;
+                    sStat[(wm * BN + col) * 2 + 0] = s1;
+                    sStat[(wm * BN + col) * 2 + 1] = s2;
+                }
+            }
+        }
+        __syncthreads();
+        if (p.partials && tid < BN && n0 + tid < p.Co) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                s1 += sStat[(w * BN + tid) * 2 + 0];
+                s2 += sStat[(w * BN + tid) * 2 + 1];
+            }
+            p.partials[((long)bm * 2 + 0) * p.Co + n0 + tid] = s1;
+            p.partials[((long)bm * 2 + 1) * p.Co + n0 + tid] = s2;
+        }
+        const int cc = tid % CPR, r0 = tid / CPR;
+        const int ncol = n0 + cc * 8;
+        if (ncol < p.Co) {
+            char* yp = p.y + ((long)(m0 + r0) * p.Co + ncol) * 2;
+            const long ystep = (long)RSTEP * p.Co * 2;
+            const char* sp = sC + r0 * LEAN_PITCH + cc * 16;
+#pragma unroll
+            for (int k = 0; k < NPASS; ++k) {
+                if (m0 + r0 + k * RSTEP < p.M)
+                    *reinterpret_cast<uint4*>(yp + k * ystep) = *reinterpret_cast<const uint4*>(sp + k * RSTEP * LEAN_PITCH);
+            }
+        }
+        return;
     }
 
     // ---- epilogue -----------------------------------------------------------------------
@@ -428,17 +416,17 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int STAGES>
+template <typename T, int BM, int BN, int WM, int WN, int STAGES, bool LEAN>
 int launch_conv_st(const ConvParams& p0, hipStream_t st) {
     ConvParams p = p0;
     constexpr int STAGE = (BM + BN) * 128;
-    constexpr int C_BYTES = (BM / WM) * BN * 4;
+    constexpr int C_BYTES = LEAN ? BM * (BN * 2 + 16) : (BM / WM) * BN * 4;
     constexpr int MAIN = (STAGES * STAGE > C_BYTES) ? STAGES * STAGE : C_BYTES;
     constexpr int LDS = MAIN + WM * BN * 2 * 4;
-    static_assert(MAIN >= 256 * 2 * 8 * 4, "reduction scratch of the fused BN-backward epilogue must fit");
+    static_assert(LEAN || MAIN >= 256 * 2 * 8 * 4, "reduction scratch of the fused BN-backward epilogue must fit");
     p.tilesM = (p.M + BM - 1) / BM;
     p.tilesN = (p.Co + BN - 1) / BN;
-    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, STAGES>;
+    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, STAGES, LEAN>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -457,8 +445,15 @@ template <typename T, int BM, int BN, int WM, int WN>
 int launch_conv(const ConvParams& p, hipStream_t st) {
     const char* v = getenv("SM3_CONV_SINGLE_STAGE_MAX");
     const int single_max = v ? atoi(v) : 8;
-    if (p.ntaps * p.kchunks <= single_max) return launch_conv_st<T, BM, BN, WM, WN, 1>(p, st);
-    return launch_conv_st<T, BM, BN, WM, WN, 2>(p, st);
+    const bool single = p.ntaps * p.kchunks <= single_max;
+    if constexpr (sizeof(T) == 2) {
+        const char* lv = getenv("SM3_CONV_LEAN");
+        const bool dense = p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.HWout == p.HoWo;
+        if (!(lv && atoi(lv) == 0) && dense && !p.addend && !p.fz_x && !p.ep_scale)
+            return single ? launch_conv_st<T, BM, BN, WM, WN, 1, true>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, true>(p, st);
+    }
+    if (single) return launch_conv_st<T, BM, BN, WM, WN, 1, false>(p, st);
+    return launch_conv_st<T, BM, BN, WM, WN, 2, false>(p, st);
 }
 
 constexpr int kBM = 128;
@@ -526,6 +521,7 @@ static int conv_gather_gemm_impl(const sm3_conv_desc* d, const void* x, const vo
     p.ep_shift = ep_shift;
     p.ep_relu = ep_relu;
     hipStream_t st = (hipStream_t)stream;
+    if (conv_v2_eligible(d)) return launch_conv_v2(p, st);
     const bool narrow = d->Co <= 64;
     if (d->dtype == SM3_BF16)
         return narrow ? launch_conv<bf16_t, kBM, 64, 2, 2>(p, st) : launch_conv<bf16_t, kBM, 128, 2, 2>(p, st);
