@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsm3hip.so")
+LIB_PATH = os.environ.get("SM3_LIBRARY") or os.path.join(_HERE, "libsm3hip.so")  # override: A/B of two builds
 
 SM3_F32, SM3_BF16 = 0, 1
 MAX_TAPS = 9
