@@ -48,33 +48,62 @@ __global__ __launch_bounds__(256) void bn_stats_reduce_a(const float* __restrict
     const int col = blockIdx.x * 64 + tx;  // in [0, 2C): stat-major within a partial row
     double a = 0.0;
     if (col < 2 * C) {
-        for (int r = blockIdx.y * 4 + ty; r < rows; r += gridDim.y * 4) a += (double)partials[(long)r * 2 * C + col];
+        // four independent chains: the loads of a chain of dependent fp64 adds would otherwise go out one at a time
+        double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        const int step = gridDim.y * 4;
+        int r = blockIdx.y * 4 + ty;
+        for (; r + 3 * step < rows; r += 4 * step) {
+            a += (double)partials[(long)r * 2 * C + col];
+            a1 += (double)partials[(long)(r + step) * 2 * C + col];
+            a2 += (double)partials[(long)(r + 2 * step) * 2 * C + col];
+            a3 += (double)partials[(long)(r + 3 * step) * 2 * C + col];
+        }
+        for (; r < rows; r += step) a += (double)partials[(long)r * 2 * C + col];
+        a = (a + a1) + (a2 + a3);
     }
     red[ty][tx] = a;
     __syncthreads();
     if (ty == 0 && col < 2 * C) ws[(long)blockIdx.y * 2 * C + col] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
 
+// Sum over the G workspace rows of one column by the 4 lanes of a quad: lane q takes rows q, q+4, ... in four
+// independent chains (G = 64: four loads in flight, four rounds), then the quad folds.  Fixed association, so every
+// caller gets the same bits; every lane of the quad returns the total.
+__device__ __forceinline__ double quad_sum_groups(const double* __restrict__ ws, long stride, long col, int G, int q) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int g = q;
+    for (; g + 12 < G; g += 16) {
+        a0 += ws[(long)g * stride + col];
+        a1 += ws[(long)(g + 4) * stride + col];
+        a2 += ws[(long)(g + 8) * stride + col];
+        a3 += ws[(long)(g + 12) * stride + col];
+    }
+    for (; g < G; g += 4) a0 += ws[(long)g * stride + col];
+    double a = (a0 + a1) + (a2 + a3);
+    a += __shfl_xor(a, 1, 64);
+    a += __shfl_xor(a, 2, 64);
+    return a;
+}
+
 __global__ void bn_stats_reduce_b(const double* __restrict__ ws, int G, int C, double* __restrict__ sums) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= 2 * C) return;
-    double a = 0.0;
-    for (int g = 0; g < G; ++g) a += ws[(long)g * 2 * C + col];
-    sums[col] = a;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, q = t & 3;
+    const int col = t >> 2;
+    const double a = quad_sum_groups(ws, 2L * C, col < 2 * C ? col : 0, G, q);
+    if (col < 2 * C && q == 0) sums[col] = a;
 }
 
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, int groups, double count, int C, const float* gamma,
                                    const float* beta, float eps, float momentum, float* running_mean,
                                    float* running_var, int64_t* nbt, float* scale, float* shift, float* save_mean,
                                    float* save_invstd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && nbt) nbt[0] += 1;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int g = 0; g < groups; ++g) {  // groups > 1: stage B of the statistics reduction folded in here
-        s1 += sums[(long)g * 2 * C + c];
-        s2 += sums[(long)g * 2 * C + C + c];
-    }
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, q = t & 3;
+    const int c = t >> 2;
+    if (t == 0 && nbt) nbt[0] += 1;
+    // groups > 1: stage B of the statistics reduction folded in here (same association as bn_stats_reduce_b)
+    const int cc = c < C ? c : 0;
+    const double s1 = quad_sum_groups(sums, 2L * C, cc, groups, q);
+    const double s2 = quad_sum_groups(sums, 2L * C, (long)C + cc, groups, q);
+    if (c >= C || q != 0) return;
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0) var = 0;
@@ -375,7 +404,7 @@ extern "C" int sm3_bn_stats_reduce(const float* partials, int rows, int C, doubl
     hipLaunchKernelGGL(bn_stats_reduce_a, dim3((2 * C + 63) / 64, G), dim3(256), 0, st, partials, rows, C, workspace);
     SM3_CHECK_LAUNCH();
     if (sums) {  // sums == NULL: the caller hands workspace + groups to sm3_bn_finalize instead (one launch fewer)
-        hipLaunchKernelGGL(bn_stats_reduce_b, dim3((2 * C + 255) / 256), dim3(256), 0, st, workspace, G, C, sums);
+        hipLaunchKernelGGL(bn_stats_reduce_b, dim3((8 * C + 255) / 256), dim3(256), 0, st, workspace, G, C, sums);
         SM3_CHECK_LAUNCH();
     }
     return 0;
@@ -386,7 +415,7 @@ extern "C" int sm3_bn_finalize(const double* sums, int groups, double count, int
                                int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean,
                                float* save_invstd, void* stream) {
     if (!sums || !scale || !shift || C <= 0 || count <= 0 || groups < 1) return SM3_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, groups, count, C,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((4 * C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, groups, count, C,
                        gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift,
                        save_mean, save_invstd);
     SM3_CHECK_LAUNCH();

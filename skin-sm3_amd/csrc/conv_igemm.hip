@@ -238,7 +238,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
 #pragma unroll
             for (int k = 0; k < NPASS; ++k) {
                 if (m0 + r0 + k * RSTEP < p.M)
-                    *reinterpret_cast<uint4*>(yp + k * ystep) = *reinterpret_cast<const uint4*>(sp + k * RSTEP * LEAN_PITCH);
+                    stg16<true>(yp + k * ystep, *reinterpret_cast<const uint4*>(sp + k * RSTEP * LEAN_PITCH));
             }
         }
         return;
@@ -316,9 +316,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
                     opix = (long)nn * p.HWout + (long)(oy * p.osy + p.ooy) * p.Wout + (ox * p.osx + p.oox);
                 }
                 e_off[k] = opix * p.Co + ncol;
-                if (p.addend) pre_add[k] = *reinterpret_cast<const uint4*>(p.addend + e_off[k] * SZ);
+                if (p.addend) pre_add[k] = ldg16<true>(p.addend + e_off[k] * SZ);
                 if (fz) {
-                    pre_x[k] = *reinterpret_cast<const uint4*>(p.fz_x + e_off[k] * SZ);
+                    pre_x[k] = ldg16<true>(p.fz_x + e_off[k] * SZ);
                     if (p.fz_mask) pre_mk[k] = p.fz_mask[e_off[k] / EPC];
                 }
             }
@@ -392,9 +392,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
                     f_s1[e] += dzr[e];
                     f_s2[e] += dzr[e] * (xv[e] - f_mu[e]) * f_is[e];
                 }
-                *reinterpret_cast<uint4*>(p.y + boff) = packed;
+                stg16<true>(p.y + boff, packed);
             } else {
-                *reinterpret_cast<uint4*>(p.y + boff) = pack16<T>(v);
+                stg16<true>(p.y + boff, pack16<T>(v));
             }
         }
     }
