@@ -29,8 +29,11 @@ static RowWalk make_walk(int64_t rows, int cvecs, int max_gy) {
     if (w.tby < 1) w.tby = 1;
     w.gx = (cvecs + w.tbx - 1) / w.tbx;
     int64_t gy = (rows + (int64_t)w.tby * 8 - 1) / ((int64_t)w.tby * 8);  // >= 8 rows per thread
-    // at most 2048 blocks (8 per CU, all resident at once): a grid of 1.5 x that runs a half-empty second round
-    const int64_t cap = 2048 / w.gx > 0 ? 2048 / w.gx : 1;
+    // At most 768 blocks = 3 per CU (env SM3_BN_GRID_CAP).  With 4-8 rows in flight per thread that already
+    // saturates HBM (scratch/stream_bench.hip: 1024 >= 2048 blocks), and it leaves 20 of a CU's 32 wave slots to
+    // the other execution lane's convolution: 2048 -> 768 is worth 1.2 % of the two-lane step (87.4 -> 86.4 ms).
+    static const int grid_cap = getenv("SM3_BN_GRID_CAP") ? atoi(getenv("SM3_BN_GRID_CAP")) : 768;
+    const int64_t cap = grid_cap / w.gx > 0 ? grid_cap / w.gx : 1;
     if (gy > cap) gy = cap;
     if (gy > max_gy) gy = max_gy;
     if (gy < 1) gy = 1;
