@@ -28,6 +28,7 @@ for p in (ROOT, os.path.join(ROOT, "skin-sm3_amd")):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+HBM_PEAK_BYTES = 8.0e12  # MI355X_MICROARCH.md: HBM3E spec peak
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense, MI355X_MICROARCH.md "Chip-level parameters"
 FLOP_PER_PAIR_224 = 98.5e9
 
@@ -245,8 +246,22 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "r01b_pmc_traffic_conv_igemm_b256_bf16.json")
     if args.dtype == "bf16" and B == 256 and S == 224 and os.path.exists(tpath):
         traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
+    # The kernel's 432 launches per step straddle the ridge (peak FLOP/s / 8 TB/s = 312 FLOP/B at bf16): split them
+    # by algorithmic intensity and price each side against its own roof (extra keys; `achieved`/`frac` above them
+    # stay the all-launch MFMA figures the contract asks for).
+    ridge = peak * 1e12 / HBM_PEAK_BYTES
+    reg = {"mfma": [0.0, 0.0, 0.0, 0], "hbm": [0.0, 0.0, 0.0, 0]}
+    for tag, fl, nb, ev0, ev1 in iso.records:
+        r = reg["mfma" if fl / max(nb, 1.0) >= ridge else "hbm"]
+        r[0] += fl; r[1] += nb; r[2] += ev0.elapsed_time(ev1) * 1e-3; r[3] += 1
+    by_regime = {
+        "mfma_bound_launches": {"launches": reg["mfma"][3], "achieved_TFLOPs": round(reg["mfma"][0] / max(reg["mfma"][2], 1e-9) / 1e12, 1),
+                                "frac_of_mfma_peak": round(reg["mfma"][0] / max(reg["mfma"][2], 1e-9) / (peak * 1e12), 4)},
+        "hbm_bound_launches": {"launches": reg["hbm"][3], "achieved_GBs": round(reg["hbm"][1] / max(reg["hbm"][2], 1e-9) / 1e9, 0),
+                               "frac_of_hbm_peak": round(reg["hbm"][1] / max(reg["hbm"][2], 1e-9) / HBM_PEAK_BYTES, 4)},
+        "ridge_flop_per_byte": round(ridge, 1)}
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": traffic,
+                "frac": round(achieved / peak, 4), "traffic": traffic, "by_regime": by_regime,
                 "kernel": f"conv_igemm_kernel<{'bf16_t' if args.dtype == 'bf16' else 'float'},128,128,2,2,*>",
                 "algorithmic_bytes_per_launch": round(dom["bytes"] / max(dom["launches"], 1)),
                 "launches_per_step": dom["launches"],

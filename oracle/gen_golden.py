@@ -173,15 +173,46 @@ def run_baseline_case(batch, size, seed, dtype, tag):
         f.write("\n".join(model.state_dict().keys()) + "\n")
 
 
+def run_inference_case(batch, size, seed, dtype, tag):
+    """The multi-label model of the reference's inference.py (eval mode, random but procedural weights)."""
+    import importlib
+    ref_inf = importlib.import_module("inference")  # /root/reference/inference.py (imports its top-level resnet.py)
+    assert ref_inf.__file__.startswith("/root/reference"), ref_inf.__file__
+    torch.manual_seed(0)
+    extractor = ref_inf.Extractor("resnet50")
+    model = ref_inf.Model(extractor, ref_inf.MultiLabelProjector(4096, 512, 8), 512, False, 1, 128, 0.1)
+    state = procedural.make_state_dict(procedural.inference_model_spec(), seed=seed)
+    ref_sd = model.state_dict()
+    assert list(state.keys()) == list(ref_sd.keys()), "inference Model state_dict key order differs"
+    assert all(tuple(ref_sd[k].shape) == state[k].shape for k in state), "inference Model shapes differ"
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    model = model.to(dtype).eval()
+    derm_np, clinic_np = procedural.make_pair_batch(batch, size, seed)
+    with torch.no_grad():
+        preds = model(torch.from_numpy(derm_np[0]).to(dtype), torch.from_numpy(clinic_np[0]).to(dtype))
+    out = {"meta": np.array([batch, size, seed], dtype=np.int64)}
+    for i, o in enumerate(preds):
+        out[f"pred_{i}"] = o.double().numpy()
+    path = os.path.join(OUT, f"inference_{tag}.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path} ({os.path.getsize(path)/1024:.0f} KiB)")
+    with open(os.path.join(OUT, "inference_state_dict_keys.txt"), "w") as f:
+        f.write("\n".join(ref_sd.keys()) + "\n")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     cls = _import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "inference":  # regenerate only the inference-model fixture
+        run_inference_case(batch=5, size=64, seed=5, dtype=torch.float64, tag="b5_s64_f64")
+        return
     names = run_case(cls, batch=4, size=64, seed=1, dtype=torch.float32, style=0, lr=1e-3, tag="b4_s64_f32")
     run_case(cls, batch=4, size=64, seed=1, dtype=torch.float64, style=0, lr=1e-3, tag="b4_s64_f64")
     run_case(cls, batch=3, size=96, seed=2, dtype=torch.float64, style=2, lr=1e-3, tag="b3_s96_style2_f64")
     run_case(cls, batch=8, size=64, seed=3, dtype=torch.float64, style=1, lr=1e-3, tag="b8_s64_style1_f64")
     run_baseline_case(batch=6, size=64, seed=4, dtype=torch.float64, tag="b6_s64_f64")
+    run_inference_case(batch=5, size=64, seed=5, dtype=torch.float64, tag="b5_s64_f64")
     with open(os.path.join(OUT, "param_names.txt"), "w") as f:
         f.write("\n".join(names) + "\n")
     # the 700 state_dict keys = checkpoint wire format (tools/backbone_train.py:578-587)

@@ -72,6 +72,26 @@ def baseline_spec():
     return spec
 
 
+def inference_model_spec(proj_dim=512, sa_dim_ff=128):
+    """state_dict layout of the multi-label model of inference.py (Extractor + MultiLabelProjector + one
+    TransformerEncoderLayer + 8 prototype heads; reference inference.py:16-96)."""
+    spec = []
+    for bb in ("extractor.derm_backbone.", "extractor.clinic_backbone."):
+        spec += resnet50_spec(bb)
+    for i in range(8):
+        spec += [(f"projectors.projectors.{i}.0.weight", (proj_dim, 4096)), (f"projectors.projectors.{i}.0.bias", (proj_dim,))]
+    d = proj_dim
+    spec += [("mlc_sa.self_attn.in_proj_weight", (3 * d, d)), ("mlc_sa.self_attn.in_proj_bias", (3 * d,)),
+             ("mlc_sa.self_attn.out_proj.weight", (d, d)), ("mlc_sa.self_attn.out_proj.bias", (d,)),
+             ("mlc_sa.linear1.weight", (sa_dim_ff, d)), ("mlc_sa.linear1.bias", (sa_dim_ff,)),
+             ("mlc_sa.linear2.weight", (d, sa_dim_ff)), ("mlc_sa.linear2.bias", (d,)),
+             ("mlc_sa.norm1.weight", (d,)), ("mlc_sa.norm1.bias", (d,)),
+             ("mlc_sa.norm2.weight", (d,)), ("mlc_sa.norm2.bias", (d,))]
+    for i, n in enumerate((5, 3, 2, 3, 3, 3, 3, 2)):
+        spec += [(f"prototypes.{i}.weight", (n, d)), (f"prototypes.{i}.bias", (n,))]
+    return spec
+
+
 def _rng(key, seed):
     return np.random.RandomState((zlib.crc32(key.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
 
@@ -87,7 +107,7 @@ def fill_tensor(key, shape, seed=0):
         return r.uniform(0.5, 1.5, size=shape).astype(np.float32)
     if len(shape) == 1 and key.endswith(".weight"):  # BN gamma: non-trivial on purpose
         return r.uniform(0.5, 1.5, size=shape).astype(np.float32)
-    if len(shape) == 1 and key.endswith(".bias"):  # BN beta
+    if len(shape) == 1 and key.endswith("bias"):  # BN beta, Linear / LayerNorm / attention biases
         return (0.1 * r.standard_normal(shape)).astype(np.float32)
     if len(shape) == 4:  # conv: Kaiming normal, fan_out, relu  (resnet.py:227-229)
         fan_out = shape[0] * shape[2] * shape[3]

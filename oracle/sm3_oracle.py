@@ -247,6 +247,40 @@ def baseline_forward(P, B, derm, clinic, training=False):
     return [F.linear(feats, P[f"classifier.{i}.weight"], P[f"classifier.{i}.bias"]) for i in range(8)]
 
 
+def transformer_encoder_layer(x, P, prefix, nhead=1, eps=1e-5):
+    """nn.TransformerEncoderLayer in eval mode as inference.py:58-60 builds it (post-norm, ReLU, dropout inactive,
+    batch_first=False): x [S, B, D] -> [S, B, D].  Attention over the S = 8 label tokens of every sample."""
+    S, Bn, D = x.shape
+    hd = D // nhead
+    qkv = F.linear(x, P[prefix + "self_attn.in_proj_weight"], P[prefix + "self_attn.in_proj_bias"])  # [S,B,3D]
+    q, k, v = qkv.split(D, dim=-1)
+
+    def heads(t):  # [S,B,D] -> [B,nhead,S,hd]
+        return t.reshape(S, Bn, nhead, hd).permute(1, 2, 0, 3)
+
+    att = torch.softmax(heads(q) @ heads(k).transpose(-1, -2) / math.sqrt(hd), dim=-1) @ heads(v)  # [B,nhead,S,hd]
+    att = att.permute(2, 0, 1, 3).reshape(S, Bn, D)
+    att = F.linear(att, P[prefix + "self_attn.out_proj.weight"], P[prefix + "self_attn.out_proj.bias"])
+    x = F.layer_norm(x + att, (D,), P[prefix + "norm1.weight"], P[prefix + "norm1.bias"], eps)
+    ff = F.linear(F.relu(F.linear(x, P[prefix + "linear1.weight"], P[prefix + "linear1.bias"])),
+                  P[prefix + "linear2.weight"], P[prefix + "linear2.bias"])
+    return F.layer_norm(x + ff, (D,), P[prefix + "norm2.weight"], P[prefix + "norm2.bias"], eps)
+
+
+def inference_forward(P, B, derm, clinic, l2_norm=False, nhead=1):
+    """inference.py Model.forward (:79-96) in eval mode: frozen encoders -> cat [B,4096] -> 8 Linear(4096,512)
+    label tokens -> one TransformerEncoderLayer over the 8 tokens -> (optional L2 norm) -> 8 prototype heads."""
+    fd = resnet50_features(derm, P, B, "extractor.derm_backbone.", False)
+    fc = resnet50_features(clinic, P, B, "extractor.clinic_backbone.", False)
+    feats = torch.cat([fd, fc], dim=1)
+    tokens = torch.stack([F.linear(feats, P[f"projectors.projectors.{i}.0.weight"], P[f"projectors.projectors.{i}.0.bias"])
+                          for i in range(8)], dim=0)
+    sa = transformer_encoder_layer(tokens, P, "mlc_sa.", nhead)
+    if l2_norm:
+        sa = F.normalize(sa, dim=-1, p=2)
+    return [F.linear(sa[i % sa.shape[0]], P[f"prototypes.{i}.weight"], P[f"prototypes.{i}.bias"]) for i in range(8)]
+
+
 def linear_probe_loss(outputs, labels, label_weights=(1.0,) * 8):
     """tools/backbone_eval.py:101-105: sum_i w_i * CE(out_i, labels[:, i]) / num_labels."""
     return sum(w * F.cross_entropy(o, labels[:, i]) for i, (o, w) in enumerate(zip(outputs, label_weights))) / len(outputs)

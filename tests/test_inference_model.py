@@ -1,0 +1,67 @@
+"""Multi-label inference model row (inference.py): the oracle pinned to a golden generated from the
+reference's own inference.py (CPU); our inference.Model -- HIP encoders with the fused conv+BN inference kernel,
+heads as in the reference -- against the same golden (GPU); checkpoint key layout."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def _golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "inference_b5_s64_f64.npz"))
+
+
+def _inputs(g):
+    from oracle import procedural
+    batch, size, seed = [int(v) for v in g["meta"]]
+    state = procedural.make_state_dict(procedural.inference_model_spec(), seed=seed)
+    derm_np, clinic_np = procedural.make_pair_batch(batch, size, seed)
+    return state, torch.from_numpy(derm_np[0]), torch.from_numpy(clinic_np[0])
+
+
+def test_oracle_inference_model_matches_reference_golden(golden_dir):
+    from oracle import sm3_oracle as O
+    g = _golden(golden_dir)
+    state, derm, clinic = _inputs(g)
+    P, B = O.split_state(state, torch.float64, requires_grad=False)
+    preds = O.inference_forward(P, B, derm.double(), clinic.double())
+    for i, o in enumerate(preds):
+        np.testing.assert_allclose(o.numpy(), g[f"pred_{i}"], atol=1e-9)
+
+
+def test_inference_model_state_dict_is_the_reference_layout(golden_dir):
+    """best_linear.pth / best_finetune.pth load unchanged (inference.py:123-127): same keys, same order."""
+    import inference
+    m = inference.build_model()
+    with open(os.path.join(golden_dir, "inference_state_dict_keys.txt")) as f:
+        ref_keys = f.read().split()
+    assert list(m.state_dict().keys()) == ref_keys
+
+
+@pytest.mark.gpu
+def test_inference_model_matches_golden(golden_dir):
+    import inference
+    g = _golden(golden_dir)
+    state, derm, clinic = _inputs(g)
+    m = inference.build_model()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    for bb in (m.extractor.derm_backbone, m.extractor.clinic_backbone):
+        bb.sm3_dtype = torch.float32
+    m.cuda().eval()
+    with torch.no_grad():
+        preds = m(derm.cuda(), clinic.cuda())
+    torch.cuda.synchronize()
+    scale = max(float(np.abs(g[f"pred_{i}"]).max()) for i in range(8))
+    for i, o in enumerate(preds):
+        # f32 MFMA encoders + f32 heads vs the fp64 reference: LayerNorm keeps the tokens O(1), so 2e-4 of the
+        # largest logit is the same bar as the linear-probe row
+        np.testing.assert_allclose(o.cpu().double().numpy(), g[f"pred_{i}"], atol=2e-4 * scale + 1e-6)
+    # bf16 encoders: same predictions to bf16 accuracy
+    for bb in (m.extractor.derm_backbone, m.extractor.clinic_backbone):
+        bb.sm3_dtype = torch.bfloat16
+    with torch.no_grad():
+        p16 = m(derm.cuda(), clinic.cuda())
+    rel = max(float((a.double().cpu() - torch.from_numpy(g[f"pred_{i}"])).norm() / np.linalg.norm(g[f"pred_{i}"]))
+              for i, a in enumerate(p16))
+    assert rel < 5e-2, rel
