@@ -243,7 +243,7 @@ def main():
     # counters cannot be read from inside the process, so the committed measurement is reported, for the workload
     # it was taken on only.
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01b_pmc_traffic_conv_igemm_b256_bf16.json")
+    tpath = os.path.join(ROOT, "profiles", "r01c_pmc_traffic_conv_igemm_b256_bf16.json")
     if args.dtype == "bf16" and B == 256 and S == 224 and os.path.exists(tpath):
         traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
     # The kernel's 432 launches per step straddle the ridge (peak FLOP/s / 8 TB/s = 312 FLOP/B at bf16): split them

@@ -4,7 +4,7 @@ streams (MI355X_MICROARCH.md, HBM section).  Usage: collect_traffic.py <fetch_di
 import csv, glob, json, sys
 
 def per_launch(d, counter):
-    f = glob.glob(f"{d}/*/*_counter_collection.csv")[0]
+    f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
     tot, n = 0.0, 0
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter and "conv_igemm_kernel<bf16_t, 128, 128" in r["Kernel_Name"]:
