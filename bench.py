@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=3)
-    ap.add_argument("--workload", default="pretrain", choices=["pretrain", "linear_probe"],
+    ap.add_argument("--workload", default="pretrain", choices=["pretrain", "linear_probe", "inference"],
                     help="pretrain = BASELINE.json's metric (default); linear_probe = SURVEY.md 8f-1 (tools/backbone_eval.py "
                          "--finetune fc step at run.sh's batch 128: frozen eval-mode encoders + 8 trained heads)")
     ap.add_argument("--breakdown", default=None, help="write a per-kernel-class time/FLOP/byte table (one extra, "
@@ -153,10 +153,54 @@ def linear_probe_bench(args):
                      "kernel": "conv_igemm_kernel<bf16_t,128,128,2,2,*> with the conv+evalBN+ReLU epilogue"}}), flush=True)
 
 
+def inference_bench(args):
+    """Secondary line: forward of the reference's inference.py model (eval mode), single GPU -- HIP encoders with the
+    fused conv+BN epilogue, label projectors / 8-token transformer layer / prototype heads on csrc/heads.hip."""
+    from sm3hip import ops, profiler
+    import inference
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3407)
+    B, S = (128 if args.batch == 256 else args.batch), args.img
+    m = inference.build_model()
+    for bb in (m.extractor.derm_backbone, m.extractor.clinic_backbone):
+        bb.sm3_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    m.to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(3407)
+    derm = torch.randn(B, 3, S, S, device=dev, generator=g)
+    clinic = torch.randn(B, 3, S, S, device=dev, generator=g)
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            m(derm, clinic)
+        prof = profiler.Profiler(only={"conv_gemm_128x128"})
+        torch.cuda.synchronize()
+        ops.set_profiler(prof)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            preds = m(derm, clinic)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        ops.set_profiler(None)
+    dom = prof.summary().get("conv_gemm_128x128", {"flops": 0.0, "ms": 0.0, "launches": 0})
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+    peak = MFMA_PEAK_TFLOPS[args.dtype]
+    print(json.dumps({
+        "metric": "SM3 inference pairs/sec (224x224, ResNet-50 x2 + multi-label transformer heads)",
+        "value": round(B * args.steps / elapsed, 2), "unit": "pairs/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"inference.py Model.forward (eval), batch {B}, {S}x{S}", "global_batch": B,
+                   "parallelism": "dp1", "checksum": round(float(sum(p.float().abs().sum() for p in preds)), 4)},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                     "frac": round(achieved / peak, 4), "traffic": None,
+                     "kernel": "conv_igemm_kernel<bf16_t,128,128,2,2,*> with the conv+evalBN+ReLU epilogue"}}), flush=True)
+
+
 def main():
     args = parse()
     if args.workload == "linear_probe":
         return linear_probe_bench(args)
+    if args.workload == "inference":
+        return inference_bench(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

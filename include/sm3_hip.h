@@ -204,6 +204,20 @@ int sm3_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr,
 /* found_inf[0] |= any(!isfinite(g)) */
 int sm3_check_finite(const float* g, int64_t n, int32_t* found_inf, void* stream);
 
+/* ---- multi-label heads of the inference model (reference inference.py:53-96; eval mode) -------------------
+ * The Linear layers of that model run as sm3_conv_gather_gemm (1x1, bias-free) + sm3_bn_act(scale=1, shift=bias).
+ * qkv: [B*S, 3*D] rows b*S+s, columns [q|k|v] (nn.MultiheadAttention's in_proj layout); out: [B*S, D]:
+ * softmax(q k^T / sqrt(D/nhead)) v over the S <= 8 label tokens of each sample, per head. */
+int sm3_token_attention(int dtype, const void* qkv, void* out, int B, int S, int D, int nhead, void* stream);
+/* out = LayerNorm(a + b) * gamma + beta over the last axis (b nullable); rows x D of dtype, D <= 1024
+ * (the post-norm residual joins of nn.TransformerEncoderLayer, inference.py:58-60). */
+int sm3_add_layernorm(int dtype, const void* a, const void* b, const float* gamma, const float* beta, float eps,
+                      void* out, int64_t rows, int D, void* stream);
+/* out[b, t] = <x[b, token_of[t], :], W[t, :]> + bias[t], x: [B, S, D] of dtype (each token L2-normalised first when
+ * l2_norm != 0), W: [T, D] fp32 = the prototype Linears concatenated (inference.py:62-71,90-94). */
+int sm3_token_heads(int dtype, const void* x, const float* W, const float* bias, const int* token_of, int l2_norm,
+                    float* out, int B, int S, int D, int T, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

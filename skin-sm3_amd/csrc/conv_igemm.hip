@@ -181,7 +181,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
         }
     }
 
-    // ---- lean epilogue: plain bf16 forward convolution (dense output, no addend / fusion) --------------------
+    // ---- lean epilogue: bf16 forward convolution, dense output, no addend / BN-backward fusion ----------------
     // What the train-mode forward launches need, at a quarter of the general epilogue's VALU work (which, with 3-4
     // workgroups per CU, was as long as the HBM time of a K<=256 tile): accumulators -> bf16 pairs in registers
     // (v_cvt_pk_bf16_f32); BatchNorm sums of the ROUNDED values with two v_dot2c_f32_bf16 per pair; the whole
@@ -196,11 +196,22 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
         for (int j = 0; j < TN; ++j) {
             float s1 = 0.f, s2 = 0.f;
             char* colp = sC + (wn * WTN + j * 32 + frow) * 2 + (wm * WTM + 4 * fh) * LEAN_PITCH;
+            // inference: eval-mode BatchNorm (+ReLU) of this lane's column, applied in the accumulator layout
+            const int gcol = n0 + wn * WTN + j * 32 + frow;
+            const bool epl = p.ep_scale != nullptr;
+            const float esc = (epl && gcol < p.Co) ? p.ep_scale[gcol] : 1.f;
+            const float esh = (epl && gcol < p.Co) ? p.ep_shift[gcol] : 0.f;
+            const float elo = (epl && p.ep_relu) ? 0.f : -INFINITY;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {  // registers 2q, 2q+1 = rows R, R+1 of this lane's column
-                    const uint32_t pk = pack_bf16x2(acc[i][j][2 * q], acc[i][j][2 * q + 1]);
+                    float v0 = acc[i][j][2 * q], v1 = acc[i][j][2 * q + 1];
+                    if (epl) {
+                        v0 = fmaxf(v0 * esc + esh, elo);
+                        v1 = fmaxf(v1 * esc + esh, elo);
+                    }
+                    const uint32_t pk = pack_bf16x2(v0, v1);
                     const bf16x2_t pv = __builtin_bit_cast(bf16x2_t, pk);
                     s1 = __builtin_amdgcn_fdot2_f32_bf16(pv, ones, s1, false);
                     s2 = __builtin_amdgcn_fdot2_f32_bf16(pv, pv, s2, false);
@@ -449,7 +460,7 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         const char* lv = getenv("SM3_CONV_LEAN");
         const bool dense = p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.HWout == p.HoWo;
-        if (!(lv && atoi(lv) == 0) && dense && !p.addend && !p.fz_x && !p.ep_scale)
+        if (!(lv && atoi(lv) == 0) && dense && !p.addend && !p.fz_x)  // train-mode forward, and conv+evalBN(+ReLU)
             return single ? launch_conv_st<T, BM, BN, WM, WN, 1, true>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, true>(p, st);
     }
     if (single) return launch_conv_st<T, BM, BN, WM, WN, 1, false>(p, st);

@@ -438,14 +438,14 @@ int launch_conv_v2(const ConvParams& p0, hipStream_t st) {
     const int grid = ntiles < ncu ? (int)ntiles : ncu;
     if (env_int("SM3_CONV_V2_DIAG", 0)) {  // diagnostic: synchronous, prints the segment averages (cycles per unit)
         auto dk = conv_igemm_v2_kernel<bf16_t, true>;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(dk), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dk), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         long long* dbg = nullptr;
         const size_t n = (size_t)grid * 64;
         if (hipMalloc(&dbg, n * 8) != hipSuccess) return SM3_EINVAL;
         hipLaunchKernelGGL(dk, dim3(grid), dim3(NT), LDS_BYTES, st, p, (int)ntiles, dbg);
-        hipStreamSynchronize(st);
+        (void)hipStreamSynchronize(st);
         long long* h = (long long*)malloc(n * 8);
-        hipMemcpy(h, dbg, n * 8, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(h, dbg, n * 8, hipMemcpyDeviceToHost);
         double a[2][8] = {};
         for (int b = 0; b < grid; ++b)
             for (int w = 0; w < 8; ++w)
@@ -455,7 +455,7 @@ int launch_conv_v2(const ConvParams& p0, hipStream_t st) {
         fprintf(stderr, "[v2 diag] M=%d Co=%d taps=%d kchunks=%d tiles=%ld grid=%d: cycles per unit per wave (group A | B)\n", p.M, p.Co, p.ntaps, p.kchunks, ntiles, grid);
         for (int i = 0; i < 8; ++i) fprintf(stderr, "   %-10s %8.0f | %8.0f\n", names[i], a[0][i] / units, a[1][i] / units);
         free(h);
-        hipFree(dbg);
+        (void)hipFree(dbg);
         return 0;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), LDS_BYTES, st, p, (int)ntiles, (long long*)nullptr);

@@ -1,9 +1,11 @@
 """Minimal inference entry point on the HIP encoders -- mirrors the reference's inference.py surface
 (`Extractor`, `MultiLabelProjector`, `Model`, NUM_CLASSES ...; reference inference.py:16-96).
 
-The two ResNet-50 encoders (all of the FLOPs) run on the sm3hip engine in eval mode; the 8 x Linear(4096,512)
-projectors, the single 8-token TransformerEncoderLayer and the 8 prototype heads are a few MFLOP and stay
-stock PyTorch ("drop-in surface").  Checkpoints in the reference's wire format
+The two ResNet-50 encoders (all of the FLOPs) run on the sm3hip engine in eval mode, and so do the heads
+(`sm3hip/heads.py`): the 8 x Linear(4096,512) label projectors as one MFMA GEMM, the 8-token
+TransformerEncoderLayer (attention, residual LayerNorms, feed-forward) and the 8 prototype heads on
+`csrc/heads.hip`.  The nn.Modules below only own the parameters in the reference's layout; in training mode
+(`tools/mlc_train.py`, not built natively yet) they run as stock PyTorch.  Checkpoints in the reference's wire format
 (`best_linear.pth` / `best_finetune.pth`, keys with "encoder." stripped, inference.py:123-127) load unchanged.
 """
 import torch
@@ -54,6 +56,7 @@ class Model(nn.Module):
                                                  dropout=sa_dropout)
         self.feat_dim = feat_dim
         self.l2_norm = l2_norm
+        self._hip_heads = None
         self.prototypes = nn.ModuleList([nn.Linear(feat_dim, n) for n in NUM_CLASSES])
         for layer in self.prototypes:
             layer.weight.data.normal_(mean=0.0, std=0.01)
@@ -61,6 +64,13 @@ class Model(nn.Module):
 
     def forward(self, derm_imgs, clinic_imgs):
         feats = torch.cat(self.extractor.extract(derm_imgs, clinic_imgs), dim=1)      # [B, 4096]  (HIP encoders)
+        if not self.training and feats.is_cuda:                                       # heads on the HIP kernels
+            if self._hip_heads is None:
+                from sm3hip.heads import LabelHeads
+                self._hip_heads = LabelHeads(self)
+            import sm3hip
+            dt = self.extractor.derm_backbone.__dict__.get("sm3_dtype") or sm3hip.default_dtype()
+            return self._hip_heads(feats.float(), dt)
         tokens = torch.stack(self.projectors(feats), dim=0)                           # [8, B, 512]
         sa = self.mlc_sa(tokens)
         if self.l2_norm:

@@ -71,6 +71,9 @@ SIGNATURES = {
     "sm3_ntxent_fused": [_I, _P, _I, _I, _F, _F, _P, _P, _P, _P],
     "sm3_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P, _P],
     "sm3_check_finite": [_P, _L, _P, _P],
+    "sm3_token_attention": [_I, _P, _P, _I, _I, _I, _I, _P],
+    "sm3_add_layernorm": [_I, _P, _P, _P, _P, _F, _P, _L, _I, _P],
+    "sm3_token_heads": [_I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
 }
 
 _lib = None

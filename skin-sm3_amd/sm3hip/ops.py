@@ -520,3 +520,38 @@ def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0,
 def check_finite(g, found_inf):
     _chk(g, torch.float32); _chk(found_inf, torch.int32)
     check(_lib.load().sm3_check_finite(_ptr(g), g.numel(), _ptr(found_inf), _stream()), "sm3_check_finite")
+
+
+# ------------------------------------------------------------------------------------------
+# multi-label heads (inference model)
+# ------------------------------------------------------------------------------------------
+def token_attention(dtype, qkv, out, B, S, D, nhead):
+    tdt = TORCH_DTYPE[dtype]
+    _chk(qkv, tdt, "qkv"); _chk(out, tdt, "out")
+    if qkv.numel() != B * S * 3 * D or out.numel() != B * S * D:
+        raise ValueError("token_attention: size mismatch")
+    if S > 8 or nhead < 1 or nhead > 8 or D % nhead:
+        raise ValueError("token_attention: at most 8 tokens / 8 heads, D divisible by nhead")
+    check(_lib.load().sm3_token_attention(dtype, _ptr(qkv), _ptr(out), B, S, D, nhead, _stream()), "sm3_token_attention")
+
+
+def add_layernorm(dtype, a, b, gamma, beta, eps, out, rows, D):
+    tdt = TORCH_DTYPE[dtype]
+    _chk(a, tdt, "a"); _chk(b, tdt, "b"); _chk(out, tdt, "out"); _chk(gamma, torch.float32); _chk(beta, torch.float32)
+    if a.numel() != rows * D or out.numel() != rows * D or (b is not None and b.numel() != rows * D):
+        raise ValueError("add_layernorm: size mismatch")
+    if gamma.numel() != D or beta.numel() != D or D > 1024:
+        raise ValueError("add_layernorm: gamma/beta must have D <= 1024 entries")
+    check(_lib.load().sm3_add_layernorm(dtype, _ptr(a), _ptr(b), _ptr(gamma), _ptr(beta), float(eps), _ptr(out), rows, D,
+                                        _stream()), "sm3_add_layernorm")
+
+
+def token_heads(dtype, x, W, bias, token_of, l2_norm, out, B, S, D, T):
+    _chk(x, TORCH_DTYPE[dtype], "x"); _chk(W, torch.float32, "W"); _chk(bias, torch.float32, "bias")
+    _chk(token_of, torch.int32, "token_of"); _chk(out, torch.float32, "out")
+    if x.numel() != B * S * D or W.numel() != T * D or bias.numel() != T or token_of.numel() != T or out.numel() != B * T:
+        raise ValueError("token_heads: size mismatch")
+    if S > 8:
+        raise ValueError("token_heads: at most 8 tokens")
+    check(_lib.load().sm3_token_heads(dtype, _ptr(x), _ptr(W), _ptr(bias), _ptr(token_of), int(bool(l2_norm)), _ptr(out),
+                                      B, S, D, T, _stream()), "sm3_token_heads")

@@ -65,3 +65,37 @@ def test_inference_model_matches_golden(golden_dir):
     rel = max(float((a.double().cpu() - torch.from_numpy(g[f"pred_{i}"])).norm() / np.linalg.norm(g[f"pred_{i}"]))
               for i, a in enumerate(p16))
     assert rel < 5e-2, rel
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nhead,l2", [(1, False), (4, True)])
+def test_label_heads_kernels_match_torch_modules(nhead, l2):
+    """sm3hip.heads.LabelHeads (GEMMs + csrc/heads.hip) against the same nn.Modules run by PyTorch in fp64:
+    label projectors, multi-head attention over the 8 tokens, both residual LayerNorms, feed-forward, L2 norm,
+    prototype heads.  Odd batch on purpose."""
+    import inference
+    from sm3hip.heads import LabelHeads
+    torch.manual_seed(3)
+    m = inference.Model(torch.nn.Module(), inference.MultiLabelProjector(4096, 512, 8), 512, l2, nhead, 128, 0.1)
+    for p in m.parameters():  # biases / norms away from their trivial initial values
+        if p.dim() == 1:
+            p.data.add_(0.3 * torch.randn_like(p))
+    m.eval()
+    feats = torch.randn(7, 4096)
+    with torch.no_grad():
+        md = m.double()
+        tok = torch.stack(md.projectors(feats.double()), 0)
+        sa = md.mlc_sa(tok)
+        if l2:
+            sa = torch.nn.functional.normalize(sa, dim=-1, p=2)
+        want = [md.prototypes[i](sa[i % 8]) for i in range(8)]
+    m = m.float().cuda()
+    heads = LabelHeads(m)
+    got = heads(feats.cuda(), torch.float32)
+    scale = max(float(w.abs().max()) for w in want)
+    for a, b in zip(got, want):
+        assert a.shape == b.shape
+        assert float((a.double().cpu() - b).abs().max()) < 2e-5 * max(scale, 1.0)
+    got16 = heads(feats.cuda(), torch.bfloat16)
+    rel = max(float((a.double().cpu() - b).norm() / b.norm()) for a, b in zip(got16, want))
+    assert rel < 4e-2, rel
