@@ -15,7 +15,7 @@
 // and nn.Linear (src/models/simclr.py:17-27) inside loss.backward() (tools/backbone_train.py:125).
 #include <stdlib.h>
 
-#include "common.h"
+#include "conv_common.h"
 
 namespace {
 
@@ -35,23 +35,9 @@ struct WgradParams {
     uint32_t x_bytes;
 };
 
-constexpr uint32_t kOOB = 0xC0000000u;  // voffset beyond any tensor (< 3 GB, checked on the host): reads zeros
-
-// LDS-DMA (buffer_load_dwordx4 ... lds) issued from inline asm: see conv_igemm.hip for why (no VGPR staging, no
-// ds_write, zero-fill by the buffer range check, and hipcc must not order the ds_reads behind it).
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t lds_wave_base, uint32_t voff, uint32_t soff) {
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %1\n\t"
-        "s_nop 0\n\t"
-        "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "s"(lds_wave_base), "v"(voff), "s"(rsrc), "s"(soff)
-        : "memory");
-}
-__device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+using sm3conv::dma16;       // LDS-DMA from inline asm, zero-fill by the buffer range check: see conv_common.h
+using sm3conv::dma_drain;
+using sm3conv::kOOB;
 
 // bf16 tiles are read with ds_read_b64_tr_b16, whose 16-lane groups fetch 4 pixel rows x 32 bytes: with the
 // unpadded pitch LDS-DMA needs (a wave-instruction writes 1 KiB contiguously) those 4 rows would share banks, so

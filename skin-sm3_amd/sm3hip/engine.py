@@ -258,10 +258,10 @@ class SM3Engine:
         # the two views of a branch on two more streams (BN running statistics stay ordered through events): correct
         # (GPU test suite passes with it on) but measured slower -- 2 700 vs 2 780 pairs/s -- so off: two lanes
         # already keep HBM and MFMA busy, four only add contention
-        self.view_lanes = False
+        self.view_lanes = _os.environ.get("SM3_VIEW_LANES", "0") == "1"
         self._bn_ev = {}
         self._ordered_bn = False  # set while the two views of a branch run on two lanes
-        self.side_wgrad = False  # measured slower (2600 vs 2790 pairs/s): weight-gradient kernels fight the HBM-bound chain for L2/HBM
+        self.side_wgrad = _os.environ.get("SM3_SIDE_WGRAD", "0") == "1"  # measured slower (2600 vs 2790 pairs/s): weight-gradient kernels fight the HBM-bound chain for L2/HBM
         self._side = {}
         self.two_streams = True
         self._streams, self._streams_dev = None, None
