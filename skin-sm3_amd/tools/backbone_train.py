@@ -44,6 +44,8 @@ def get_parser():
     p.add_argument("--use-checkpoint", action="store_true")
     p.add_argument("--epochs", default=100, type=int)
     p.add_argument("--steps-per-epoch", default=100, type=int, help="synthetic data only")
+    p.add_argument("--synthetic-kind", default="noise", choices=["noise", "latent"],
+                   help="synthetic data: independent noise (throughput) or learnable latent-pattern pairs")
     p.add_argument("-b", "--batch-size", default=64, type=int, help="global mini-batch size")
     p.add_argument("-lr", "--base-lr", default=1e-3, type=float)
     p.add_argument("--wd", default=5e-2, type=float)
@@ -61,9 +63,24 @@ def get_parser():
 STYLE = {"v3": 0, "v32": 0, "v311": 1, "v321": 1, "v312": 2, "v322": 2}
 
 
-def synthetic_batch(bs, size, device, gen):
-    mk = lambda: torch.randn(bs, 3, size[0], size[1], device=device, generator=gen)
-    return [mk(), mk()], [mk(), mk()]
+def synthetic_batch(bs, size, device, gen, kind="noise"):
+    """([derm view 0, view 1], [clinic view 0, view 1]) of normalised images generated on the device.
+    "noise": independent N(0,1) images (throughput runs: nothing to learn).  "latent": every sample has a random
+    low-frequency pattern that all four of its images show (the clinical ones colour-mixed and mirrored), under
+    independent pixel noise and contrast jitter -- positives are identifiable, so the loss can fall."""
+    if kind == "noise":
+        mk = lambda: torch.randn(bs, 3, size[0], size[1], device=device, generator=gen)
+        return [mk(), mk()], [mk(), mk()]
+    z = torch.randn(bs, 3, 6, 6, device=device, generator=gen)
+    base = torch.nn.functional.interpolate(z, size=tuple(size), mode="bilinear", align_corners=False) * 1.5
+    mix = torch.tensor([[0.6, 0.3, 0.1], [0.2, 0.5, 0.3], [0.1, 0.2, 0.7]], device=device)
+    other = torch.einsum("dc,bchw->bdhw", mix, base).flip(-1)
+
+    def view(img):
+        gain = 1.0 + 0.2 * torch.randn(bs, 1, 1, 1, device=device, generator=gen)
+        return (img * gain + 0.5 * torch.randn(img.shape, device=device, generator=gen)).contiguous()
+
+    return [view(base), view(base)], [view(other), view(other)]
 
 
 def main(local_rank, args):
@@ -109,7 +126,7 @@ def main(local_rank, args):
         model.train()
         t0, seen, running = time.time(), 0, None
         for it in range(args.steps_per_epoch):
-            derm, clinic = synthetic_batch(bs, args.img_sz, dev, gen)
+            derm, clinic = synthetic_batch(bs, args.img_sz, dev, gen, args.synthetic_kind)
             if args.engine == "fused":
                 loss = trainer.step(derm, clinic)
             else:
