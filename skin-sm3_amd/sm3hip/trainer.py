@@ -46,7 +46,9 @@ class SM3Trainer:
             # communicator execute in enqueue order, so with a single one the clinic lane's first statistics
             # all-reduce would queue behind ALL of the derm lane's and the lanes would serialise.  Every rank
             # creates the groups in the same order; each lane's call sequence is identical on every rank.
-            lanes = list(eng.branches) + [k + "#1" for k in eng.branches] + ["main"]
+            # Gradient buckets get a communicator of their own: on a lane's communicator a 60 MB bucket would sit
+            # in front of that lane's next (latency-critical) BatchNorm statistics all-reduce.
+            lanes = list(eng.branches) + [k + "#1" for k in eng.branches] + ["main", "grads"]
             self._groups = {k: dist.new_group() for k in lanes}
         if self.dp and self.sync_bn and eng.__dict__.get("_explicit_sync") is None:
             eng.world_size = self.world
@@ -63,7 +65,7 @@ class SM3Trainer:
         hi = max(i for i, n in enumerate(names) if n.startswith(last))
         a = st.offsets[names[lo]]
         b = st.offsets[names[hi]] + (st._view(st.flat_g, names[hi]).numel() + 15) // 16 * 16
-        self._handles.append(dist.all_reduce(st.flat_g[a:b], async_op=True, group=self._groups[eng._lane]))
+        self._handles.append(dist.all_reduce(st.flat_g[a:b], async_op=True, group=self._groups["grads"]))
 
     def step(self, derm_imgs, clinic_imgs):
         """One optimizer step on this rank's batch; returns the (device, fp32, 1-element) loss tensor."""
