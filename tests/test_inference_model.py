@@ -99,3 +99,33 @@ def test_label_heads_kernels_match_torch_modules(nhead, l2):
     got16 = heads(feats.cuda(), torch.bfloat16)
     rel = max(float((a.double().cpu() - b).norm() / b.norm()) for a, b in zip(got16, want))
     assert rel < 4e-2, rel
+
+
+@pytest.mark.gpu
+def test_head_kernels_edge_shapes_and_argument_checks():
+    """Fewer tokens than 8, a narrow model dimension, 8 heads; and the host-side argument checks of the wrappers."""
+    from sm3hip import ops
+    torch.manual_seed(0)
+    B, S, D, nh = 3, 5, 128, 8
+    qkv = torch.randn(B * S, 3 * D)
+    q, k, v = qkv.view(B, S, 3, nh, D // nh).double().unbind(2)            # [B,S,nh,hd]
+    att = torch.softmax(torch.einsum("bihd,bjhd->bhij", q, k) / (D // nh) ** 0.5, -1)
+    want = torch.einsum("bhij,bjhd->bihd", att, v).reshape(B * S, D)
+    out = torch.empty(B * S, D, device="cuda")
+    ops.token_attention(ops.dtype_code(torch.float32), qkv.cuda(), out, B, S, D, nh)
+    assert float((out.double().cpu() - want).abs().max()) < 1e-5
+    a, b = torch.randn(B * S, D), torch.randn(B * S, D)
+    g, be = torch.rand(D) + 0.5, torch.randn(D)
+    ln = torch.empty(B * S, D, device="cuda")
+    ops.add_layernorm(ops.dtype_code(torch.float32), a.cuda(), b.cuda(), g.cuda(), be.cuda(), 1e-5, ln, B * S, D)
+    ref = torch.nn.functional.layer_norm((a + b).double(), (D,), g.double(), be.double(), 1e-5)
+    assert float((ln.double().cpu() - ref).abs().max()) < 1e-5
+    ops.add_layernorm(ops.dtype_code(torch.float32), a.cuda(), None, g.cuda(), be.cuda(), 1e-5, ln, B * S, D)  # no residual
+    ref = torch.nn.functional.layer_norm(a.double(), (D,), g.double(), be.double(), 1e-5)
+    assert float((ln.double().cpu() - ref).abs().max()) < 1e-5
+    with pytest.raises(ValueError):
+        ops.token_attention(ops.dtype_code(torch.float32), qkv.cuda(), out, B, 9, D, nh)      # more than 8 tokens
+    with pytest.raises(ValueError):
+        ops.token_attention(ops.dtype_code(torch.float32), qkv, out, B, S, D, nh)              # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        ops.add_layernorm(ops.dtype_code(torch.float32), a.cuda(), b.cuda()[:-1], g.cuda(), be.cuda(), 1e-5, ln, B * S, D)
