@@ -346,10 +346,13 @@ class SM3Engine:
                 self.stream.wait_stream(torch.cuda.current_stream())  # everything enqueued so far is visible
                 self.ctx = torch.cuda.stream(self.stream)
                 self.ctx.__enter__()
+                self.pin = ops.stream_scope()  # the lane's raw stream handle, looked up once per lane entry
+                self.pin.__enter__()
             return self
 
         def __exit__(self, *exc):
             if self.ctx is not None:
+                self.pin.__exit__(*exc)
                 self.ctx.__exit__(*exc)
             self.eng._lane = self.prev
             self.eng._view = self.prev_view
@@ -486,7 +489,7 @@ class SM3Engine:
         side.wait_stream(cur)  # dxo is ready
         for t in (dxo, r.x_in):
             t.record_stream(side)  # keep the allocator from recycling them while the side stream still reads
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), ops.stream_scope():
             ops.conv_wgrad(desc, r.x_in, dxo, gw)
 
     def _side_stream(self):

@@ -45,8 +45,36 @@ def _sz(dtype):
     return 4 if dtype == SM3_F32 else 2
 
 
+# torch.cuda.current_stream() costs ~8 us of host time and every wrapper needs the handle: 2 400 calls = 30 % of the
+# host side of a step.  A caller that owns the stream context (the engine: one scope per lane entry / step) pins the
+# raw handle with stream_scope(); outside such a scope the handle is looked up per launch as before.
+_PINNED_STREAM = None
+
+
+class stream_scope:
+    """with ops.stream_scope(): every launch inside goes to torch's current stream AS OF ENTRY (raw handle cached).
+    Nest a new scope whenever the current stream changes (torch.cuda.stream(...))."""
+
+    def __enter__(self):
+        global _PINNED_STREAM
+        self.prev = _PINNED_STREAM
+        _PINNED_STREAM = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0
+        return self
+
+    def __exit__(self, *exc):
+        global _PINNED_STREAM
+        _PINNED_STREAM = self.prev
+        return False
+
+
+def _stream_handle():
+    if _PINNED_STREAM is not None:
+        return _PINNED_STREAM
+    return torch.cuda.current_stream().cuda_stream
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_stream_handle())
 
 
 def _ptr(t):
@@ -248,7 +276,7 @@ _bn_ws = {}
 
 def _bn_workspace(device, Cn):
     """fp64 scratch of the two-stage statistics reduction (stream-ordered reuse: one per device AND stream)."""
-    device = (device, torch.cuda.current_stream().cuda_stream if device.type == "cuda" else 0)
+    device = (device, _stream_handle() if device.type == "cuda" else 0)
     t = _bn_ws.get(device)
     need = BN_REDUCE_GROUPS * 2 * Cn
     if t is None or t.numel() < need:

@@ -69,6 +69,10 @@ class SM3Trainer:
 
     def step(self, derm_imgs, clinic_imgs):
         """One optimizer step on this rank's batch; returns the (device, fp32, 1-element) loss tensor."""
+        with ops.stream_scope():  # launches outside the lanes go to the stream that is current now
+            return self._step(derm_imgs, clinic_imgs)
+
+    def _step(self, derm_imgs, clinic_imgs):
         eng = self._engine()
         dev = derm_imgs[0].device
         eng.prepare(dev)
