@@ -134,3 +134,26 @@ def test_adamw_grad_scale_and_overflow_skip_in_trainer_units():
     ops.adamw(p, g, m, v, 1e-2, 0.9, 0.999, 1e-5, 0.0, 1, grad_scale=1.0 / 8)
     torch.cuda.synchronize()
     assert torch.allclose(m, torch.full_like(m, 0.1)) and torch.allclose(p, torch.full_like(p, 1 - 1e-2), atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("proj_dim,temp,style", [(256, 0.5, 0), (64, 0.07, 2)])
+def test_other_projection_widths_temperatures_and_styles(proj_dim, temp, style):
+    """Constructor arguments other than the recipe's (proj_dim 128, temperature 0.1): fused step loss against the
+    CPU oracle in fp64 on the same weights and inputs (B = 8, 64x64, exact-f32 MFMA mode)."""
+    from oracle import procedural, sm3_oracle as O
+    from sm3hip.trainer import SM3Trainer
+    from src.models.simclr import SimCLRSkinV32
+    torch.manual_seed(1)
+    model = SimCLRSkinV32("resnet50", None, proj_dim, temp)
+    state = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+    P, B = O.split_state(state, torch.float64)
+    model.sm3_dtype = torch.float32
+    model.to("cuda:0")
+    derm_np, clinic_np = procedural.make_pair_batch(8, 64, 9)
+    want, _ = O.train_step(P, B, [torch.from_numpy(a).double() for a in derm_np],
+                           [torch.from_numpy(a).double() for a in clinic_np], style, temp)
+    tr = SM3Trainer(model, lr=1e-6, style=style)
+    got = tr.step([torch.from_numpy(a).cuda() for a in derm_np], [torch.from_numpy(a).cuda() for a in clinic_np])
+    torch.cuda.synchronize()
+    assert abs(float(got) - float(want)) < 1e-3, (float(got), float(want))
