@@ -76,10 +76,13 @@ int sm3_conv_gather_gemm(const sm3_conv_desc* d, const void* x, const void* w, v
 typedef struct sm3_bn_bwd_fuse {
     const uint8_t* relu_mask;
     const void* x;
-    const float* mean;
-    const float* invstd;
+    const float* mean;           /* [views][Co] */
+    const float* invstd;         /* [views][Co] */
     float* partials;
-    int32_t partial_row_offset;
+    int32_t partial_row_offset;  /* first partial row of view 0's tiles */
+    int32_t views;               /* 0 or 1: one BatchNorm batch.  2: the launch covers two views back to back (rows
+                                  * [0, M/2) and [M/2, M), M/2 a multiple of 128), each with its own mean / invstd ... */
+    int32_t partial_row_offset_view1; /* ... and view 1's tiles write their partial rows from here */
 } sm3_bn_bwd_fuse;
 int sm3_conv_dgrad_bnfuse(const sm3_conv_desc* d, const void* dy_in, const void* w_dgrad, void* dz_out,
                           const void* addend, const sm3_bn_bwd_fuse* fuse, void* stream);
@@ -107,16 +110,22 @@ int sm3_conv_wgrad(const sm3_conv_desc* d, const void* x, const void* dy, float*
 #define SM3_BN_REDUCE_GROUPS 64
 /* number of fp64 [2C] rows stage A leaves in workspace for `rows` partial rows */
 int sm3_bn_reduce_groups(int rows);
-/* sums == NULL: only stage A runs; pass (workspace, sm3_bn_reduce_groups(rows)) to sm3_bn_finalize */
-int sm3_bn_stats_reduce(const float* partials, int rows, int C, double* sums, double* workspace, void* stream);
+/* "views": the two views of a branch go through the convolutions as ONE batch (view 0's rows, then view 1's) but
+ * keep separate BatchNorm statistics (simclr.py:58-59).  Every BatchNorm entry point takes `views` >= 1 and treats
+ * its tensors as `views` equal row ranges laid out back to back, with per-view parameter vectors [views][C] /
+ * [views][2C]; `rows` is always the row count of ONE view.
+ * sums == NULL: only stage A runs; pass (workspace, sm3_bn_reduce_groups(rows)) to sm3_bn_finalize.
+ * partials: [views][rows][2][C]; sums: [views][2C]; workspace: views * SM3_BN_REDUCE_GROUPS * 2C doubles. */
+int sm3_bn_stats_reduce(const float* partials, int rows, int C, double* sums, double* workspace, int views,
+                        void* stream);
 /* From (possibly all-reduced) sums and the global element count per channel: mean, biased var ->
  * scale = gamma*invstd, shift = beta - mean*scale; running stats momentum update with the unbiased
  * variance; saves mean / invstd for backward.  gamma/beta NULL => affine=False. */
-int sm3_bn_finalize(const double* sums, int groups /* sums is [groups][2C], summed here */, double count, int C,
-                    const float* gamma, const float* beta,
+int sm3_bn_finalize(const double* sums, int groups /* sums is [views][groups][2C], groups summed here */, int views,
+                    double count /* per view */, int C, const float* gamma, const float* beta,
                     float eps, float momentum, float* running_mean, float* running_var,
-                    int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean,
-                    float* save_invstd, void* stream);
+                    int64_t* num_batches_tracked /* += views */, float* scale, float* shift, float* save_mean,
+                    float* save_invstd /* all four [views][C]; running statistics updated view by view */, void* stream);
 /* eval mode: scale/shift from the running statistics */
 int sm3_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean,
                             const float* running_var, float eps, int C, float* scale, float* shift,
@@ -126,20 +135,20 @@ int sm3_bn_eval_scale_shift(const float* gamma, const float* beta, const float* 
  * pass needs of y, at 1/16 of its bytes.
  * replaces the bn->relu / bn->add->relu chains of Bottleneck.forward (resnet.py:154-174). */
 int sm3_bn_act(int dtype, const void* x, const float* scale, const float* shift, const void* residual,
-               int relu, int out_f32, void* y, uint8_t* relu_mask, int64_t rows, int C, void* stream);
+               int relu, int out_f32, void* y, uint8_t* relu_mask, int64_t rows, int C, int views, void* stream);
 /* Backward, phase 1: dz = dy * (y > 0), the mask taken from relu_mask if given, else from y if given, else all
  * ones; writes dz (may alias dy; NULL to skip) and
  * per-block partial sums [bwd_partial_rows][2][C] of (dz, dz * xhat), xhat = (x-mean)*invstd. */
 int sm3_bn_bwd_partial_rows(int64_t rows, int C);
 int sm3_bn_bwd_reduce(int dtype, const void* dy, const void* y, const uint8_t* relu_mask, const void* x,
-                      const float* mean, const float* invstd, void* dz, int64_t rows, int C, float* partials,
-                      void* stream);
+                      const float* mean, const float* invstd, void* dz, int64_t rows, int C,
+                      float* partials /* [views][bwd_partial_rows][2][C] */, int views, void* stream);
 /* Backward, phase 2: dx = gamma*invstd*(dz - sum_dz/count - xhat*sum_dz_xhat/count) with the
  * (all-reduced) global sums; dgamma += local sum(dz*xhat), dbeta += local sum(dz) (NULL to skip). */
 int sm3_bn_bwd_apply(int dtype, const void* dz, const void* x, const float* mean, const float* invstd,
                      const float* gamma, const double* global_sums, double count,
                      const double* local_sums, float* dgamma, float* dbeta, void* dx, int64_t rows,
-                     int C, void* stream);
+                     int C, int views, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Stem, pooling.  replaces resnet.py:208-213,224,294-305.

@@ -18,7 +18,7 @@ struct RowWalk {
     int tbx, tby;   // threads along channel vectors / rows
     int gx, gy;     // blocks along channel vectors / row groups
 };
-static RowWalk make_walk(int64_t rows, int cvecs, int max_gy) {
+static RowWalk make_walk(int64_t rows, int cvecs, int max_gy, int views = 1) {
     RowWalk w;
     if (cvecs >= 256) {
         w.tbx = 256;
@@ -33,7 +33,7 @@ static RowWalk make_walk(int64_t rows, int cvecs, int max_gy) {
     // saturates HBM (scratch/stream_bench.hip: 1024 >= 2048 blocks), and it leaves 20 of a CU's 32 wave slots to
     // the other execution lane's convolution: 2048 -> 768 is worth 1.2 % of the two-lane step (87.4 -> 86.4 ms).
     static const int grid_cap = getenv("SM3_BN_GRID_CAP") ? atoi(getenv("SM3_BN_GRID_CAP")) : 768;
-    const int64_t cap = grid_cap / w.gx > 0 ? grid_cap / w.gx : 1;
+    const int64_t cap = grid_cap / (w.gx * views) > 0 ? grid_cap / (w.gx * views) : 1;  // the cap is per launch, views included
     if (gy > cap) gy = cap;
     if (gy > max_gy) gy = max_gy;
     if (gy < 1) gy = 1;
@@ -44,9 +44,13 @@ static RowWalk make_walk(int64_t rows, int cvecs, int max_gy) {
 // Stage A: grid (ceil(2C/64), G).  256 threads = 64 columns x 4 row lanes; a block sums its share of the
 // partial rows in fp64 and writes one row of the [G][2C] fp64 workspace.  Stage B sums the G rows.  Two tiny
 // launches, deterministic (no atomics); rows are read as 256-byte coalesced segments.
+// "views" (blockIdx.z): the same kernel over V independent row ranges laid out back to back -- the two views of a
+// branch go through the convolutions as one batch but keep separate BatchNorm statistics (simclr.py:58-59).
 __global__ __launch_bounds__(256) void bn_stats_reduce_a(const float* __restrict__ partials, int rows, int C,
                                                          double* __restrict__ ws) {
     __shared__ double red[4][64];
+    partials += (long)blockIdx.z * rows * 2 * C;
+    ws += (long)blockIdx.z * gridDim.y * 2 * C;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + tx;  // in [0, 2C): stat-major within a partial row
     double a = 0.0;
@@ -89,38 +93,44 @@ __device__ __forceinline__ double quad_sum_groups(const double* __restrict__ ws,
 }
 
 __global__ void bn_stats_reduce_b(const double* __restrict__ ws, int G, int C, double* __restrict__ sums) {
+    ws += (long)blockIdx.z * G * 2 * C;
+    sums += (long)blockIdx.z * 2 * C;
     const int t = blockIdx.x * blockDim.x + threadIdx.x, q = t & 3;
     const int col = t >> 2;
     const double a = quad_sum_groups(ws, 2L * C, col < 2 * C ? col : 0, G, q);
     if (col < 2 * C && q == 0) sums[col] = a;
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, int groups, double count, int C, const float* gamma,
-                                   const float* beta, float eps, float momentum, float* running_mean,
-                                   float* running_var, int64_t* nbt, float* scale, float* shift, float* save_mean,
-                                   float* save_invstd) {
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int groups, int views, double count, int C,
+                                   const float* gamma, const float* beta, float eps, float momentum,
+                                   float* running_mean, float* running_var, int64_t* nbt, float* scale, float* shift,
+                                   float* save_mean, float* save_invstd) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x, q = t & 3;
     const int c = t >> 2;
-    if (t == 0 && nbt) nbt[0] += 1;
-    // groups > 1: stage B of the statistics reduction folded in here (same association as bn_stats_reduce_b)
+    if (t == 0 && nbt) nbt[0] += views;
     const int cc = c < C ? c : 0;
-    const double s1 = quad_sum_groups(sums, 2L * C, cc, groups, q);
-    const double s2 = quad_sum_groups(sums, 2L * C, (long)C + cc, groups, q);
-    if (c >= C || q != 0) return;
-    const double mean = s1 / count;
-    double var = s2 / count - mean * mean;
-    if (var < 0) var = 0;
-    const double invstd = 1.0 / sqrt(var + (double)eps);
-    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    const float sc = (float)(g * invstd);
-    scale[c] = sc;
-    shift[c] = (float)((double)b - mean * (double)g * invstd);
-    if (save_mean) save_mean[c] = (float)mean;
-    if (save_invstd) save_invstd[c] = (float)invstd;
-    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-    if (running_var) {
-        const double unbiased = var * (count / fmax(count - 1.0, 1.0));
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    // views are finalised in order by the same thread: the running statistics see view 0's update before view 1's,
+    // as in the reference's sequential encoder(x1); encoder(x2)
+    for (int v = 0; v < views; ++v) {
+        // groups > 1: stage B of the statistics reduction folded in here (same association as bn_stats_reduce_b)
+        const double* sv = sums + (long)v * groups * 2 * C;
+        const double s1 = quad_sum_groups(sv, 2L * C, cc, groups, q);
+        const double s2 = quad_sum_groups(sv, 2L * C, (long)C + cc, groups, q);
+        if (c >= C || q != 0) continue;
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
+        if (var < 0) var = 0;
+        const double invstd = 1.0 / sqrt(var + (double)eps);
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        scale[(long)v * C + c] = (float)(g * invstd);
+        shift[(long)v * C + c] = (float)((double)b - mean * (double)g * invstd);
+        if (save_mean) save_mean[(long)v * C + c] = (float)mean;
+        if (save_invstd) save_invstd[(long)v * C + c] = (float)invstd;
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        if (running_var) {
+            const double unbiased = var * (count / fmax(count - 1.0, 1.0));
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
     }
 }
 
@@ -146,6 +156,15 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x, co
     const int tx = threadIdx.x % tbx, ty = threadIdx.x / tbx;
     const int cv = blockIdx.x * tbx + tx;
     if (cv * E >= C || ty >= tby) return;
+    {  // view blockIdx.z: its own row range and scale/shift
+        const int64_t vo = (int64_t)blockIdx.z * rows * C;
+        x += vo;
+        if (res) res += vo;
+        y = OUT_F32 ? (void*)(reinterpret_cast<float*>(y) + vo) : (void*)(reinterpret_cast<T*>(y) + vo);
+        if (mask) mask += (int64_t)blockIdx.z * rows * (C / E);
+        scale += (int64_t)blockIdx.z * C;
+        shift += (int64_t)blockIdx.z * C;
+    }
     float sc[E], sh[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -215,6 +234,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     const int tx = threadIdx.x % tbx, ty = threadIdx.x / tbx;
     const int cv = blockIdx.x * tbx + tx;
     const bool active = (cv * E < C) && (ty < tby);
+    {  // view blockIdx.z
+        const int64_t vo = (int64_t)blockIdx.z * rows * C;
+        dy += vo;
+        x += vo;
+        if (y) y += vo;
+        if (dz) dz += vo;
+        if (mask) mask += (int64_t)blockIdx.z * rows * (C / E);
+        mean += (int64_t)blockIdx.z * C;
+        invstd += (int64_t)blockIdx.z * C;
+        partials += (int64_t)blockIdx.z * gridDim.y * 2 * C;
+    }
     float s1[E], s2[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) s1[e] = s2[e] = 0.f;
@@ -311,6 +341,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     const int tx = threadIdx.x % tbx, ty = threadIdx.x / tbx;
     const int cv = blockIdx.x * tbx + tx;
     if (cv * E >= C || ty >= tby) return;
+    {  // view blockIdx.z
+        const int64_t vo = (int64_t)blockIdx.z * rows * C;
+        dz += vo;
+        x += vo;
+        dx += vo;
+        mean += (int64_t)blockIdx.z * C;
+        invstd += (int64_t)blockIdx.z * C;
+        gsums += (int64_t)blockIdx.z * 2 * C;
+        if (lsums) lsums += (int64_t)blockIdx.z * 2 * C;
+    }
     // dx = g*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)) = k0*(dz - k1) - (x - mu)*q
     float mu[E], k0[E], k1[E], q[E];
 #pragma unroll
@@ -400,26 +440,26 @@ extern "C" int sm3_bn_reduce_groups(int rows) {
 }
 
 extern "C" int sm3_bn_stats_reduce(const float* partials, int rows, int C, double* sums, double* workspace,
-                                   void* stream) {
-    if (!partials || !workspace || rows <= 0 || C <= 0) return SM3_EINVAL;
+                                   int views, void* stream) {
+    if (!partials || !workspace || rows <= 0 || C <= 0 || views < 1) return SM3_EINVAL;
     const int G = sm3_bn_reduce_groups(rows);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_stats_reduce_a, dim3((2 * C + 63) / 64, G), dim3(256), 0, st, partials, rows, C, workspace);
+    hipLaunchKernelGGL(bn_stats_reduce_a, dim3((2 * C + 63) / 64, G, views), dim3(256), 0, st, partials, rows, C, workspace);
     SM3_CHECK_LAUNCH();
     if (sums) {  // sums == NULL: the caller hands workspace + groups to sm3_bn_finalize instead (one launch fewer)
-        hipLaunchKernelGGL(bn_stats_reduce_b, dim3((8 * C + 255) / 256), dim3(256), 0, st, workspace, G, C, sums);
+        hipLaunchKernelGGL(bn_stats_reduce_b, dim3((8 * C + 255) / 256, 1, views), dim3(256), 0, st, workspace, G, C, sums);
         SM3_CHECK_LAUNCH();
     }
     return 0;
 }
 
-extern "C" int sm3_bn_finalize(const double* sums, int groups, double count, int C, const float* gamma, const float* beta,
-                               float eps, float momentum, float* running_mean, float* running_var,
+extern "C" int sm3_bn_finalize(const double* sums, int groups, int views, double count, int C, const float* gamma,
+                               const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                                int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean,
                                float* save_invstd, void* stream) {
-    if (!sums || !scale || !shift || C <= 0 || count <= 0 || groups < 1) return SM3_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((4 * C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, groups, count, C,
-                       gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift,
+    if (!sums || !scale || !shift || C <= 0 || count <= 0 || groups < 1 || views < 1) return SM3_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((4 * C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, groups, views,
+                       count, C, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift,
                        save_mean, save_invstd);
     SM3_CHECK_LAUNCH();
     return 0;
@@ -436,13 +476,14 @@ extern "C" int sm3_bn_eval_scale_shift(const float* gamma, const float* beta, co
 }
 
 extern "C" int sm3_bn_act(int dtype, const void* x, const float* scale, const float* shift, const void* residual,
-                          int relu, int out_f32, void* y, uint8_t* relu_mask, int64_t rows, int C, void* stream) {
-    if (!x || !scale || !shift || !y || rows <= 0 || C <= 0) return SM3_EINVAL;
+                          int relu, int out_f32, void* y, uint8_t* relu_mask, int64_t rows, int C, int views,
+                          void* stream) {
+    if (!x || !scale || !shift || !y || rows <= 0 || C <= 0 || views < 1) return SM3_EINVAL;
     if (dtype != SM3_F32 && dtype != SM3_BF16) return SM3_EDTYPE;
     const int E = dtype == SM3_F32 ? 4 : 8;
     if (C % E) return SM3_EALIGN;
-    const RowWalk w = make_walk(rows, C / E, 8192);
-    dim3 grid(w.gx, w.gy), block(256);
+    const RowWalk w = make_walk(rows, C / E, 8192, views);
+    dim3 grid(w.gx, w.gy, views), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define SM3_ACT(U, NT)                                                                                            \
     if (dtype == SM3_F32) /* f32 storage: the two output forms coincide */                                        \
@@ -474,14 +515,14 @@ extern "C" int sm3_bn_bwd_partial_rows(int64_t rows, int C) {
 
 extern "C" int sm3_bn_bwd_reduce(int dtype, const void* dy, const void* y, const uint8_t* relu_mask, const void* x,
                                  const float* mean, const float* invstd, void* dz, int64_t rows, int C,
-                                 float* partials, void* stream) {
-    if (!dy || !x || !mean || !invstd || !partials || rows <= 0 || C <= 0) return SM3_EINVAL;
+                                 float* partials, int views, void* stream) {
+    if (!dy || !x || !mean || !invstd || !partials || rows <= 0 || C <= 0 || views < 1) return SM3_EINVAL;
     if (dtype != SM3_F32 && dtype != SM3_BF16) return SM3_EDTYPE;
     const int E = dtype == SM3_F32 ? 4 : 8;
     if (C % E) return SM3_EALIGN;
     RowWalk w = make_walk(rows, C / E, 1 << 30);
     w.gy = bwd_gy(rows);
-    dim3 grid(w.gx, w.gy), block(256);
+    dim3 grid(w.gx, w.gy, views), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define SM3_RED(U, NT)                                                                                              \
     if (dtype == SM3_F32)                                                                                           \
@@ -501,13 +542,14 @@ extern "C" int sm3_bn_bwd_reduce(int dtype, const void* dy, const void* y, const
 extern "C" int sm3_bn_bwd_apply(int dtype, const void* dz, const void* x, const float* mean, const float* invstd,
                                 const float* gamma, const double* global_sums, double count,
                                 const double* local_sums, float* dgamma, float* dbeta, void* dx, int64_t rows, int C,
-                                void* stream) {
-    if (!dz || !x || !mean || !invstd || !global_sums || !dx || rows <= 0 || C <= 0 || count <= 0) return SM3_EINVAL;
+                                int views, void* stream) {
+    if (!dz || !x || !mean || !invstd || !global_sums || !dx || rows <= 0 || C <= 0 || count <= 0 || views < 1)
+        return SM3_EINVAL;
     if (dtype != SM3_F32 && dtype != SM3_BF16) return SM3_EDTYPE;
     const int E = dtype == SM3_F32 ? 4 : 8;
     if (C % E) return SM3_EALIGN;
-    const RowWalk w = make_walk(rows, C / E, 8192);
-    dim3 grid(w.gx, w.gy), block(256);
+    const RowWalk w = make_walk(rows, C / E, 8192, views);
+    dim3 grid(w.gx, w.gy, views), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define SM3_APP(U, NT)                                                                                             \
     if (dtype == SM3_F32)                                                                                          \

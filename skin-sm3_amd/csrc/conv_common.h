@@ -29,6 +29,8 @@ struct ConvParams {
     const float* fz_invstd;
     float* fz_partials;         // [fz_row_off + tilesM][2][Co]
     int fz_row_off;
+    int fz_view_tiles;          // 0: one BatchNorm batch; else tiles (of 128 rows) per view, two views back to back
+    int fz_row_off1;            // first partial row of view 1
     // optional inference epilogue: y = relu?(acc * ep_scale[co] + ep_shift[co] (+ addend))  (eval-mode BatchNorm)
     const float* ep_scale;
     const float* ep_shift;

@@ -296,13 +296,16 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
 
     // f_mu/f_is double as the inference epilogue's per-channel scale/shift (the two modes are exclusive)
     const bool ep = p.ep_scale != nullptr;
+    // two views in one launch: a tile belongs to exactly one of them (view rows are a multiple of BM)
+    const int fz_view = (p.fz_view_tiles > 0 && bm >= p.fz_view_tiles) ? 1 : 0;
+    const int fz_prow = fz_view ? p.fz_row_off1 + bm - p.fz_view_tiles : p.fz_row_off + bm;
     float f_mu[EPC], f_is[EPC], f_s1[EPC], f_s2[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
         f_s1[e] = 0.f;
         f_s2[e] = 0.f;
-        f_mu[e] = (ncol < p.Co) ? (fz ? p.fz_mean[ncol + e] : (ep ? p.ep_shift[ncol + e] : 0.f)) : 0.f;
-        f_is[e] = (ncol < p.Co) ? (fz ? p.fz_invstd[ncol + e] : (ep ? p.ep_scale[ncol + e] : 0.f)) : 0.f;
+        f_mu[e] = (ncol < p.Co) ? (fz ? p.fz_mean[fz_view * p.Co + ncol + e] : (ep ? p.ep_shift[ncol + e] : 0.f)) : 0.f;
+        f_is[e] = (ncol < p.Co) ? (fz ? p.fz_invstd[fz_view * p.Co + ncol + e] : (ep ? p.ep_scale[ncol + e] : 0.f)) : 0.f;
     }
 
 #pragma unroll
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
             const int stat = o / BN, col = o % BN;  // channel n0+col lives in threads with cc == col/EPC
             float a = 0.f;
             for (int rl = 0; rl < NT / CPR; ++rl) a += sRed[(rl * CPR + col / EPC) * 2 * EPC + stat * EPC + col % EPC];
-            if (n0 + col < p.Co) p.fz_partials[((long)(p.fz_row_off + bm) * 2 + stat) * p.Co + n0 + col] = a;
+            if (n0 + col < p.Co) p.fz_partials[((long)fz_prow * 2 + stat) * p.Co + n0 + col] = a;
         }
     }
 }
@@ -528,11 +531,18 @@ static int conv_gather_gemm_impl(const sm3_conv_desc* d, const void* x, const vo
     p.fz_invstd = fuse ? fuse->invstd : nullptr;
     p.fz_partials = fuse ? fuse->partials : nullptr;
     p.fz_row_off = fuse ? fuse->partial_row_offset : 0;
+    p.fz_view_tiles = 0;
+    p.fz_row_off1 = 0;
+    if (fuse && fuse->views > 1) {
+        if (fuse->views != 2 || (p.M % 2) || ((p.M / 2) % kBM) || fuse->partial_row_offset_view1 < 0) return SM3_EALIGN;
+        p.fz_view_tiles = p.M / 2 / kBM;
+        p.fz_row_off1 = fuse->partial_row_offset_view1;
+    }
     p.ep_scale = ep_scale;
     p.ep_shift = ep_shift;
     p.ep_relu = ep_relu;
     hipStream_t st = (hipStream_t)stream;
-    if (conv_v2_eligible(d)) return launch_conv_v2(p, st);
+    if (conv_v2_eligible(d) && p.fz_view_tiles == 0) return launch_conv_v2(p, st);
     const bool narrow = d->Co <= 64;
     if (d->dtype == SM3_BF16)
         return narrow ? launch_conv<bf16_t, kBM, 64, 2, 2>(p, st) : launch_conv<bf16_t, kBM, 128, 2, 2>(p, st);

@@ -28,7 +28,8 @@ class ConvDesc(C.Structure):
 
 class BnBwdFuse(C.Structure):
     _fields_ = [("relu_mask", C.c_void_p), ("x", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
-                ("partials", C.c_void_p), ("partial_row_offset", C.c_int32)]
+                ("partials", C.c_void_p), ("partial_row_offset", C.c_int32), ("views", C.c_int32),
+                ("partial_row_offset_view1", C.c_int32)]
 
 
 class WPrepItem(C.Structure):
@@ -48,14 +49,14 @@ SIGNATURES = {
     "sm3_conv_dgrad_bnfuse": [_DESC, _P, _P, _P, _P, _P, _P],
     "sm3_conv_bn_act_eval": [_DESC, _P, _P, _P, _P, _P, _I, _P, _P],
     "sm3_conv_wgrad": [_DESC, _P, _P, _P, _P],
-    "sm3_bn_stats_reduce": [_P, _I, _I, _P, _P, _P],
+    "sm3_bn_stats_reduce": [_P, _I, _I, _P, _P, _I, _P],
     "sm3_bn_reduce_groups": [_I],
-    "sm3_bn_finalize": [_P, _I, _D, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
+    "sm3_bn_finalize": [_P, _I, _I, _D, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
     "sm3_bn_eval_scale_shift": [_P, _P, _P, _P, _F, _I, _P, _P, _P],
-    "sm3_bn_act": [_I, _P, _P, _P, _P, _I, _I, _P, _P, _L, _I, _P],
+    "sm3_bn_act": [_I, _P, _P, _P, _P, _I, _I, _P, _P, _L, _I, _I, _P],
     "sm3_bn_bwd_partial_rows": [_L, _I],
-    "sm3_bn_bwd_reduce": [_I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P],
-    "sm3_bn_bwd_apply": [_I, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _P, _L, _I, _P],
+    "sm3_bn_bwd_reduce": [_I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _I, _P],
+    "sm3_bn_bwd_apply": [_I, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _P, _L, _I, _I, _P],
     "sm3_stem_im2col": [_I, _P, _P, _I, _I, _I, _I, _P],
     "sm3_maxpool3x3s2_fwd": [_I, _P, _P, _P, _I, _I, _I, _I, _P],
     "sm3_maxpool3x3s2_bwd": [_I, _P, _P, _P, _I, _I, _I, _I, _P],

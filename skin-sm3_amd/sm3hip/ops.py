@@ -189,9 +189,12 @@ def conv_gemm(desc, x, w, y, addend=None, partials=None):
                                                _ptr(partials), _stream()), "sm3_conv_gather_gemm")
 
 
-def conv_dgrad_bnfuse(desc, dy_in, w_dgrad, dz_out, addend, mask, bn_x, mean, invstd, partials, row_offset):
+def conv_dgrad_bnfuse(desc, dy_in, w_dgrad, dz_out, addend, mask, bn_x, mean, invstd, partials, row_offset,
+                      views=1, row_offset_view1=0):
     """Data-gradient launch that also masks with the producer BN's ReLU bits and emits its backward partial sums
-    (see sm3_conv_dgrad_bnfuse).  Returns the number of partial rows this launch wrote."""
+    (see sm3_conv_dgrad_bnfuse).  Returns the number of partial rows this launch wrote (both views together).
+    views=2: the launch's rows are two views back to back (each a multiple of 128 rows), mean/invstd are [2][C],
+    view 0's tiles write partial rows from row_offset, view 1's from row_offset_view1."""
     tdt = TORCH_DTYPE[desc.dtype]
     _chk(dy_in, tdt, "dy_in"); _chk(w_dgrad, tdt, "w"); _chk(dz_out, tdt, "dz_out"); _chk(addend, tdt, "addend")
     _chk(bn_x, tdt, "bn_x"); _chk(mask, torch.uint8, "mask"); _chk(mean, torch.float32); _chk(invstd, torch.float32)
@@ -203,17 +206,24 @@ def conv_dgrad_bnfuse(desc, dy_in, w_dgrad, dz_out, addend, mask, bn_x, mean, in
         raise ValueError("dz_out / bn_x / addend size does not match descriptor")
     if mask is not None and mask.numel() != n_out // (16 // _sz(desc.dtype)):
         raise ValueError("mask size mismatch")
-    if mean.numel() < desc.Co or invstd.numel() < desc.Co:
+    if mean.numel() < views * desc.Co or invstd.numel() < views * desc.Co:
         raise ValueError("mean/invstd too small")
     prow = conv_partial_rows(desc)
-    if partials.numel() < (row_offset + prow) * 2 * desc.Co:
-        raise ValueError("partials workspace too small")
+    if views == 1:
+        if partials.numel() < (row_offset + prow) * 2 * desc.Co:
+            raise ValueError("partials workspace too small")
+    else:
+        if views != 2 or (desc.N * desc.Ho * desc.Wo) % 256 or prow % 2:
+            raise ValueError("two views need a multiple of 128 rows each")
+        if partials.numel() < (max(row_offset, row_offset_view1) + prow // 2) * 2 * desc.Co:
+            raise ValueError("partials workspace too small")
     if desc.Ci % K_CHUNK[desc.dtype]:
         raise ValueError(f"Ci={desc.Ci} is not a multiple of {K_CHUNK[desc.dtype]}")
     f = _lib.BnBwdFuse()
     f.relu_mask = mask.data_ptr() if mask is not None else None
     f.x, f.mean, f.invstd, f.partials = bn_x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), partials.data_ptr()
     f.partial_row_offset = row_offset
+    f.views, f.partial_row_offset_view1 = views, row_offset_view1
     M = desc.N * desc.Ho * desc.Wo
     sz = _sz(desc.dtype)
     tag = "conv_gemm_128x64" if desc.Co <= 64 else "conv_gemm_128x128"
@@ -274,13 +284,13 @@ BN_REDUCE_GROUPS = 64
 _bn_ws = {}
 
 
-def _bn_workspace(device, Cn):
+def _bn_workspace(device, Cn, views=1):
     """fp64 scratch of the two-stage statistics reduction (stream-ordered reuse: one per device AND stream)."""
     device = (device, _stream_handle() if device.type == "cuda" else 0)
     t = _bn_ws.get(device)
-    need = BN_REDUCE_GROUPS * 2 * Cn
+    need = views * BN_REDUCE_GROUPS * 2 * Cn
     if t is None or t.numel() < need:
-        t = torch.empty(max(need, BN_REDUCE_GROUPS * 2 * 2048), dtype=torch.float64, device=device[0])
+        t = torch.empty(max(need, 2 * BN_REDUCE_GROUPS * 2 * 2048), dtype=torch.float64, device=device[0])
         _bn_ws[device] = t
     return t
 
@@ -289,32 +299,37 @@ def bn_reduce_groups(rows):
     return min(BN_REDUCE_GROUPS, (rows + 31) // 32)
 
 
-def bn_stats_reduce(partials, rows, Cn, sums):
-    """sums: fp64 [2C] output, or None to run stage A only -- then returns (workspace, groups) for bn_finalize."""
+def bn_stats_reduce(partials, rows, Cn, sums, views=1):
+    """sums: fp64 [views][2C] output, or None to run stage A only -- then returns (workspace, groups) for bn_finalize.
+    rows: partial rows of ONE view; partials holds `views` such blocks back to back."""
     _chk(partials, torch.float32, "partials"); _chk(sums, torch.float64, "sums")
-    if partials.numel() < rows * 2 * Cn or (sums is not None and sums.numel() < 2 * Cn):
+    if partials.numel() < views * rows * 2 * Cn or (sums is not None and sums.numel() < views * 2 * Cn):
         raise ValueError("bn_stats_reduce: buffer too small")
-    ws = _bn_workspace(partials.device, Cn)
-    with _prof("bn_stats_reduce", 0.0, 4.0 * rows * 2 * Cn):
-        check(_lib.load().sm3_bn_stats_reduce(_ptr(partials), rows, Cn, _ptr(sums), _ptr(ws), _stream()),
+    ws = _bn_workspace(partials.device, Cn, views)
+    with _prof("bn_stats_reduce", 0.0, 4.0 * views * rows * 2 * Cn):
+        check(_lib.load().sm3_bn_stats_reduce(_ptr(partials), rows, Cn, _ptr(sums), _ptr(ws), views, _stream()),
               "sm3_bn_stats_reduce")
     return ws, bn_reduce_groups(rows)
 
 
 def bn_finalize(sums, count, Cn, gamma, beta, eps, momentum, running_mean, running_var, nbt, scale, shift,
-                save_mean, save_invstd, groups=1):
-    for t, n in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var"),
-                 (scale, "scale"), (shift, "shift"), (save_mean, "save_mean"), (save_invstd, "save_invstd")):
+                save_mean, save_invstd, groups=1, views=1):
+    """count: elements per channel of ONE view; scale / shift / save_mean / save_invstd: [views][C]."""
+    for t, n in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
         _chk(t, torch.float32, n)
         if t is not None and t.numel() < Cn:
             raise ValueError(f"{n} too small")
+    for t, n in ((scale, "scale"), (shift, "shift"), (save_mean, "save_mean"), (save_invstd, "save_invstd")):
+        _chk(t, torch.float32, n)
+        if t is not None and t.numel() < views * Cn:
+            raise ValueError(f"{n} too small")
     _chk(sums, torch.float64, "sums"); _chk(nbt, torch.int64, "num_batches_tracked")
-    if sums.numel() < groups * 2 * Cn:
+    if sums.numel() < views * groups * 2 * Cn:
         raise ValueError("bn_finalize: sums too small for groups")
     with _prof("bn_finalize", 0.0, 40.0 * Cn):
-        check(_lib.load().sm3_bn_finalize(_ptr(sums), groups, float(count), Cn, _ptr(gamma), _ptr(beta), eps, momentum,
-                                          _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(scale), _ptr(shift),
-                                          _ptr(save_mean), _ptr(save_invstd), _stream()), "sm3_bn_finalize")
+        check(_lib.load().sm3_bn_finalize(_ptr(sums), groups, views, float(count), Cn, _ptr(gamma), _ptr(beta), eps,
+                                          momentum, _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(scale),
+                                          _ptr(shift), _ptr(save_mean), _ptr(save_invstd), _stream()), "sm3_bn_finalize")
 
 
 def bn_eval_scale_shift(gamma, beta, running_mean, running_var, eps, Cn, scale, shift):
@@ -324,62 +339,71 @@ def bn_eval_scale_shift(gamma, beta, running_mean, running_var, eps, Cn, scale, 
                                               Cn, _ptr(scale), _ptr(shift), _stream()), "sm3_bn_eval_scale_shift")
 
 
-def bn_act(dtype, x, scale, shift, residual, relu, y, rows, Cn, out_f32=False, mask=None):
+def bn_act(dtype, x, scale, shift, residual, relu, y, rows, Cn, out_f32=False, mask=None, views=1):
+    """rows: rows of ONE view; tensors hold `views` row ranges back to back, scale/shift are [views][C]."""
     tdt = TORCH_DTYPE[dtype]
     _chk(x, tdt, "x"); _chk(residual, tdt, "residual"); _chk(scale, torch.float32); _chk(shift, torch.float32)
     _chk(y, torch.float32 if out_f32 else tdt, "y")
-    if x.numel() != rows * Cn or y.numel() != rows * Cn or (residual is not None and residual.numel() != rows * Cn):
+    n = views * rows * Cn
+    if x.numel() != n or y.numel() != n or (residual is not None and residual.numel() != n):
         raise ValueError("bn_act: size mismatch")
+    if scale.numel() < views * Cn or shift.numel() < views * Cn:
+        raise ValueError("bn_act: scale/shift too small")
     _chk(mask, torch.uint8, "mask")
-    if mask is not None and mask.numel() != rows * Cn // (16 // _sz(dtype)):
+    if mask is not None and mask.numel() != n // (16 // _sz(dtype)):
         raise ValueError("bn_act: mask size mismatch")
-    n = rows * Cn
     tag = "bn_act"
     if _PROFILER is not None and getattr(_PROFILER, "detail", False):
-        tag += f"|rows{rows}_C{Cn}_res{int(residual is not None)}"
+        tag += f"|rows{views * rows}_C{Cn}_res{int(residual is not None)}"
     with _prof(tag, 0.0, _sz(dtype) * n * (2 if residual is None else 3)):
         check(_lib.load().sm3_bn_act(dtype, _ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), int(relu),
-                                     int(out_f32), _ptr(y), _ptr(mask), rows, Cn, _stream()), "sm3_bn_act")
+                                     int(out_f32), _ptr(y), _ptr(mask), rows, Cn, views, _stream()), "sm3_bn_act")
 
 
 def bn_bwd_partial_rows(rows, Cn):
     return _lib.load().sm3_bn_bwd_partial_rows(rows, Cn)
 
 
-def bn_bwd_reduce(dtype, dy, y, x, mean, invstd, dz, rows, Cn, partials, mask=None):
+def bn_bwd_reduce(dtype, dy, y, x, mean, invstd, dz, rows, Cn, partials, mask=None, views=1):
+    """rows: rows of ONE view; partials: [views][bn_bwd_partial_rows(rows)][2][C]; mean/invstd: [views][C]."""
     tdt = TORCH_DTYPE[dtype]
-    for t, n in ((dy, "dy"), (y, "y"), (x, "x"), (dz, "dz")):
-        _chk(t, tdt, n)
-        if t is not None and t.numel() != rows * Cn:
-            raise ValueError(f"bn_bwd_reduce: {n} size mismatch")
+    n = views * rows * Cn
+    for t, nm in ((dy, "dy"), (y, "y"), (x, "x"), (dz, "dz")):
+        _chk(t, tdt, nm)
+        if t is not None and t.numel() != n:
+            raise ValueError(f"bn_bwd_reduce: {nm} size mismatch")
     _chk(partials, torch.float32)
-    if partials.numel() < bn_bwd_partial_rows(rows, Cn) * 2 * Cn:
+    if partials.numel() < views * bn_bwd_partial_rows(rows, Cn) * 2 * Cn:
         raise ValueError("bn_bwd_reduce: partials too small")
+    if mean.numel() < views * Cn or invstd.numel() < views * Cn:
+        raise ValueError("bn_bwd_reduce: mean/invstd too small")
     _chk(mask, torch.uint8, "mask")
-    if mask is not None and mask.numel() != rows * Cn // (16 // _sz(dtype)):
+    if mask is not None and mask.numel() != n // (16 // _sz(dtype)):
         raise ValueError("bn_bwd_reduce: mask size mismatch")
-    n = rows * Cn
     reads = 2 + (1 if (y is not None and mask is None) else 0) + (1 if dz is not None else 0)
     with _prof("bn_bwd_reduce", 0.0, _sz(dtype) * n * reads + (n // 8 if mask is not None else 0)):
         check(_lib.load().sm3_bn_bwd_reduce(dtype, _ptr(dy), _ptr(y), _ptr(mask), _ptr(x), _ptr(mean), _ptr(invstd),
-                                            _ptr(dz), rows, Cn, _ptr(partials), _stream()), "sm3_bn_bwd_reduce")
+                                            _ptr(dz), rows, Cn, _ptr(partials), views, _stream()), "sm3_bn_bwd_reduce")
 
 
-def bn_bwd_apply(dtype, dz, x, mean, invstd, gamma, gsums, count, lsums, dgamma, dbeta, dx, rows, Cn):
+def bn_bwd_apply(dtype, dz, x, mean, invstd, gamma, gsums, count, lsums, dgamma, dbeta, dx, rows, Cn, views=1):
+    """rows / count: of ONE view; gsums / lsums: [views][2C]; mean / invstd: [views][C]."""
     tdt = TORCH_DTYPE[dtype]
     for t, n in ((dz, "dz"), (x, "x"), (dx, "dx")):
         _chk(t, tdt, n)
-        if t.numel() != rows * Cn:
+        if t.numel() != views * rows * Cn:
             raise ValueError(f"bn_bwd_apply: {n} size mismatch")
     _chk(gsums, torch.float64); _chk(lsums, torch.float64)
     _chk(dgamma, torch.float32); _chk(dbeta, torch.float32); _chk(gamma, torch.float32)
+    if gsums.numel() < views * 2 * Cn or (lsums is not None and lsums.numel() < views * 2 * Cn):
+        raise ValueError("bn_bwd_apply: sums too small")
     tag = "bn_bwd_apply"
     if _PROFILER is not None and getattr(_PROFILER, "detail", False):
-        tag += f"|rows{rows}_C{Cn}"
-    with _prof(tag, 0.0, _sz(dtype) * rows * Cn * 3):
+        tag += f"|rows{views * rows}_C{Cn}"
+    with _prof(tag, 0.0, _sz(dtype) * views * rows * Cn * 3):
         check(_lib.load().sm3_bn_bwd_apply(dtype, _ptr(dz), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma),
                                            _ptr(gsums), float(count), _ptr(lsums), _ptr(dgamma), _ptr(dbeta), _ptr(dx),
-                                           rows, Cn, _stream()), "sm3_bn_bwd_apply")
+                                           rows, Cn, views, _stream()), "sm3_bn_bwd_apply")
 
 
 # ------------------------------------------------------------------------------------------

@@ -19,7 +19,7 @@ class _FakeFn:
         if self.name == "sm3_bn_bwd_partial_rows":
             return max(1, min(1024, (int(args[0]) + 63) // 64))
         if self.name == "sm3_abi_version":
-            return 1
+            return 2
         return 0
 
 

@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_symbol():
     lib = _lib.load()
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.sm3_abi_version() == 1
+    assert lib.sm3_abi_version() == 2
 
 
 def test_arg_rejection_launches_nothing():
@@ -37,7 +37,7 @@ def test_arg_rejection_launches_nothing():
     lib = _lib.load()
     d = _lib.ConvDesc()
     assert lib.sm3_conv_gather_gemm(C.byref(d), None, None, None, None, None, None) == -1
-    assert lib.sm3_bn_act(7, None, None, None, None, 0, 0, None, None, 0, 0, None) == -1
+    assert lib.sm3_bn_act(7, None, None, None, None, 0, 0, None, None, 0, 0, 1, None) == -1
     assert lib.sm3_adamw(None, None, None, None, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 1, 1.0, None, None) == -1
 
 

@@ -426,3 +426,119 @@ def test_adamw_matches_torch():
     ops.adamw(pd, bad.to(D), md, vd, 1e-3, 0.9, 0.999, 1e-5, 5e-2, 4, 1.0, found)
     torch.cuda.synchronize()
     assert int(found) == 1 and torch.equal(before, pd)
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+def test_bn_two_views_in_one_launch_equal_two_launches(dt):
+    """`views=2` (two row ranges back to back, per-view statistics / parameters) must give bit for bit what two
+    `views=1` calls give, running statistics updated view 0 first."""
+    ops = _ops()
+    code = ops.dtype_code(dt)
+    D = dev()
+    E = 4 if dt == torch.float32 else 8
+    rows, Cn, nblk = 384, 256, 3
+    g = torch.Generator().manual_seed(21)
+    x = torch.cat([torch.randn(rows, Cn, generator=g) * 1.5 + 0.3, torch.randn(rows, Cn, generator=g) * 0.7 - 1.0])
+    xd = x.to(dt).to(D)
+    res = torch.randn(2 * rows, Cn, generator=g).to(dt).to(D)
+    partials = torch.zeros(2 * nblk, 2, Cn)
+    xr = xd.float().cpu().double()
+    for b in range(2 * nblk):
+        blk = xr[b * 128:(b + 1) * 128]
+        partials[b, 0], partials[b, 1] = blk.sum(0).float(), (blk * blk).sum(0).float()
+    partials = partials.to(D)
+    gamma, beta = (torch.rand(Cn, generator=g) + 0.5).to(D), torch.randn(Cn, generator=g).to(D)
+    out = {}
+    for mode in ("two_launches", "one_launch"):
+        rm, rv = torch.zeros(Cn, device=D), torch.ones(Cn, device=D)
+        nbt = torch.zeros((), dtype=torch.int64, device=D)
+        scale, shift = torch.empty(2, Cn, device=D), torch.empty(2, Cn, device=D)
+        mean, invstd = torch.empty(2, Cn, device=D), torch.empty(2, Cn, device=D)
+        y = torch.empty(2 * rows, Cn, dtype=dt, device=D)
+        mask = torch.empty(2 * rows * Cn // E, dtype=torch.uint8, device=D)
+        if mode == "one_launch":
+            ws, groups = ops.bn_stats_reduce(partials, nblk, Cn, None, views=2)
+            ops.bn_finalize(ws, rows, Cn, gamma, beta, 1e-5, 0.1, rm, rv, nbt, scale, shift, mean, invstd, groups=groups, views=2)
+            ops.bn_act(code, xd, scale, shift, res, True, y, rows, Cn, mask=mask, views=2)
+        else:
+            for v in range(2):
+                ws, groups = ops.bn_stats_reduce(partials[v * nblk:(v + 1) * nblk], nblk, Cn, None)
+                ops.bn_finalize(ws, rows, Cn, gamma, beta, 1e-5, 0.1, rm, rv, nbt, scale[v], shift[v], mean[v], invstd[v], groups=groups)
+                sl, ms = slice(v * rows, (v + 1) * rows), slice(v * rows * Cn // E, (v + 1) * rows * Cn // E)
+                ops.bn_act(code, xd[sl], scale[v], shift[v], res[sl], True, y[sl], rows, Cn, mask=mask[ms])
+        # backward
+        dy = torch.randn(2 * rows, Cn, generator=torch.Generator().manual_seed(5)).to(dt).to(D)
+        prow = ops.bn_bwd_partial_rows(rows, Cn)
+        bpart = torch.empty(2 * prow, 2, Cn, device=D)
+        lsums = torch.empty(2, 2 * Cn, dtype=torch.float64, device=D)
+        dx = torch.empty(2 * rows, Cn, dtype=dt, device=D)
+        dgamma, dbeta = torch.zeros(Cn, device=D), torch.zeros(Cn, device=D)
+        if mode == "one_launch":
+            ops.bn_bwd_reduce(code, dy, None, xd, mean, invstd, dy, rows, Cn, bpart, mask=mask, views=2)
+            ops.bn_stats_reduce(bpart, prow, Cn, lsums, views=2)
+            ops.bn_bwd_apply(code, dy, xd, mean, invstd, gamma, lsums, rows, lsums, dgamma, dbeta, dx, rows, Cn, views=2)
+        else:
+            for v in range(2):
+                sl, ms = slice(v * rows, (v + 1) * rows), slice(v * rows * Cn // E, (v + 1) * rows * Cn // E)
+                bp = bpart[v * prow:(v + 1) * prow]
+                ops.bn_bwd_reduce(code, dy[sl], None, xd[sl], mean[v], invstd[v], dy[sl], rows, Cn, bp, mask=mask[ms])
+                ops.bn_stats_reduce(bp, prow, Cn, lsums[v])
+                ops.bn_bwd_apply(code, dy[sl], xd[sl], mean[v], invstd[v], gamma, lsums[v], rows, lsums[v], dgamma, dbeta, dx[sl], rows, Cn)
+        torch.cuda.synchronize()
+        out[mode] = [t.clone() for t in (scale, shift, mean, invstd, rm, rv, nbt, y, mask, dy, lsums, dx)]
+        out[mode + "_dg"] = (dgamma.clone(), dbeta.clone())
+    for a, b in zip(out["one_launch"], out["two_launches"]):
+        assert torch.equal(a, b)
+    assert int(out["one_launch"][6]) == 2
+    for a, b in zip(out["one_launch_dg"], out["two_launches_dg"]):  # float atomics of two views: order may differ
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-4)
+    assert not torch.equal(out["one_launch"][0][0], out["one_launch"][0][1])  # the views really differ
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", [(16, 256, 128, 8, 8, 1, 1, 0), (8, 64, 64, 16, 16, 3, 1, 1), (16, 128, 128, 8, 8, 3, 2, 1)])
+def test_fused_dgrad_two_views_equal_two_launches(case, dt):
+    """sm3_conv_dgrad_bnfuse over a batch that holds two views (per-view BN mean/invstd, per-view partial rows)
+    against one launch per view."""
+    ops = _ops()
+    N, Ci, Co, H, W, k, s, p = case   # forward conv Ci -> Co on N images = 2 views of N/2
+    code = ops.dtype_code(dt)
+    E = 4 if dt == torch.float32 else 8
+    g = torch.Generator().manual_seed(sum(case) + 3)
+    D = dev()
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dy = torch.randn(N, Ho, Wo, Co, generator=g).to(dt).to(D)
+    w_dg = (torch.randn(Ci, k * k, Co, generator=g) / math.sqrt(Co * k * k)).to(dt).to(D)
+    addend = torch.randn(N, H, W, Ci, generator=g).to(dt).to(D)
+    rows = N * H * W
+    bn_x = torch.randn(rows, Ci, generator=g).to(dt).to(D)
+    mask = torch.randint(0, 256, (rows * Ci // E,), generator=g, dtype=torch.uint8).to(D)
+    if E == 4:
+        mask &= 0x0F
+    mean, invstd = torch.randn(2, Ci, generator=g).to(D), (torch.rand(2, Ci, generator=g) + 0.5).to(D)
+    # one launch per class over both views
+    descs, full = ops.dgrad_descs(code, N, H, W, Ci, Co, k, s, p)
+    assert full
+    half = sum(ops.conv_partial_rows(dd) for dd in descs) // 2
+    out2 = torch.empty(rows, Ci, dtype=dt, device=D)
+    part2 = torch.full((2 * half, 2, Ci), float("nan"), device=D)
+    off = 0
+    for dd in descs:
+        n = ops.conv_dgrad_bnfuse(dd, dy, w_dg, out2, addend, mask, bn_x, mean, invstd, part2, off, views=2,
+                                  row_offset_view1=half + off)
+        off += n // 2
+    assert off == half
+    # reference: each view on its own
+    descs1, _ = ops.dgrad_descs(code, N // 2, H, W, Ci, Co, k, s, p)
+    out1 = torch.empty(rows, Ci, dtype=dt, device=D)
+    part1 = torch.full((2 * half, 2, Ci), float("nan"), device=D)
+    for v in range(2):
+        hs = slice(v * rows // 2, (v + 1) * rows // 2)
+        off = v * half
+        for dd in descs1:
+            off += ops.conv_dgrad_bnfuse(dd, dy[v * N // 2:(v + 1) * N // 2], w_dg, out1[hs], addend[v * N // 2:(v + 1) * N // 2],
+                                         mask[v * rows * Ci // E // 2:(v + 1) * rows * Ci // E // 2], bn_x[hs], mean[v], invstd[v],
+                                         part1, off)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out1)
+    assert torch.equal(part2, part1)
