@@ -154,7 +154,7 @@ class BNUnit:
 
 class Rec:
     """What one conv+BN(+act) application saves for backward."""
-    __slots__ = ("cu", "bu", "N", "H", "W", "Ho", "Wo", "x_in", "xo", "mean", "invstd", "y", "relu", "mask")
+    __slots__ = ("cu", "bu", "N", "H", "W", "Ho", "Wo", "x_in", "xo", "mean", "invstd", "y", "relu", "mask", "V")
 
 
 class EncoderPlan:
@@ -255,6 +255,12 @@ class SM3Engine:
         self._allocated = False
         self._lane = "main"
         self._view = 0
+        self._V = 1  # views in the batch of the encoder pass being enqueued (1, or 2 back to back)
+        # Both views of a branch through the encoder as ONE batch of 2B images -- half the convolution /
+        # weight-gradient / BatchNorm launches, longer K loops per weight-gradient workgroup, one SyncBN statistics
+        # all-reduce per BatchNorm for both views -- with BatchNorm statistics still per view (simclr.py:58-59).
+        # Needs every feature map of a view to be a multiple of 128 rows (B a multiple of 128 at 224x224).
+        self.pair_views = _os.environ.get("SM3_PAIR_VIEWS", "1") != "0"
         # the two views of a branch on two more streams (BN running statistics stay ordered through events): correct
         # (GPU test suite passes with it on) but measured slower -- 2 700 vs 2 780 pairs/s -- so off: two lanes
         # already keep HBM and MFMA busy, four only add contention
@@ -386,38 +392,45 @@ class SM3Engine:
 
     # ---- conv + BN (+residual) (+ReLU) ---------------------------------------------------
     def conv_bn(self, cu, bu, x, N, H, W, relu, residual=None, train=True, save=None, out_f32=False, y_out=None):
+        """One conv + BatchNorm (+residual) (+ReLU) unit on N images.  With self._V == 2 the batch is two views back
+        to back (N = 2B): one convolution launch, BatchNorm statistics / running-statistics updates per view."""
         dev = x.device
         d = cu.fwd_desc(self.dtype, N, H, W)
         Ho, Wo = (1, 1) if cu.stem else (d.Ho, d.Wo)
         rows = N if cu.stem else N * Ho * Wo
         C = cu.Co
+        V = self._V if train else 1
+        rows_v = rows // V
         xo = torch.empty(rows, C, dtype=self.tdt, device=dev)
-        scale, shift = self._work("scale", 2048), self._work("shift", 2048)
+        scale, shift = self._work("scale", 2 * 2048), self._work("shift", 2 * 2048)
         gamma = self._p(bu.name + ".weight") if bu.affine else None
         beta = self._p(bu.name + ".bias") if bu.affine else None
         rm, rv = self.buffers[bu.name + ".running_mean"], self.buffers[bu.name + ".running_var"]
         mean = invstd = None
         if train:
             prow = ops.conv_partial_rows(d)
+            if V > 1 and (rows_v % 128 or prow % V):
+                raise ValueError("two views in one batch need a multiple of 128 rows per view")
             partials = self._work("partials", prow * 2 * C)
             ops.conv_gemm(d, x, cu.w_fwd, xo, None, partials)
-            count, groups = rows, 1
+            count, groups = rows_v, 1
             if self.stat_sync is not None:
-                sums = self._work("sums", 2 * 2048, torch.float64)
-                ops.bn_stats_reduce(partials, prow, C, sums)
-                self.stat_sync(sums[: 2 * C])
-                count = rows * self.world_size
+                sums = self._work("sums", 2 * 2 * 2048, torch.float64)
+                ops.bn_stats_reduce(partials, prow // V, C, sums, views=V)
+                self.stat_sync(sums[: V * 2 * C])  # one all-reduce for both views
+                count = rows_v * self.world_size
             else:  # single rank: stage B of the reduction is folded into bn_finalize (one launch fewer per BN)
-                sums, groups = ops.bn_stats_reduce(partials, prow, C, None)
-            mean = torch.empty(C, dtype=torch.float32, device=dev)
-            invstd = torch.empty(C, dtype=torch.float32, device=dev)
+                sums, groups = ops.bn_stats_reduce(partials, prow // V, C, None, views=V)
+            mean = torch.empty(V * C, dtype=torch.float32, device=dev)
+            invstd = torch.empty(V * C, dtype=torch.float32, device=dev)
             ordered = self._ordered_bn and dev.type == "cuda"
             if ordered and self._view == 1:
                 # running_mean/var/num_batches_tracked are updated view 0 first, then view 1, as in the reference's
                 # sequential encoder(x1); encoder(x2): the view-1 lane waits for view 0's update of THIS BatchNorm
                 torch.cuda.current_stream().wait_event(self._bn_ev[bu.name])
             ops.bn_finalize(sums, count, C, gamma, beta, BN_EPS, BN_MOMENTUM, rm, rv,
-                            self.buffers[bu.name + ".num_batches_tracked"], scale, shift, mean, invstd, groups=groups)
+                            self.buffers[bu.name + ".num_batches_tracked"], scale, shift, mean, invstd, groups=groups,
+                            views=V)
             if ordered and self._view == 0:
                 ev = self._bn_ev.get(bu.name)
                 if ev is None:
@@ -438,11 +451,12 @@ class SM3Engine:
         mask = None
         if save is not None and relu:  # 1 bit per element of (y > 0): what backward needs instead of re-reading y
             mask = torch.empty(rows * C // (16 // ops._sz(self.dtype)), dtype=torch.uint8, device=dev)
-        ops.bn_act(self.dtype, xo, scale, shift, residual, relu, y_out, rows, C, out_f32=out_f32, mask=mask)
+        ops.bn_act(self.dtype, xo, scale, shift, residual, relu, y_out, rows_v, C, out_f32=out_f32, mask=mask, views=V)
         if save is not None:
             r = Rec()
             r.cu, r.bu, r.N, r.H, r.W, r.Ho, r.Wo = cu, bu, N, H, W, Ho, Wo
             r.x_in, r.xo, r.mean, r.invstd, r.y, r.relu, r.mask = x, xo, mean, invstd, y_out, relu, mask
+            r.V = V
             save.append(r)
         return y_out, Ho, Wo
 
@@ -452,28 +466,29 @@ class SM3Engine:
         data-gradient launch that already masked it and left `fused_rows` rows of partial sums in the
         "fz_partials" workspace (conv_backward(..., fuse=r)): phase 1 is skipped."""
         C = r.cu.Co
-        rows = r.xo.shape[0]
+        V = r.V
+        rows = r.xo.shape[0] // V  # per view
         if fused_rows is None:
             prow = ops.bn_bwd_partial_rows(rows, C)
-            bpart = self._work("partials", prow * 2 * C)
+            bpart = self._work("partials", V * prow * 2 * C)
             ops.bn_bwd_reduce(self.dtype, dy, None, r.xo, r.mean, r.invstd, dy if r.relu else None, rows, C, bpart,
-                              mask=r.mask if r.relu else None)
-        else:
+                              mask=r.mask if r.relu else None, views=V)
+        else:  # [V][fused_rows][2][C], left by the data-gradient launches
             prow, bpart = fused_rows, self._ws[(self._lane, "fz_partials")]
-        lsums = self._work("lsums", 2 * 2048, torch.float64)
-        ops.bn_stats_reduce(bpart, prow, C, lsums)
+        lsums = self._work("lsums", 2 * 2 * 2048, torch.float64)
+        ops.bn_stats_reduce(bpart, prow, C, lsums, views=V)
         gsums, count = lsums, rows
         if self.stat_sync is not None:
-            gsums = self._work("gsums", 2 * 2048, torch.float64)
-            gsums[: 2 * C].copy_(lsums[: 2 * C])
-            self.stat_sync(gsums[: 2 * C])
+            gsums = self._work("gsums", 2 * 2 * 2048, torch.float64)
+            gsums[: V * 2 * C].copy_(lsums[: V * 2 * C])
+            self.stat_sync(gsums[: V * 2 * C])
             count = rows * self.world_size
         dxo = torch.empty_like(r.xo) if (keep_dz or _APPLY_OUT_OF_PLACE) else dy
         gamma = self._p(r.bu.name + ".weight") if r.bu.affine else None
         dgamma = self._g(r.bu.name + ".weight") if r.bu.affine else None
         dbeta = self._g(r.bu.name + ".bias") if r.bu.affine else None
         ops.bn_bwd_apply(self.dtype, dy, r.xo, r.mean, r.invstd, gamma, gsums, count, lsums, dgamma, dbeta, dxo,
-                         rows, C)
+                         rows, C, views=V)
         return dxo, dy
 
     def _wgrad(self, cu, r, dxo):
@@ -523,13 +538,18 @@ class SM3Engine:
             return into, None
         if full:
             dx = torch.empty(r.N * r.H * r.W, cu.Ci, dtype=self.tdt, device=dxo.device)
-            if fuse is not None and self.fuse_bn_bwd:
+            V = fuse.V if fuse is not None else 1
+            if fuse is not None and self.fuse_bn_bwd and (
+                    V == 1 or all((dd.N * dd.Ho * dd.Wo) % 256 == 0 for dd in descs)):
                 total = sum(ops.conv_partial_rows(dd) for dd in descs)
-                part = self._work("fz_partials", total * 2 * cu.Ci)
+                part = self._work("fz_partials", total * 2 * cu.Ci)  # [V][total / V][2][Ci]
+                per_view = total // V
                 off = 0
                 for dd in descs:
-                    off += ops.conv_dgrad_bnfuse(dd, dxo, cu.w_dgrad, dx, addend, fuse.mask if fuse.relu else None,
-                                                 fuse.xo, fuse.mean, fuse.invstd, part, off)
+                    n = ops.conv_dgrad_bnfuse(dd, dxo, cu.w_dgrad, dx, addend, fuse.mask if fuse.relu else None,
+                                              fuse.xo, fuse.mean, fuse.invstd, part, off, views=V,
+                                              row_offset_view1=per_view + off)
+                    off += n // V
                 return dx, off
             for dd in descs:
                 ops.conv_gemm(dd, dxo, cu.w_dgrad, dx, addend, None)
@@ -541,11 +561,31 @@ class SM3Engine:
         return dx, None
 
     # ---- encoder -------------------------------------------------------------------------
-    def encoder_forward(self, plan, x, train, feat_f32, feat_t, save=None):
+    @staticmethod
+    def pair_ok(n_view, H, W):
+        """Two views can share a batch when every feature map of one view is a multiple of 128 rows (the row tile of
+        the convolution kernels: a tile, its BatchNorm partial row and its fused BN-backward statistics then belong
+        to exactly one view).  The smallest map is the last stage's, (H/32) x (W/32) per image."""
+        h, w = H, W
+        for _ in range(5):  # stem, maxpool, layer2..4 halve the map
+            h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+            if (n_view * h * w) % 128:
+                return False
+        return True
+
+    def encoder_forward(self, plan, x, train, feat_f32, feat_t, save=None, views=1):
         """x: NCHW fp32 [N,3,H,W] (as the loader delivers it, tools/backbone_train.py:89-92).
-        Writes the pooled features into feat_f32 [N,2048] (fp32) and feat_t (dtype copy, optional)."""
+        Writes the pooled features into feat_f32 [N,2048] (fp32) and feat_t (dtype copy, optional).
+        views=2: x holds two views back to back (N = 2B), BatchNorm statistics per view."""
         if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
             raise ValueError("encoder input must be NCHW float32 with 3 channels")
+        self._V = views if train else 1
+        try:
+            self._encoder_forward(plan, x, train, feat_f32, feat_t, save)
+        finally:
+            self._V = 1
+
+    def _encoder_forward(self, plan, x, train, feat_f32, feat_t, save):
         x = x.contiguous()
         N, _, H, W = x.shape
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
@@ -573,7 +613,7 @@ class SM3Engine:
         ops.avgpool_fwd(self.dtype, cur, feat_f32, feat_t, N, h * w, plan.out_dim)
         if save is not None:
             save.append({"plan": plan, "stem": recs[0], "stem_hw": (Ho, Wo), "pool_hw": (Hp, Wp), "argmax": amax,
-                         "blocks": block_recs, "N": N, "last_hw": (h, w)})
+                         "blocks": block_recs, "N": N, "last_hw": (h, w), "V": self._V})
 
     def encoder_backward(self, ctx, dfeat, last_view=True):
         """dfeat: [N,2048] `dtype` gradient of the pooled features.  On the last view of a step each stage's
@@ -670,7 +710,15 @@ class SM3Engine:
             split = bool(streams) and self.view_lanes
             self._ordered_bn = split and train
             # the two views go through the encoder separately: BN statistics per view (simclr.py:58-59)
-            for v in (0, 1):
+            pair = (self.pair_views and train and not split and len(imgs) == 2 and imgs[0].shape == imgs[1].shape
+                    and self.pair_ok(B, imgs[0].shape[2], imgs[0].shape[3]))
+            if pair:  # both views as one batch of 2B images (BatchNorm statistics still per view)
+                with self.lane(key, streams):
+                    tmp = [] if want_grad else None
+                    self.encoder_forward(plan, torch.cat([imgs[0], imgs[1]], 0), train, f32, ft, tmp, views=2)
+                    if want_grad:
+                        ctxs = [tmp[0]]
+            for v in (() if pair else (0, 1)):
                 with self.lane(key + "#1" if (split and v == 1) else key, streams):
                     tmp = [] if want_grad else None
                     self.encoder_forward(plan, imgs[v], train, f32[v * B:(v + 1) * B], ft[v * B:(v + 1) * B], tmp)
@@ -743,6 +791,12 @@ class SM3Engine:
             self._notify(self.cross[0].prefix, self.cross[-1].prefix)
         split = bool(streams) and self.view_lanes
         for key, (plan, proj) in self.branches.items():
+            if len(saved[key]["enc"]) == 1:  # both views went through as one batch
+                with self.lane(key, streams):
+                    self.encoder_backward(saved[key]["enc"][0], dfe[key], last_view=True)
+                    saved[key]["enc"][0] = None
+                    self._sync_side()
+                continue
             for v in (1, 0):
                 with self.lane(key + "#1" if (split and v == 1) else key, streams):
                     # with the views on two lanes a stage's gradients are final only when BOTH are done: the

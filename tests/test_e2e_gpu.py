@@ -285,3 +285,44 @@ def test_training_overfits_a_fixed_batch(dt):
     torch.cuda.synchronize()
     first, last = float(losses[0]), float(sum(losses[-3:]) / 3)
     assert first > 5.0 and np.isfinite(last) and last < 0.3, (first, last, [round(float(v), 3) for v in losses])
+
+
+def test_both_views_as_one_batch_equal_per_view_passes_and_the_oracle():
+    """B = 32 at 64x64 is the smallest configuration in which every feature map of a view is a multiple of 128 rows,
+    so the engine sends both views of a branch through the encoder as ONE batch of 2B images (per-view BatchNorm
+    statistics).  Forward arithmetic is tile for tile the same as in two per-view passes -> identical loss and
+    running statistics; weight gradients differ only by the summation order of the longer pixel axis; and the
+    whole step matches the CPU oracle (fp64)."""
+    from oracle import procedural, sm3_oracle as O
+    from sm3hip.trainer import SM3Trainer
+    seed, batch, size = 21, 32, 64
+    derm_np, clinic_np = procedural.make_pair_batch(batch, size, seed)
+    derm = [torch.from_numpy(a).cuda() for a in derm_np]
+    clinic = [torch.from_numpy(a).cuda() for a in clinic_np]
+    runs = {}
+    for pair in (True, False):
+        model = _build(seed, torch.float32)
+        tr = SM3Trainer(model, lr=1e-6, weight_decay=5e-2, eps=1e-5, style=0)
+        eng = tr._engine()
+        eng.pair_views = pair
+        assert eng.pair_ok(batch, size, size)
+        loss = tr.step(derm, clinic)
+        torch.cuda.synchronize()
+        grads = [g.clone() for g in eng.store.grad_views()]
+        sd = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}
+        runs[pair] = (float(loss), grads, sd)
+    assert abs(runs[True][0] - runs[False][0]) < 1e-5  # the four loss terms are added with float atomics
+    for k in runs[True][2]:
+        assert torch.equal(runs[True][2][k], runs[False][2][k]), k
+    for a, b in zip(runs[True][1], runs[False][1]):
+        assert float((a - b).norm()) <= 1e-4 * float(b.norm()) + 1e-9
+    state = procedural.make_state_dict(seed=seed)
+    P, B = O.split_state(state, torch.float64)
+    want, _ = O.train_step(P, B, [torch.from_numpy(a).double() for a in derm_np],
+                           [torch.from_numpy(a).double() for a in clinic_np], 0, 0.1)
+    assert abs(runs[True][0] - float(want)) < 1e-3
+    names = open(os.path.join(os.path.dirname(__file__), "golden", "param_names.txt")).read().split()
+    gn = np.array([float(g.double().norm()) for g in runs[True][1]])
+    on = np.array([float(P[k].grad.norm()) for k in names])
+    np.testing.assert_allclose(gn, on, rtol=3e-2, atol=1e-7)
+    assert int(runs[True][2]["derm_backbone.encoder.bn1.num_batches_tracked"]) == 2
