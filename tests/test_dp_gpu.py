@@ -31,7 +31,7 @@ class _AllReduceSum(torch.autograd.Function):
         return g
 
 
-def _rank_main(rank, world, port, q):
+def _rank_main(rank, world, port, q, Bl=4):
     try:
         for p in (ROOT, os.path.join(ROOT, "skin-sm3_amd"), os.path.join(ROOT, "tests")):
             if p not in sys.path:
@@ -41,7 +41,7 @@ def _rank_main(rank, world, port, q):
         from oracle import procedural, sm3_oracle as O
         from sm3hip.trainer import SM3Trainer
         from src.models.simclr import SimCLRSkinV32
-        Bl, size, seed, T, lr = 4, 64, 21, 0.1, 1e-3
+        size, seed, T, lr = 64, 21, 0.1, 1e-3
         state = procedural.make_state_dict(seed=seed)
         derm_np, clinic_np = procedural.make_pair_batch(Bl * world, size, seed)
         sl = slice(rank * Bl, (rank + 1) * Bl)
@@ -66,6 +66,7 @@ def _rank_main(rank, world, port, q):
         loss = tr.step([torch.from_numpy(a[sl]).to(dev) for a in derm_np], [torch.from_numpy(a[sl]).to(dev) for a in clinic_np])
         torch.cuda.synchronize()
         eng = tr._engine()
+        assert eng.pair_ok(Bl, size, size) == (Bl % 32 == 0)  # 32 per rank: both views of a branch as one batch
         names = eng.store.names
         g = torch.cat([v.reshape(-1).double().cpu() for v in eng.store.grad_views()]) / world  # AdamW applies 1/world
         # flat order == named_parameters order == P order
@@ -87,11 +88,14 @@ def _rank_main(rank, world, port, q):
         q.put((rank, False, traceback.format_exc()))
 
 
-def test_two_rank_dp_step_matches_sharded_oracle():
+@pytest.mark.parametrize("Bl", [4, 32], ids=["per_view_passes", "both_views_one_batch"])
+def test_two_rank_dp_step_matches_sharded_oracle(Bl):
+    """Bl = 32 per rank is aligned for the two-views-in-one-batch mode: one SyncBN statistics all-reduce covers both
+    views of a BatchNorm."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q, Bl)) for r in range(2)]
     for p in procs:
         p.start()
     res = {}
