@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--workload", default="pretrain", choices=["pretrain", "linear_probe", "inference"],
                     help="pretrain = BASELINE.json's metric (default); linear_probe = SURVEY.md 8f-1 (tools/backbone_eval.py "
                          "--finetune fc step at run.sh's batch 128: frozen eval-mode encoders + 8 trained heads)")
+    ap.add_argument("--single-lane", action="store_true",
+                    help="run the derm and clinic branches on ONE stream (diagnostic: per-kernel durations without the "
+                         "other lane's kernels sharing the chip -- what roofline.achieved is measured on)")
     ap.add_argument("--breakdown", default=None, help="write a per-kernel-class time/FLOP/byte table (one extra, "
                                                        "untimed, fully instrumented step) to this file")
     return ap.parse_args()
@@ -245,6 +248,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.single_lane:
+        trainer._engine().two_streams = False
     for _ in range(args.warmup):
         trainer.step(derm, clinic)
     prof = profiler.Profiler(only={"conv_gemm_128x128"})
@@ -278,7 +283,7 @@ def main():
     trainer.step(derm, clinic)
     torch.cuda.synchronize()
     ops.set_profiler(None)
-    eng.two_streams = True
+    eng.two_streams = not args.single_lane
     dom = iso.summary().get("conv_gemm_128x128", {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0})
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
     peak = MFMA_PEAK_TFLOPS[args.dtype]
@@ -287,7 +292,7 @@ def main():
     # counters cannot be read from inside the process, so the committed measurement is reported, for the workload
     # it was taken on only.
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01c_pmc_traffic_conv_igemm_b256_bf16.json")
+    tpath = os.path.join(ROOT, "profiles", "r01d_pmc_traffic_conv_igemm_b256_bf16.json")
     if args.dtype == "bf16" and B == 256 and S == 224 and os.path.exists(tpath):
         traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
     # The kernel's 432 launches per step straddle the ridge (peak FLOP/s / 8 TB/s = 312 FLOP/B at bf16): split them
