@@ -711,7 +711,11 @@ class SM3Engine:
             self._ordered_bn = split and train
             # the two views go through the encoder separately: BN statistics per view (simclr.py:58-59)
             pair = (self.pair_views and train and not split and len(imgs) == 2 and imgs[0].shape == imgs[1].shape
-                    and self.pair_ok(B, imgs[0].shape[2], imgs[0].shape[3]))
+                    and self.pair_ok(B, imgs[0].shape[2], imgs[0].shape[3])
+                    # the kernels address a tensor with 32-bit buffer offsets below 3 GB; the largest one is the stem's
+                    # im2col matrix
+                    and 2 * B * ((imgs[0].shape[2] - 1) // 2 + 1) * ((imgs[0].shape[3] - 1) // 2 + 1) * STEM_KPAD
+                    * ops._sz(self.dtype) < 0xC0000000)
             if pair:  # both views as one batch of 2B images (BatchNorm statistics still per view)
                 with self.lane(key, streams):
                     tmp = [] if want_grad else None
