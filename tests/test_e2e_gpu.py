@@ -326,3 +326,14 @@ def test_both_views_as_one_batch_equal_per_view_passes_and_the_oracle():
     on = np.array([float(P[k].grad.norm()) for k in names])
     np.testing.assert_allclose(gn, on, rtol=3e-2, atol=1e-7)
     assert int(runs[True][2]["derm_backbone.encoder.bn1.num_batches_tracked"]) == 2
+    # the reference's literal call contract (model(...) -> CrossEntropyLoss -> backward) takes the same route
+    model = _build(seed, torch.float32)
+    model.train()
+    outs = model(derm, clinic, 0)
+    crit = torch.nn.CrossEntropyLoss()
+    loss = crit(*outs[0]) + crit(*outs[1]) + 0.5 * crit(*outs[2][0]) + 0.5 * crit(*outs[2][1])
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss.detach()) - runs[True][0]) < 1e-4
+    cn = np.array([float(p_.grad.double().norm()) for _, p_ in model.named_parameters()])
+    np.testing.assert_allclose(cn, gn, rtol=2e-3, atol=1e-7)
