@@ -33,6 +33,31 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense, MI355X_MICROARCH.md 
 FLOP_PER_PAIR_224 = 98.5e9
 
 
+def kernel_source_sha():
+    """sha256 over the sources of the dominant kernel: ties a committed PMC measurement to the code it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("conv_igemm.hip", "conv_common.h", "common.h"):
+        h.update(open(os.path.join(ROOT, "skin-sm3_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def replayed_traffic(dtype, B, S):
+    """HBM bytes per launch of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate runs of this same command, FETCH_SIZE doubled per the gfx950 correction; scratch/collect_traffic.py).
+    Counters cannot be read from inside the process, so the newest committed measurement is REPLAYED -- only for the
+    workload it was taken on and only while the kernel sources still hash to what it recorded; otherwise null."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_conv_igemm_b256_bf16.json")))
+    if not (dtype == "bf16" and B == 256 and S == 224 and files):
+        return None, "none for this workload"
+    rec = json.load(open(files[-1]))
+    rel = os.path.relpath(files[-1], ROOT)
+    if rec.get("kernel_source_sha") != kernel_source_sha():
+        return None, f"{rel} is stale (kernel sources changed since it was collected): not reported"
+    return round(rec["hbm_bytes_per_launch"]), f"{rel} (replayed; rocprofv3 --pmc passes of this command, not measured in this run)"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,20 +223,42 @@ def inference_bench(args):
                      "kernel": "conv_igemm_kernel<bf16_t,128,128,2,2,*> with the conv+evalBN+ReLU epilogue"}}), flush=True)
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh worker processes of this same file, one rank
+    per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1), and return
+    rank 0's exit code.  Decided before this process has touched the GPU: the parent never initialises HIP (no
+    torch.cuda call but device_count(), no exec of a GPU process); rank 0's stdout carries the ONE JSON line."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()  # does not initialise the GPU
+    if os.environ.get("SM3_FORCE_DEVICE") is None and have < n:
+        raise SystemExit(f"--gpus {n} but only {have} GPU(s) visible")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    return next((rc for rc in rcs if rc), 0)
+
+
 def main():
     args = parse()
     if args.workload == "linear_probe":
         return linear_probe_bench(args)
     if args.workload == "inference":
         return inference_bench(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
     # test knobs (a 2-rank rehearsal of this file on a one-GPU box: both ranks on device 0 over gloo)
@@ -287,14 +334,7 @@ def main():
     dom = iso.summary().get("conv_gemm_128x128", {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0})
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
     peak = MFMA_PEAK_TFLOPS[args.dtype]
-    # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-    # runs of this same command, FETCH_SIZE doubled per the gfx950 correction; scratch/collect_traffic.py):
-    # counters cannot be read from inside the process, so the committed measurement is reported, for the workload
-    # it was taken on only.
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01d_pmc_traffic_conv_igemm_b256_bf16.json")
-    if args.dtype == "bf16" and B == 256 and S == 224 and os.path.exists(tpath):
-        traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
+    traffic, traffic_source = replayed_traffic(args.dtype, B, S)
     # The kernel's 432 launches per step straddle the ridge (peak FLOP/s / 8 TB/s = 312 FLOP/B at bf16): split them
     # by algorithmic intensity and price each side against its own roof (extra keys; `achieved`/`frac` above them
     # stay the all-launch MFMA figures the contract asks for).
@@ -310,7 +350,9 @@ def main():
                                "frac_of_hbm_peak": round(reg["hbm"][1] / max(reg["hbm"][2], 1e-9) / HBM_PEAK_BYTES, 4)},
         "ridge_flop_per_byte": round(ridge, 1)}
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": traffic, "by_regime": by_regime,
+                "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
+                "frac_in_timed_region_two_lanes": round(in_region["flops"] / max(in_region["ms"] * 1e-3, 1e-9) / 1e12 / peak, 4),
+                "by_regime": by_regime,
                 "kernel": f"conv_igemm_kernel<{'bf16_t' if args.dtype == 'bf16' else 'float'},128,128,2,2,*>",
                 "algorithmic_bytes_per_launch": round(dom["bytes"] / max(dom["launches"], 1)),
                 "launches_per_step": dom["launches"],

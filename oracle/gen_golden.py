@@ -37,7 +37,7 @@ def _subsample(t, n=256):
     return flat[::step][:n].double().numpy()
 
 
-def run_case(SimCLRSkinV32, batch, size, seed, dtype, style, lr, tag):
+def run_case(SimCLRSkinV32, batch, size, seed, dtype, style, lr, tag, extract_rows=None, save=True):
     torch.manual_seed(0)
     model = SimCLRSkinV32("resnet50", None, 128, 0.1)
     state = procedural.make_state_dict(seed=seed)
@@ -116,8 +116,8 @@ def run_case(SimCLRSkinV32, batch, size, seed, dtype, style, lr, tag):
     model.eval()
     with torch.no_grad():
         feats = model.extract(derm[0], clinic[0])
-    out["extract_derm"] = feats[0].double().numpy()
-    out["extract_clinic"] = feats[1].double().numpy()
+    out["extract_derm"] = feats[0][:extract_rows].double().numpy()  # extract_rows: first rows only (fixture size)
+    out["extract_clinic"] = feats[1][:extract_rows].double().numpy()
     model.train()
 
     optimizer.step()
@@ -133,10 +133,27 @@ def run_case(SimCLRSkinV32, batch, size, seed, dtype, style, lr, tag):
               "derm_backbone.projector.1.running_var"):
         out["post_buf_full." + k] = sd[k].double().numpy()
 
+    if not save:
+        return out
     path = os.path.join(OUT, f"sm3_v32_{tag}.npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path}: loss={loss.item():.8f} ({os.path.getsize(path)/1024:.0f} KiB)")
     return names
+
+
+def run_b32_case(cls):
+    """The well-conditioned case (round 2): B = 32 pairs at 64x64 -- BatchNorm1d over 32 / 64 rows instead of 4 / 8,
+    and the smallest batch that takes the engine's both-views-in-one-batch route.  Also runs the reference in fp32
+    and prints its own fp32-vs-fp64 spread: the floor any fp32-accumulating implementation can be held to."""
+    run_case(cls, batch=32, size=64, seed=6, dtype=torch.float64, style=0, lr=1e-3, tag="b32_s64_f64", extract_rows=8)
+    g64 = np.load(os.path.join(OUT, "sm3_v32_b32_s64_f64.npz"))
+    g32 = run_case(cls, batch=32, size=64, seed=6, dtype=torch.float32, style=0, lr=1e-3, tag="", extract_rows=8, save=False)
+    print("reference fp32 vs fp64 at B=32: |dloss| = %.3e, max|dlogit| = %.3e, grad-norm max rel = %.3e" % (
+        abs(float(g32["loss"]) - float(g64["loss"])), np.abs(g32["derm_logits"] - g64["derm_logits"]).max(),
+        np.max(np.abs(g32["grad_norm"] - g64["grad_norm"]) / np.maximum(g64["grad_norm"], 1e-12))))
+    for k in g64.files:
+        if k.startswith(("grad_full.", "grad_sub.")):
+            print("  %-70s rel L2 %.3e" % (k, np.linalg.norm(g32[k] - g64[k]) / np.linalg.norm(g64[k])))
 
 
 def run_baseline_case(batch, size, seed, dtype, tag):
@@ -204,6 +221,9 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     cls = _import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "b32":  # generate only the round-2 well-conditioned fixture
+        run_b32_case(cls)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "inference":  # regenerate only the inference-model fixture
         run_inference_case(batch=5, size=64, seed=5, dtype=torch.float64, tag="b5_s64_f64")
         return
@@ -211,6 +231,7 @@ def main():
     run_case(cls, batch=4, size=64, seed=1, dtype=torch.float64, style=0, lr=1e-3, tag="b4_s64_f64")
     run_case(cls, batch=3, size=96, seed=2, dtype=torch.float64, style=2, lr=1e-3, tag="b3_s96_style2_f64")
     run_case(cls, batch=8, size=64, seed=3, dtype=torch.float64, style=1, lr=1e-3, tag="b8_s64_style1_f64")
+    run_b32_case(cls)
     run_baseline_case(batch=6, size=64, seed=4, dtype=torch.float64, tag="b6_s64_f64")
     run_inference_case(batch=5, size=64, seed=5, dtype=torch.float64, tag="b5_s64_f64")
     with open(os.path.join(OUT, "param_names.txt"), "w") as f:

@@ -90,8 +90,4 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t lds_
 __device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 
-// conv_igemm_v2.hip
-bool conv_v2_eligible(const sm3_conv_desc* d);
-int launch_conv_v2(const ConvParams& p, hipStream_t st);
-
 }  // namespace sm3conv

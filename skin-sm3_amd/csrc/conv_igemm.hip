@@ -542,7 +542,6 @@ static int conv_gather_gemm_impl(const sm3_conv_desc* d, const void* x, const vo
     p.ep_shift = ep_shift;
     p.ep_relu = ep_relu;
     hipStream_t st = (hipStream_t)stream;
-    if (conv_v2_eligible(d) && p.fz_view_tiles == 0) return launch_conv_v2(p, st);
     const bool narrow = d->Co <= 64;
     if (d->dtype == SM3_BF16)
         return narrow ? launch_conv<bf16_t, kBM, 64, 2, 2>(p, st) : launch_conv<bf16_t, kBM, 128, 2, 2>(p, st);

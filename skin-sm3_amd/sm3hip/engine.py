@@ -154,7 +154,8 @@ class BNUnit:
 
 class Rec:
     """What one conv+BN(+act) application saves for backward."""
-    __slots__ = ("cu", "bu", "N", "H", "W", "Ho", "Wo", "x_in", "xo", "mean", "invstd", "y", "relu", "mask", "V")
+    __slots__ = ("cu", "bu", "N", "H", "W", "Ho", "Wo", "x_in", "xo", "mean", "invstd", "y", "relu", "mask", "V",
+                 "frozen_stats")
 
 
 class EncoderPlan:
@@ -446,6 +447,11 @@ class SM3Engine:
         else:
             ops.conv_gemm(d, x, cu.w_fwd, xo, None, None)
             ops.bn_eval_scale_shift(gamma, beta, rm, rv, BN_EPS, C, scale, shift)
+            if save is not None:
+                # eval-mode BatchNorm inside an autograd graph (module.eval() with trainable parameters): the statistics
+                # are constants, so backward is dx = gamma * invstd * dz and d(gamma), d(beta) are the plain sums --
+                # bn_backward runs the same kernels with the batch-statistics terms zeroed (Rec.frozen_stats)
+                mean, invstd = rm.clone(), torch.rsqrt(rv + BN_EPS)
         if y_out is None:
             y_out = torch.empty(rows, C, dtype=torch.float32 if out_f32 else self.tdt, device=dev)
         mask = None
@@ -457,6 +463,7 @@ class SM3Engine:
             r.cu, r.bu, r.N, r.H, r.W, r.Ho, r.Wo = cu, bu, N, H, W, Ho, Wo
             r.x_in, r.xo, r.mean, r.invstd, r.y, r.relu, r.mask = x, xo, mean, invstd, y_out, relu, mask
             r.V = V
+            r.frozen_stats = not train
             save.append(r)
         return y_out, Ho, Wo
 
@@ -478,7 +485,10 @@ class SM3Engine:
         lsums = self._work("lsums", 2 * 2 * 2048, torch.float64)
         ops.bn_stats_reduce(bpart, prow, C, lsums, views=V)
         gsums, count = lsums, rows
-        if self.stat_sync is not None:
+        if r.frozen_stats:  # eval-mode BatchNorm: no mean(dz) / mean(dz * xhat) terms in dx
+            gsums = self._work("zsums", 2 * 2 * 2048, torch.float64)
+            gsums.zero_()
+        elif self.stat_sync is not None:
             gsums = self._work("gsums", 2 * 2 * 2048, torch.float64)
             gsums[: V * 2 * C].copy_(lsums[: V * 2 * C])
             self.stat_sync(gsums[: V * 2 * C])

@@ -108,15 +108,17 @@ class SM3Trainer:
     def optimizer_state_dict(self):
         """torch.optim.AdamW-compatible state_dict (exp_avg / exp_avg_sq per parameter, shared step)."""
         eng = self._engine()
+        eng.prepare(next(self.model.parameters()).device)
         st = eng.store
         state = {}
-        for i, n in enumerate(st.names):
-            state[i] = {"step": torch.tensor(float(self.step_count)),
-                        "exp_avg": st._view(self.m, n).clone(), "exp_avg_sq": st._view(self.v, n).clone()}
+        if self.m is not None:  # before the first step torch.optim.AdamW's state is empty too
+            for i, n in enumerate(st.names):
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": st._view(self.m, n).clone(), "exp_avg_sq": st._view(self.v, n).clone()}
         group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.wd, "amsgrad": False,
                  "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
                  "params": list(range(len(st.names)))}
-        return {"state": state if self.m is not None else {}, "param_groups": [group]}
+        return {"state": state, "param_groups": [group]}
 
     def load_optimizer_state_dict(self, sd):
         eng = self._engine()

@@ -46,28 +46,16 @@ CONV_CASES = [
     (2, 256, 512, 10, 10, 1, 2, 0),
     (1, 512, 128, 7, 7, 1, 1, 0),
     (5, 128, 192, 6, 6, 3, 1, 1),
-    # large enough for the persistent 256x128 kernel (bf16, >= 128 tiles): several tiles per workgroup, M tail
+    # many tiles per launch, M tail
     (16, 64, 256, 56, 56, 1, 1, 0),
     (13, 128, 256, 41, 37, 3, 1, 1),
     (9, 256, 384, 50, 46, 1, 2, 0),
 ]
 
 
-@pytest.fixture(params=[False, True], ids=["auto", "v2forced"])
-def conv_structure(request, monkeypatch):
-    """The gather-GEMM has two kernel structures (conv_igemm.hip / conv_igemm_v2.hip); the library picks by tile
-    count.  'v2forced' lowers the threshold so the small cases (strided data gradients, tails) run on the
-    persistent 256x128 kernel too."""
-    if request.param:
-        monkeypatch.setenv("SM3_CONV_V2_MIN_TILES", "1")
-    return request.param
-
-
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_fwd_dgrad_wgrad(case, dt, conv_structure):
-    if conv_structure and dt == torch.float32:
-        pytest.skip("the 256x128 structure is bf16 only")
+def test_conv_fwd_dgrad_wgrad(case, dt):
     ops = _ops()
     N, Ci, Co, H, W, k, s, p = case
     g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
@@ -133,7 +121,7 @@ def test_conv_fwd_dgrad_wgrad(case, dt, conv_structure):
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", [(2, 64, 128, 9, 11, 1, 1, 0), (3, 128, 64, 10, 8, 3, 1, 1), (2, 64, 192, 13, 11, 3, 2, 1),
                                   (12, 256, 128, 57, 50, 1, 1, 0), (8, 128, 64, 66, 62, 3, 2, 1)])
-def test_dgrad_with_fused_bn_backward_phase1(case, dt, conv_structure):
+def test_dgrad_with_fused_bn_backward_phase1(case, dt):
     """sm3_conv_dgrad_bnfuse == sm3_conv_gather_gemm followed by sm3_bn_bwd_reduce (dz bit-exact, sums equal)."""
     ops = _ops()
     N, Ci, Co, H, W, k, s, p = case   # forward conv Ci -> Co; its data gradient has Ci output channels
