@@ -3,7 +3,8 @@
   * config 2 at its own size -- B = 256 pairs, 224x224, bf16, both views of a branch in one batch (the 2.47 GB
     stem im2col tensor included): identical forward / running statistics to per-view passes, loss against the
     exact-f32 mode on the same inputs, finite gradients;
-  * T2 (SURVEY.md 8c): bf16 vs exact-f32 from a TRAINED, well-conditioned state -- logits, loss, gradient norm;
+  * T2: bf16 vs exact-f32 at random init and from a trained state, with PyTorch's own bf16 autocast of
+    the same network (CPU oracle) as the yardstick -- loss, logits, gradient direction;
   * the B = 32 golden generated from the reference itself (oracle/gen_golden.py b32): BatchNorm1d over 32 / 64
     rows instead of 4 / 8, so the gradient bounds are the reference's own fp32-vs-fp64 spread at THIS size;
   * config 5's image size (448x448) at B = 32 in bf16;
@@ -105,39 +106,78 @@ def test_config2_b256_224_bf16():
             assert float(d) < 2e-2, (k, float(d))
 
 
-def test_T2_bf16_vs_f32_from_a_trained_state():
-    """SURVEY.md 8c T2.  30 fused f32 steps on one fixed batch of 32 learnable (`latent`) pairs separate the
-    features (loss 11 -> < 0.3); from THAT state one step of the reference's literal loop in bf16 and in exact f32
-    on the same batch: logits, loss and gradient norm side by side."""
+def _flat(grads, names):
+    return torch.cat([grads[k].detach().double().cpu().flatten() for k in names])
+
+
+@pytest.mark.parametrize("steps", [0, 10], ids=["random_init", "after_10_steps"])
+def test_T2_bf16_step_against_f32_with_torch_autocast_as_yardstick(steps):
+    """SURVEY.md 8c T2.  One step of the reference's literal loop in bf16 and in exact f32 from the same state on the
+    same batch of 32 learnable (`latent`) pairs -- at random init and after 10 fused f32 steps (loss 14 -> ~0.5).
+
+    What bf16 can deliver here is not a free parameter: the 1/0.1 temperature behind BatchNorm1d(affine=False) +
+    L2-normalise turns a 3 % feature error into logit errors of ~0.5-1 (range +-10), and the gradient follows the
+    softmax weights.  PyTorch's OWN bf16 autocast of this network (the CPU oracle under torch.autocast -- what the
+    reference would compute with --amp in bf16) lands at: loss off by 0.49, logits rms 0.96, gradient cosine 0.15
+    against fp32 at B = 32 on the procedural batch (measured; the reference's real AMP mode, fp16, gives 0.022 / 0.26 /
+    0.61); on this test's states: logits rms 0.93 / cosine 0.12 at random init and 0.68 / 0.31 after 10 steps, where
+    the HIP bf16 step measures 0.87 / 0.17 and 0.57 / 0.35.  So the
+    yardstick is that run, on the same state: the HIP bf16 step must be no further from f32 than torch's bf16
+    autocast is, and the HIP f32 step must agree with the fp32 oracle outright."""
+    from oracle import sm3_oracle as O
     from sm3hip.trainer import SM3Trainer
     from src.models.simclr import SimCLRSkinV32
     torch.manual_seed(5)
     model = SimCLRSkinV32("resnet50", None, 128, 0.1)
     model.sm3_dtype = torch.float32
     model.to(DEV)
-    tr = SM3Trainer(model, lr=3e-4, weight_decay=5e-2, eps=1e-5, style=0)
     derm, clinic = _latent_batch(32, 64, 7)
-    losses = [float(tr.step(derm, clinic)) for _ in range(30)]
-    assert losses[-1] < 0.5, losses
-    trained = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    del tr, model
-    res = {}
+    if steps:
+        tr = SM3Trainer(model, lr=3e-4, weight_decay=5e-2, eps=1e-5, style=0)
+        for _ in range(steps):
+            tr.step(derm, clinic)
+        del tr
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    del model
+    names = [k for k in state if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+    hip = {}
     for dt in (torch.float32, torch.bfloat16):
-        m = _build(0, dt, trained)
+        m = _build(0, dt, state)
         m.train()
-        res[dt] = _compat_step(m, derm, clinic)
+        loss, logits, grads = _compat_step(m, derm, clinic)
+        hip[dt] = (loss, torch.cat([l.double().cpu().flatten() for l in logits]), _flat(grads, names))
         del m
-    lf, lb = res[torch.float32][1], res[torch.bfloat16][1]
-    dlogit = max(float((a - b).abs().max()) for a, b in zip(lf, lb))
-    dloss = abs(res[torch.float32][0] - res[torch.bfloat16][0])
-    gn = {dt: float(torch.sqrt(sum((g.double() ** 2).sum() for g in res[dt][2].values()))) for dt in res}
-    print(f"T2: loss f32 {res[torch.float32][0]:.5f} bf16 {res[torch.bfloat16][0]:.5f}; max|dlogit| {dlogit:.4f}; "
-          f"|grad| f32 {gn[torch.float32]:.5f} bf16 {gn[torch.bfloat16]:.5f}")
-    # logits span [-10, 10] (cosine / 0.1): 0.25 is 1.2 % of the range, i.e. bf16's 2^-8 on a cosine times 1/tau
-    # with headroom for the BN-MLP head; the loss and the gradient norm are the quantities training sees
-    assert dlogit < 0.25, dlogit
-    assert dloss < 2e-2, dloss
-    assert abs(gn[torch.bfloat16] - gn[torch.float32]) < 0.05 * gn[torch.float32], gn
+    # CPU oracle: fp32, and the same code under torch's bf16 autocast
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    cpu = {}
+    state_np = {k: v.cpu().numpy() for k, v in state.items()}
+    dc, cc = [t.cpu() for t in derm], [t.cpu() for t in clinic]
+    for key, amp in (("f32", None), ("bf16", torch.bfloat16)):
+        P, Bf = O.split_state(state_np, torch.float32)
+        with torch.autocast("cpu", dtype=amp, enabled=amp is not None):
+            outs = O.sm3_v32_forward(P, Bf, dc, cc, 0, 0.1, True, None)
+            loss = O.sm3_loss(outs, 0)
+        loss.backward()
+        lg = [outs[0][0], outs[1][0]] + [o[0] for o in outs[2]]
+        cpu[key] = (float(loss), torch.cat([l.detach().double().flatten() for l in lg]),
+                    torch.cat([P[k].grad.double().flatten() for k in names]))
+
+    def dist(a, b):
+        cos = float(a[2] @ b[2] / (a[2].norm() * b[2].norm()))
+        return abs(a[0] - b[0]), float((a[1] - b[1]).pow(2).mean().sqrt()), cos
+
+    f32_vs_oracle = dist(hip[torch.float32], cpu["f32"])
+    hip_bf16 = dist(hip[torch.bfloat16], hip[torch.float32])
+    torch_bf16 = dist(cpu["bf16"], cpu["f32"])
+    print(f"T2[{steps}]: (|dloss|, logit rms, grad cosine)  HIP f32 vs oracle f32 {f32_vs_oracle};  "
+          f"HIP bf16 vs HIP f32 {hip_bf16};  torch bf16 autocast vs fp32 {torch_bf16}")
+    assert f32_vs_oracle[0] < 1e-3 and f32_vs_oracle[1] < 2e-3 and f32_vs_oracle[2] > 0.999, f32_vs_oracle
+    # the loss is one scalar: either run can land close to f32 by luck (torch's did at random init: 0.007 against a
+    # logit rms of 0.93), so it only gets an absolute bound; logits and gradient direction carry the comparison
+    assert hip_bf16[0] <= max(1.5 * torch_bf16[0], 0.3), (hip_bf16, torch_bf16)
+    assert hip_bf16[1] <= 1.25 * torch_bf16[1], (hip_bf16, torch_bf16)
+    assert hip_bf16[2] >= torch_bf16[2] - 0.05, (hip_bf16, torch_bf16)
+    assert hip_bf16[0] < 0.6 and hip_bf16[2] > 0.1, hip_bf16  # absolute sanity, whatever the yardstick says
 
 
 def test_b32_golden_from_the_reference(golden_dir):
@@ -203,8 +243,10 @@ def test_config5_image_size_448_b32_bf16():
         out[dt] = (loss, float(eng.store.flat_g.double().norm()))
         del tr, eng, model
         torch.cuda.empty_cache()
-    assert abs(out[torch.bfloat16][0] - out[torch.float32][0]) < 0.15, out
-    assert abs(out[torch.bfloat16][1] - out[torch.float32][1]) < 0.2 * out[torch.float32][1], out
+    # random init at B = 32: the loss is only comparable to ~1 in bf16 (see T2 above: torch's own bf16 autocast of this
+    # network is 0.5 off at this batch size); the gradient norm is the tighter signal
+    assert abs(out[torch.bfloat16][0] - out[torch.float32][0]) < 1.0, out
+    assert abs(out[torch.bfloat16][1] - out[torch.float32][1]) < 0.1 * out[torch.float32][1], out
 
 
 def test_checkpoint_resume_in_the_reference_wire_format(tmp_path):
@@ -278,7 +320,8 @@ def test_torch_adamw_checkpoint_resumes_in_the_fused_engine():
     for i in range(2):
         torch_step(*batches[i])
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    osd = opt.state_dict()
+    import copy
+    osd = copy.deepcopy(opt.state_dict())  # state_dict() hands out the live tensors
     loss3 = torch_step(*batches[2])
     torch.cuda.synchronize()
     p3 = {k: v.detach().clone() for k, v in model.named_parameters()}
