@@ -136,6 +136,13 @@ int sm3_bn_eval_scale_shift(const float* gamma, const float* beta, const float* 
  * replaces the bn->relu / bn->add->relu chains of Bottleneck.forward (resnet.py:154-174). */
 int sm3_bn_act(int dtype, const void* x, const float* scale, const float* shift, const void* residual,
                int relu, int out_f32, void* y, uint8_t* relu_mask, int64_t rows, int C, int views, void* stream);
+/* The join of a Bottleneck with a downsample branch in ONE pass (resnet.py:164-172: out = bn3(conv3); identity =
+ * downsample(x) [conv + BatchNorm]; out += identity; relu):  y = [relu]( x*scale + shift + x2*scale2 + shift2 ),
+ * x2 the pre-BatchNorm output of the downsample convolution, scale2/shift2 [views][C] from its sm3_bn_finalize.
+ * The downsample BatchNorm's own apply pass (one read + one write of a block-output-sized tensor) disappears. */
+int sm3_bn_add_bn_act(int dtype, const void* x, const float* scale, const float* shift, const void* x2,
+                      const float* scale2, const float* shift2, int relu, void* y, uint8_t* relu_mask,
+                      int64_t rows, int C, int views, void* stream);
 /* Backward, phase 1: dz = dy * (y > 0), the mask taken from relu_mask if given, else from y if given, else all
  * ones; writes dz (may alias dy; NULL to skip) and
  * per-block partial sums [bwd_partial_rows][2][C] of (dz, dz * xhat), xhat = (x-mean)*invstd. */
@@ -150,17 +157,61 @@ int sm3_bn_bwd_apply(int dtype, const void* dz, const void* x, const float* mean
                      const double* local_sums, float* dgamma, float* dbeta, void* dx, int64_t rows,
                      int C, int views, void* stream);
 
+/* Phase 2 for the TWO BatchNorms of such a join, which receive the same dz: reads dz once, writes both input
+ * gradients (arithmetic of each side = sm3_bn_bwd_apply). */
+typedef struct sm3_bn_apply_side {
+    const void* x;                 /* pre-BatchNorm tensor, [views][rows][C] */
+    const float* mean;             /* [views][C] */
+    const float* invstd;
+    const float* gamma;            /* [C], nullable */
+    const double* global_sums;     /* [views][2C] */
+    const double* local_sums;      /* [views][2C], nullable with dgamma/dbeta */
+    float* dgamma;
+    float* dbeta;
+    void* dx;
+} sm3_bn_apply_side;
+int sm3_bn_bwd_apply2(int dtype, const void* dz, double count, const sm3_bn_apply_side* a,
+                      const sm3_bn_apply_side* b, int64_t rows, int C, int views, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Stem, pooling.  replaces resnet.py:208-213,224,294-305.
  * ------------------------------------------------------------------------------------------ */
 /* 7x7/2 pad-3 im2col of an NCHW fp32 image batch into rows [N*Ho*Wo, Kpad] of dtype,
  * k = (kh*7+kw)*3 + c for k < 147, zero for 147 <= k < Kpad. */
 int sm3_stem_im2col(int dtype, const float* x_nchw, void* cols, int N, int H, int W, int Kpad, void* stream);
+/* Direct stem (bf16 only; the exact-f32 parity mode keeps sm3_stem_im2col + sm3_conv_gather_gemm): the 7x7/2 pad-3
+ * convolution straight from the NCHW fp32 images, no im2col matrix in HBM.
+ *   w_stem: dtype [64][176] from sm3_stem_weight_prep (K order (kh, c, kw padded to 8); master is [64][kh][kw][c]);
+ *   y: [N*Ho*Wo, 64] dtype; stat_partials (nullable): [sm3_stem_partial_rows][2][64], one row per tile of <= 128
+ *   output pixels of one output row -- tiles are image-major, so a view's rows are contiguous. */
+int sm3_stem_partial_rows(int N, int H, int W);
+int sm3_stem_weight_prep(int dtype, const float* w_master, void* w_stem, void* stream);
+int sm3_stem_conv_fwd(int dtype, const float* x_nchw, const void* w_stem, void* y, float* stat_partials, int N, int H,
+                      int W, void* stream);
+/* Stem weight gradient with phase 2 of bn1's backward fused into its operand load:
+ *   dxo = gamma*invstd*(dz - sum_dz/count - xhat*sum_dz_xhat/count)   (never written to HBM: the stem has no data
+ *   gradient, so this tensor has no other consumer),  dw[64][147] += dxo^T * im2col(x)  (float atomics),
+ *   dgamma += local sum(dz*xhat), dbeta += local sum(dz).  Arguments as sm3_bn_bwd_apply; dz, xo: [N*Ho*Wo, 64]. */
+int sm3_stem_wgrad_bn(int dtype, const float* x_nchw, const void* dz, const void* xo, const float* mean,
+                      const float* invstd, const float* gamma, const double* global_sums, double count,
+                      const double* local_sums, float* dgamma, float* dbeta, float* dw, int N, int H, int W, int views,
+                      void* stream);
 /* argmax (nullable): [N,Ho,Wo,C] bytes, window position kh*3+kw of the first maximum in scan order (ATen's tie rule) */
 int sm3_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* argmax, int N, int H, int W, int C, void* stream);
 /* dx[n,iy,ix,c] = sum of dy over the windows whose recorded argmax is (iy,ix); gather form, no atomics */
 int sm3_maxpool3x3s2_bwd(int dtype, const uint8_t* argmax, const void* dy, void* dx, int N, int H, int W, int C,
                          void* stream);
+/* Stem chain bn1 -> relu -> maxpool (resnet.py:295-297) in ONE pass over the pre-BatchNorm stem output x [N,H,W,C]:
+ * y[N,Ho,Wo,C] = maxpool3x3s2(relu(x*scale + shift)), argmax as above; scale/shift [views][C] (images [0,N/views) are
+ * view 0).  Bit-identical to sm3_bn_act followed by sm3_maxpool3x3s2_fwd; the post-ReLU map is never stored. */
+int sm3_bn_relu_maxpool_fwd(int dtype, const void* x, const float* scale, const float* shift, void* y,
+                            uint8_t* argmax, int N, int H, int W, int C, int views, void* stream);
+/* ... and its backward up to BatchNorm-backward phase 1: dz[N,H,W,C] = (x*scale+shift > 0) * maxpool_bwd(dy), plus
+ * partial sums [views][sm3_maxpool_bn_bwd_partial_rows][2][C] of (dz, dz*xhat) as sm3_bn_bwd_reduce writes them. */
+int sm3_maxpool_bn_bwd_partial_rows(int N, int H, int W, int views);
+int sm3_maxpool_bn_bwd(int dtype, const uint8_t* argmax, const void* dy, const void* x, const float* scale,
+                       const float* shift, const float* mean, const float* invstd, void* dz, float* partials,
+                       int N, int H, int W, int C, int views, void* stream);
 /* feat[n,c] = mean over HW; feat_f32 and feat_t (dtype copy for the projector GEMM) both optional */
 int sm3_avgpool_fwd(int dtype, const void* x, float* feat_f32, void* feat_t, int N, int HW, int C, void* stream);
 int sm3_avgpool_bwd(int dtype, const void* dfeat, void* dx, int N, int HW, int C, void* stream);

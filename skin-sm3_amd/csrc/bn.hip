@@ -101,36 +101,56 @@ __global__ void bn_stats_reduce_b(const double* __restrict__ ws, int G, int C, d
     if (col < 2 * C && q == 0) sums[col] = a;
 }
 
+// 16 lanes per channel: lane = (view v in {0,1}) x (statistic in {sum, sum of squares}) x (quad lane q); the four
+// group sums of a channel (2 views x 2 statistics) run side by side instead of one after the other -- this kernel is
+// pure latency (a chain of dependent L2 loads per sum) and sits on the critical path of every BatchNorm.  views > 2
+// loop over pairs.  Running statistics are still updated view 0 first, then view 1, by one lane, as in the reference's
+// sequential encoder(x1); encoder(x2).
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, int groups, int views, double count, int C,
                                    const float* gamma, const float* beta, float eps, float momentum,
                                    float* running_mean, float* running_var, int64_t* nbt, float* scale, float* shift,
                                    float* save_mean, float* save_invstd) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x, q = t & 3;
-    const int c = t >> 2;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = t & 3, stat = (t >> 2) & 1, vl = (t >> 3) & 1, c = t >> 4;
     if (t == 0 && nbt) nbt[0] += views;
     const int cc = c < C ? c : 0;
-    // views are finalised in order by the same thread: the running statistics see view 0's update before view 1's,
-    // as in the reference's sequential encoder(x1); encoder(x2)
-    for (int v = 0; v < views; ++v) {
+    float rm = 0.f, rv = 0.f;
+    const bool owner = (c < C) && ((t & 15) == 0);
+    if (owner) {
+        rm = running_mean ? running_mean[c] : 0.f;
+        rv = running_var ? running_var[c] : 0.f;
+    }
+    for (int v0 = 0; v0 < views; v0 += 2) {
+        const int v = v0 + vl;
+        const bool vok = v < views;
         // groups > 1: stage B of the statistics reduction folded in here (same association as bn_stats_reduce_b)
-        const double* sv = sums + (long)v * groups * 2 * C;
-        const double s1 = quad_sum_groups(sv, 2L * C, cc, groups, q);
-        const double s2 = quad_sum_groups(sv, 2L * C, (long)C + cc, groups, q);
-        if (c >= C || q != 0) continue;
-        const double mean = s1 / count;
-        double var = s2 / count - mean * mean;
-        if (var < 0) var = 0;
-        const double invstd = 1.0 / sqrt(var + (double)eps);
-        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-        scale[(long)v * C + c] = (float)(g * invstd);
-        shift[(long)v * C + c] = (float)((double)b - mean * (double)g * invstd);
-        if (save_mean) save_mean[(long)v * C + c] = (float)mean;
-        if (save_invstd) save_invstd[(long)v * C + c] = (float)invstd;
-        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-        if (running_var) {
+        const double* sv = sums + (long)(vok ? v : v0) * groups * 2 * C;
+        const double mine = quad_sum_groups(sv, 2L * C, (long)stat * C + cc, groups, q);
+        // lanes (vl, stat, q=0) of the channel's 16-lane group hold the four sums; bring them to lane 0 of the group
+        const double s2_same_view = __shfl_down(mine, 4, 64);   // from (vl, stat=1)
+        const double s1_v1 = __shfl_down(mine, 8, 64);          // from (vl=1, stat=0)
+        const double s2_v1 = __shfl_down(mine, 12, 64);         // from (vl=1, stat=1)
+        if (!owner) continue;
+        for (int k = 0; k < 2 && v0 + k < views; ++k) {
+            const double s1 = k ? s1_v1 : mine, s2 = k ? s2_v1 : s2_same_view;
+            const int vv = v0 + k;
+            const double mean = s1 / count;
+            double var = s2 / count - mean * mean;
+            if (var < 0) var = 0;
+            const double invstd = 1.0 / sqrt(var + (double)eps);
+            const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+            scale[(long)vv * C + c] = (float)(g * invstd);
+            shift[(long)vv * C + c] = (float)((double)b - mean * (double)g * invstd);
+            if (save_mean) save_mean[(long)vv * C + c] = (float)mean;
+            if (save_invstd) save_invstd[(long)vv * C + c] = (float)invstd;
+            rm = (1.f - momentum) * rm + momentum * (float)mean;
             const double unbiased = var * (count / fmax(count - 1.0, 1.0));
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+            rv = (1.f - momentum) * rv + momentum * (float)unbiased;
         }
+    }
+    if (owner) {
+        if (running_mean) running_mean[c] = rm;
+        if (running_var) running_var[c] = rv;
     }
 }
 
@@ -150,8 +170,10 @@ __global__ void bn_eval_kernel(const float* gamma, const float* beta, const floa
 template <typename T, bool OUT_F32, int U, bool NT>
 __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, const T* __restrict__ res,
-                                                     int relu, void* __restrict__ y, uint8_t* __restrict__ mask,
-                                                     int64_t rows, int C, int tbx, int tby) {
+                                                     const float* __restrict__ res_scale,
+                                                     const float* __restrict__ res_shift, int relu,
+                                                     void* __restrict__ y, uint8_t* __restrict__ mask, int64_t rows,
+                                                     int C, int tbx, int tby) {
     constexpr int E = ElemTraits<T>::kPer16B;
     const int tx = threadIdx.x % tbx, ty = threadIdx.x / tbx;
     const int cv = blockIdx.x * tbx + tx;
@@ -164,12 +186,24 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x, co
         if (mask) mask += (int64_t)blockIdx.z * rows * (C / E);
         scale += (int64_t)blockIdx.z * C;
         shift += (int64_t)blockIdx.z * C;
+        if (res_scale) {
+            res_scale += (int64_t)blockIdx.z * C;
+            res_shift += (int64_t)blockIdx.z * C;
+        }
     }
-    float sc[E], sh[E];
+    // res_scale: the residual is itself a pre-BatchNorm tensor (the downsample branch, resnet.py:166-167): its
+    // normalisation is applied here, y = relu(x*scale + shift + res*res_scale + res_shift), and the separate
+    // bn_act pass over the downsample output (one read + one write of a block-output-sized tensor) disappears
+    float sc[E], sh[E], rs[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         sc[e] = scale[cv * E + e];
         sh[e] = shift[cv * E + e];
+        rs[e] = 1.f;
+        if (res_scale) {
+            rs[e] = res_scale[cv * E + e];
+            sh[e] += res_shift[cv * E + e];
+        }
     }
     const int64_t rstep = (int64_t)gridDim.y * tby;
     auto finish = [&](int64_t r, const uint4& xu, const uint4& ru) {
@@ -182,7 +216,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x, co
             float q[E];
             unpack16<T>(ru, q);
 #pragma unroll
-            for (int e = 0; e < E; ++e) v[e] += q[e];
+            for (int e = 0; e < E; ++e) v[e] += q[e] * rs[e];
         }
         if (relu) {
             if (mask) {  // one bit per element (y > 0), one byte per 16-byte vector: what backward needs of y
@@ -399,6 +433,81 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
+// Two BatchNorms that received the SAME output gradient: the bn3 / downsample-BN pair of a Bottleneck's join
+// (out = relu(bn3(conv3) + bn_d(conv_d)), resnet.py:164-172).  One pass reads dz once and writes both input
+// gradients; each BatchNorm's arithmetic is exactly bn_bwd_apply_kernel's.
+struct BnApplySide {
+    const void* x;
+    const float *mean, *invstd, *gamma;
+    const double *gsums, *lsums;
+    float *dgamma, *dbeta;
+    void* dx;
+};
+template <typename T, int U, bool NT>
+__global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const T* __restrict__ dz, BnApplySide a, BnApplySide b,
+                                                            double inv_count, int64_t rows, int C, int tbx, int tby) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    const int tx = threadIdx.x % tbx, ty = threadIdx.x / tbx;
+    const int cv = blockIdx.x * tbx + tx;
+    if (cv * E >= C || ty >= tby) return;
+    const int64_t vo = (int64_t)blockIdx.z * rows * C;
+    dz += vo;
+    const T* xa = reinterpret_cast<const T*>(a.x) + vo;
+    const T* xb = reinterpret_cast<const T*>(b.x) + vo;
+    T* dxa = reinterpret_cast<T*>(a.dx) + vo;
+    T* dxb = reinterpret_cast<T*>(b.dx) + vo;
+    float mua[E], k0a[E], k1a[E], qa[E], mub[E], k0b[E], k1b[E], qb[E];
+    auto coeffs = [&](const BnApplySide& s, float* mu, float* k0, float* k1, float* q) {
+        const int64_t vc = (int64_t)blockIdx.z * C, v2 = (int64_t)blockIdx.z * 2 * C;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int c = cv * E + e;
+            mu[e] = s.mean[vc + c];
+            const float is = s.invstd[vc + c];
+            const float g = s.gamma ? s.gamma[c] : 1.f;
+            k0[e] = g * is;
+            k1[e] = (float)(s.gsums[v2 + c] * inv_count);
+            q[e] = k0[e] * is * (float)(s.gsums[v2 + C + c] * inv_count);
+            if (blockIdx.y == 0 && ty == 0 && s.lsums) {
+                if (s.dbeta) atomicAdd(&s.dbeta[c], (float)s.lsums[v2 + c]);
+                if (s.dgamma) atomicAdd(&s.dgamma[c], (float)s.lsums[v2 + C + c]);
+            }
+        }
+    };
+    coeffs(a, mua, k0a, k1a, qa);
+    coeffs(b, mub, k0b, k1b, qb);
+    const int64_t rstep = (int64_t)gridDim.y * tby;
+    auto finish = [&](int64_t r, const uint4& gu, const uint4& xau, const uint4& xbu) {
+        float g[E], xv[E], o[E];
+        unpack16<T>(gu, g);
+        unpack16<T>(xau, xv);
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] = k0a[e] * (g[e] - k1a[e]) - (xv[e] - mua[e]) * qa[e];
+        stg16<NT>(dxa + r * C + (int64_t)cv * E, pack16<T>(o));
+        unpack16<T>(xbu, xv);
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] = k0b[e] * (g[e] - k1b[e]) - (xv[e] - mub[e]) * qb[e];
+        stg16<NT>(dxb + r * C + (int64_t)cv * E, pack16<T>(o));
+    };
+    int64_t r = (int64_t)blockIdx.y * tby + ty;
+    for (; r + (U - 1) * rstep < rows; r += U * rstep) {
+        uint4 gu[U], xau[U], xbu[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t off = (r + u * rstep) * C + (int64_t)cv * E;
+            gu[u] = ldg16<NT>(dz + off);
+            xau[u] = ldg16<NT>(xa + off);
+            xbu[u] = ldg16<NT>(xb + off);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) finish(r + u * rstep, gu[u], xau[u], xbu[u]);
+    }
+    for (; r < rows; r += rstep) {
+        const int64_t off = r * C + (int64_t)cv * E;
+        finish(r, ldg16<false>(dz + off), ldg16<false>(xa + off), ldg16<false>(xb + off));
+    }
+}
+
 // Row-walk tuning knobs (environment, read once): SM3_BN_UNROLL[_ACT|_RED|_APP] in {1,2,4,8}, SM3_BN_NT in {0,1}.
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
@@ -458,7 +567,7 @@ extern "C" int sm3_bn_finalize(const double* sums, int groups, int views, double
                                int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean,
                                float* save_invstd, void* stream) {
     if (!sums || !scale || !shift || C <= 0 || count <= 0 || groups < 1 || views < 1) return SM3_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((4 * C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, groups, views,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((16 * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, groups, views,
                        count, C, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift,
                        save_mean, save_invstd);
     SM3_CHECK_LAUNCH();
@@ -475,10 +584,11 @@ extern "C" int sm3_bn_eval_scale_shift(const float* gamma, const float* beta, co
     return 0;
 }
 
-extern "C" int sm3_bn_act(int dtype, const void* x, const float* scale, const float* shift, const void* residual,
-                          int relu, int out_f32, void* y, uint8_t* relu_mask, int64_t rows, int C, int views,
-                          void* stream) {
+static int bn_act_impl(int dtype, const void* x, const float* scale, const float* shift, const void* residual,
+                       const float* res_scale, const float* res_shift, int relu, int out_f32, void* y,
+                       uint8_t* relu_mask, int64_t rows, int C, int views, void* stream) {
     if (!x || !scale || !shift || !y || rows <= 0 || C <= 0 || views < 1) return SM3_EINVAL;
+    if ((res_scale != nullptr) != (res_shift != nullptr) || (res_scale && !residual)) return SM3_EINVAL;
     if (dtype != SM3_F32 && dtype != SM3_BF16) return SM3_EDTYPE;
     const int E = dtype == SM3_F32 ? 4 : 8;
     if (C % E) return SM3_EALIGN;
@@ -488,17 +598,33 @@ extern "C" int sm3_bn_act(int dtype, const void* x, const float* scale, const fl
 #define SM3_ACT(U, NT)                                                                                            \
     if (dtype == SM3_F32) /* f32 storage: the two output forms coincide */                                        \
         hipLaunchKernelGGL((bn_act_kernel<float, false, U, NT>), grid, block, 0, st, (const float*)x, scale, shift, \
-                           (const float*)residual, relu, y, relu_mask, rows, C, w.tbx, w.tby);                    \
+                           (const float*)residual, res_scale, res_shift, relu, y, relu_mask, rows, C, w.tbx, w.tby); \
     else if (out_f32)                                                                                             \
         hipLaunchKernelGGL((bn_act_kernel<bf16_t, true, U, NT>), grid, block, 0, st, (const bf16_t*)x, scale,     \
-                           shift, (const bf16_t*)residual, relu, y, relu_mask, rows, C, w.tbx, w.tby);            \
+                           shift, (const bf16_t*)residual, res_scale, res_shift, relu, y, relu_mask, rows, C,     \
+                           w.tbx, w.tby);                                                                         \
     else                                                                                                          \
         hipLaunchKernelGGL((bn_act_kernel<bf16_t, false, U, NT>), grid, block, 0, st, (const bf16_t*)x, scale,    \
-                           shift, (const bf16_t*)residual, relu, y, relu_mask, rows, C, w.tbx, w.tby)
+                           shift, (const bf16_t*)residual, res_scale, res_shift, relu, y, relu_mask, rows, C,     \
+                           w.tbx, w.tby)
     SM3_BN_DISPATCH(0, SM3_ACT);
 #undef SM3_ACT
     SM3_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int sm3_bn_act(int dtype, const void* x, const float* scale, const float* shift, const void* residual,
+                          int relu, int out_f32, void* y, uint8_t* relu_mask, int64_t rows, int C, int views,
+                          void* stream) {
+    return bn_act_impl(dtype, x, scale, shift, residual, nullptr, nullptr, relu, out_f32, y, relu_mask, rows, C, views,
+                       stream);
+}
+
+extern "C" int sm3_bn_add_bn_act(int dtype, const void* x, const float* scale, const float* shift, const void* x2,
+                                 const float* scale2, const float* shift2, int relu, void* y, uint8_t* relu_mask,
+                                 int64_t rows, int C, int views, void* stream) {
+    if (!x2 || !scale2 || !shift2) return SM3_EINVAL;
+    return bn_act_impl(dtype, x, scale, shift, x2, scale2, shift2, relu, 0, y, relu_mask, rows, C, views, stream);
 }
 
 static int bwd_gy(int64_t rows) {
@@ -562,6 +688,33 @@ extern "C" int sm3_bn_bwd_apply(int dtype, const void* dz, const void* x, const 
                            dbeta, (bf16_t*)dx, rows, C, w.tbx, w.tby)
     SM3_BN_DISPATCH(2, SM3_APP);
 #undef SM3_APP
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_bn_bwd_apply2(int dtype, const void* dz, double count, const sm3_bn_apply_side* a,
+                                 const sm3_bn_apply_side* b, int64_t rows, int C, int views, void* stream) {
+    if (!dz || !a || !b || rows <= 0 || C <= 0 || count <= 0 || views < 1) return SM3_EINVAL;
+    for (const sm3_bn_apply_side* s : {a, b})
+        if (!s->x || !s->mean || !s->invstd || !s->global_sums || !s->dx) return SM3_EINVAL;
+    if (dtype != SM3_F32 && dtype != SM3_BF16) return SM3_EDTYPE;
+    const int E = dtype == SM3_F32 ? 4 : 8;
+    if (C % E) return SM3_EALIGN;
+    const RowWalk w = make_walk(rows, C / E, 8192, views);
+    dim3 grid(w.gx, w.gy, views), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const BnApplySide sa = {a->x, a->mean, a->invstd, a->gamma, a->global_sums, a->local_sums, a->dgamma, a->dbeta, a->dx};
+    const BnApplySide sb = {b->x, b->mean, b->invstd, b->gamma, b->global_sums, b->local_sums, b->dgamma, b->dbeta, b->dx};
+    // half the unroll of the single form: three input streams per row instead of two
+#define SM3_APP2(U, NT)                                                                                            \
+    if (dtype == SM3_F32)                                                                                          \
+        hipLaunchKernelGGL((bn_bwd_apply2_kernel<float, (U > 4 ? 4 : U), NT>), grid, block, 0, st, (const float*)dz, sa, sb, \
+                           1.0 / count, rows, C, w.tbx, w.tby);                                                    \
+    else                                                                                                           \
+        hipLaunchKernelGGL((bn_bwd_apply2_kernel<bf16_t, (U > 4 ? 4 : U), NT>), grid, block, 0, st, (const bf16_t*)dz, sa, sb, \
+                           1.0 / count, rows, C, w.tbx, w.tby)
+    SM3_BN_DISPATCH(2, SM3_APP2);
+#undef SM3_APP2
     SM3_CHECK_LAUNCH();
     return 0;
 }

@@ -1,5 +1,4 @@
-// Pieces shared by the gather-GEMM convolution kernels (conv_igemm.hip: 128-row tiles, 4 waves;
-// conv_igemm_v2.hip: persistent 256x128 tiles, 8 waves, 3-stage LDS-DMA ring).
+// Pieces shared by the gather-GEMM convolution kernels (conv_igemm.hip: 128-row tiles, 4 waves; conv_wgrad.hip).
 #pragma once
 #include "common.h"
 

@@ -172,6 +172,175 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restr
     }
 }
 
+// Stem: BatchNorm + ReLU + max-pool in one pass (resnet.py:295-297 bn1 -> relu -> maxpool).  Reads the pre-BN stem
+// output once (window overlap comes from L2) and writes only the pooled map and its argmax bytes: the post-ReLU
+// stem activation -- the largest tensor of the network -- is never stored.  Every window value is rounded to T
+// before the comparison, so maxima and tie-breaks are exactly those of sm3_bn_act followed by sm3_maxpool3x3s2_fwd.
+// n_per_view: images per view (scale/shift are [views][C]).
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, T* __restrict__ y,
+                                                                  uint8_t* __restrict__ argmax, int N, int H, int W, int C,
+                                                                  int Ho, int Wo, int n_per_view, uint32_t total,
+                                                                  const PixDiv dv) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        int c, n, oy, ox;
+        uint32_t pix32;
+        split_index(idx, dv, c, pix32, n, oy, ox);
+        const int64_t pix = pix32;
+        const int view = n / n_per_view;
+        float sc[E], sh[E], best[E];
+        int arg[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            sc[e] = scale[view * C + c * E + e];
+            sh[e] = shift[view * C + c * E + e];
+            best[e] = -INFINITY;
+            arg[e] = -1;
+        }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int iy = oy * 2 - 1 + kh;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ix = ox * 2 - 1 + kw;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                float v[E];
+                unpack16<T>(*reinterpret_cast<const uint4*>(x + (((int64_t)n * H + iy) * W + ix) * C + (int64_t)c * E), v);
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const float a = ElemTraits<T>::round(fmaxf(v[e] * sc[e] + sh[e], 0.f));
+                    if (a > best[e] || arg[e] < 0) {
+                        best[e] = a;
+                        arg[e] = kh * 3 + kw;
+                    }
+                }
+            }
+        }
+        *reinterpret_cast<uint4*>(y + pix * C + (int64_t)c * E) = pack16<T>(best);
+        if (argmax) {
+            uint8_t* a = argmax + pix * C + (int64_t)c * E;
+            if constexpr (E == 8) {
+                *reinterpret_cast<uint2*>(a) = make_uint2(
+                    (unsigned)arg[0] | ((unsigned)arg[1] << 8) | ((unsigned)arg[2] << 16) | ((unsigned)arg[3] << 24),
+                    (unsigned)arg[4] | ((unsigned)arg[5] << 8) | ((unsigned)arg[6] << 16) | ((unsigned)arg[7] << 24));
+            } else {
+                *reinterpret_cast<unsigned*>(a) =
+                    (unsigned)arg[0] | ((unsigned)arg[1] << 8) | ((unsigned)arg[2] << 16) | ((unsigned)arg[3] << 24);
+            }
+        }
+    }
+}
+
+// Backward of that chain up to BatchNorm-backward phase 1, in one pass over the stem-sized tensors: gathers the
+// pooled gradient through the argmax bytes (as maxpool_bwd_kernel), masks it with the ReLU recomputed from the
+// pre-BN tensor (x*scale + shift > 0), stores dz and emits the per-block partial sums of (dz, dz * xhat) in the
+// layout of sm3_bn_bwd_reduce.  Replaces maxpool_bwd + bn_bwd_reduce: one write and one read of the gradient of
+// the largest activation fewer, and no ReLU mask was ever stored.
+// grid (vectors per pixel / tbx, row groups, views); rows = pixels of ONE view.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bn_bwd_kernel(const uint8_t* __restrict__ argmax, const T* __restrict__ dy,
+                                                             const T* __restrict__ x, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, T* __restrict__ dz,
+                                                             float* __restrict__ partials, int H, int W, int C, int Ho,
+                                                             int Wo, int n_per_view, int64_t rows, int tbx, int tby,
+                                                             const FastDiv div_hw, const FastDiv div_w) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    __shared__ float sred[256 * 2 * 8];
+    const int tx = threadIdx.x % tbx, ty = threadIdx.x / tbx;
+    const int cv = blockIdx.x * tbx + tx;
+    const bool active = (cv * E < C) && (ty < tby);
+    const int view = blockIdx.z;
+    float s1[E], s2[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) s1[e] = s2[e] = 0.f;
+    if (active) {
+        float sc[E], sh[E], mu[E], is[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            sc[e] = scale[view * C + cv * E + e];
+            sh[e] = shift[view * C + cv * E + e];
+            mu[e] = mean[view * C + cv * E + e];
+            is[e] = invstd[view * C + cv * E + e];
+        }
+        const int64_t rstep = (int64_t)gridDim.y * tby;
+        for (int64_t r = (int64_t)blockIdx.y * tby + ty; r < rows; r += rstep) {
+            const uint32_t nl = fdiv((uint32_t)r, div_hw);
+            const uint32_t rem = (uint32_t)r - nl * div_hw.d;
+            const int iy = (int)fdiv(rem, div_w), ix = (int)(rem - (uint32_t)iy * div_w.d);
+            const int64_t n = (int64_t)view * n_per_view + nl;
+            const int64_t pix = (int64_t)view * rows + r;
+            const uint4 xu = ldg16<true>(x + pix * C + (int64_t)cv * E);
+            float g[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) g[e] = 0.f;
+            const int oy_lo = iy / 2, oy_hi = min(Ho - 1, (iy + 1) / 2);
+            const int ox_lo = ix / 2, ox_hi = min(Wo - 1, (ix + 1) / 2);
+            for (int oy = oy_lo; oy <= oy_hi; ++oy)
+                for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                    const int self = (iy - (oy * 2 - 1)) * 3 + (ix - (ox * 2 - 1));
+                    const int64_t o = ((n * Ho + oy) * Wo + ox) * C + (int64_t)cv * E;
+                    unsigned a[2];
+                    if constexpr (E == 8) {
+                        const uint2 q = *reinterpret_cast<const uint2*>(argmax + o);
+                        a[0] = q.x;
+                        a[1] = q.y;
+                    } else {
+                        a[0] = *reinterpret_cast<const unsigned*>(argmax + o);
+                        a[1] = 0;
+                    }
+                    float d[E];
+                    unpack16<T>(*reinterpret_cast<const uint4*>(dy + o), d);
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
+                        if ((int)((a[e >> 2] >> (8 * (e & 3))) & 0xff) == self) g[e] += d[e];
+                }
+            float xv[E];
+            unpack16<T>(xu, xv);
+#pragma unroll
+            for (int e = 0; e < E; ++e) g[e] = (xv[e] * sc[e] + sh[e] > 0.f) ? g[e] : 0.f;
+            const uint4 packed = pack16<T>(g);
+            stg16<true>(dz + pix * C + (int64_t)cv * E, packed);
+            float gr[E];
+            unpack16<T>(packed, gr);  // sums of the STORED (rounded) dz: what the apply pass will read
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                s1[e] += gr[e];
+                s2[e] += gr[e] * (xv[e] - mu[e]) * is[e];
+            }
+        }
+    }
+    float* mine = sred + threadIdx.x * 2 * E;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        mine[e] = s1[e];
+        mine[E + e] = s2[e];
+    }
+    __syncthreads();
+    if (ty == 0 && cv * E < C) {
+        for (int j = 1; j < tby; ++j) {
+            const float* o = sred + (j * tbx + tx) * 2 * E;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                s1[e] += o[e];
+                s2[e] += o[E + e];
+            }
+        }
+        float* pv = partials + (int64_t)view * gridDim.y * 2 * C;
+        float* p1 = pv + ((int64_t)blockIdx.y * 2 + 0) * C + (int64_t)cv * E;
+        float* p2 = pv + ((int64_t)blockIdx.y * 2 + 1) * C + (int64_t)cv * E;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            p1[e] = s1[e];
+            p2[e] = s2[e];
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ x, float* __restrict__ f32,
                                                           T* __restrict__ ft, int N, int HW, int C) {
@@ -343,6 +512,58 @@ extern "C" int sm3_maxpool3x3s2_bwd(int dtype, const uint8_t* argmax, const void
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(g), dim3(256), 0, st, argmax, (const float*)dy, (float*)dx, N, H, W, C, Ho, Wo, (uint32_t)total, dv),
                hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, argmax, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo, (uint32_t)total, dv));
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_bn_relu_maxpool_fwd(int dtype, const void* x, const float* scale, const float* shift, void* y,
+                                       uint8_t* argmax, int N, int H, int W, int C, int views, void* stream) {
+    if (!x || !scale || !shift || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || views < 1 || N % views) return SM3_EINVAL;
+    if (dtype != SM3_F32 && dtype != SM3_BF16) return SM3_EDTYPE;
+    const int E = dtype == SM3_F32 ? 4 : 8;
+    if (C % E) return SM3_EALIGN;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int64_t total = (int64_t)N * Ho * Wo * (C / E);
+    if (total >= 0x7fffffffLL) return SM3_EINVAL;
+    const unsigned g = grid_for(total, 256, 1 << 20);
+    hipStream_t st = (hipStream_t)stream;
+    const PixDiv dv = make_pixdiv(C / E, Wo, Ho);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, scale, shift, (float*)y, argmax, N, H, W, C, Ho, Wo, N / views, (uint32_t)total, dv),
+               hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, scale, shift, (bf16_t*)y, argmax, N, H, W, C, Ho, Wo, N / views, (uint32_t)total, dv));
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_maxpool_bn_bwd_partial_rows(int N, int H, int W, int views) {
+    if (N <= 0 || H <= 0 || W <= 0 || views < 1 || N % views) return SM3_EINVAL;
+    int64_t gy = ((int64_t)(N / views) * H * W + 63) / 64;
+    return (int)(gy > 1024 ? 1024 : gy);
+}
+
+extern "C" int sm3_maxpool_bn_bwd(int dtype, const uint8_t* argmax, const void* dy, const void* x, const float* scale,
+                                  const float* shift, const float* mean, const float* invstd, void* dz,
+                                  float* partials, int N, int H, int W, int C, int views, void* stream) {
+    if (!argmax || !dy || !x || !scale || !shift || !mean || !invstd || !dz || !partials) return SM3_EINVAL;
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || views < 1 || N % views) return SM3_EINVAL;
+    if (dtype != SM3_F32 && dtype != SM3_BF16) return SM3_EDTYPE;
+    const int E = dtype == SM3_F32 ? 4 : 8;
+    if (C % E || C / E > 256) return SM3_EALIGN;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int64_t rows = (int64_t)(N / views) * H * W;
+    if (rows * views >= 0x7fffffffLL) return SM3_EINVAL;
+    const int cvecs = C / E;
+    int tbx = 1;
+    while (tbx < cvecs && tbx < 256) tbx <<= 1;  // power of two >= cvecs (idle lanes when C/E is not one)
+    const int tby = 256 / tbx;
+    const int gx = (cvecs + tbx - 1) / tbx;
+    const int gy = sm3_maxpool_bn_bwd_partial_rows(N, H, W, views);
+    hipStream_t st = (hipStream_t)stream;
+    const FastDiv dhw = make_fastdiv((uint32_t)(H * W)), dw = make_fastdiv((uint32_t)W);
+    dim3 grid(gx, gy, views);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(maxpool_bn_bwd_kernel<float>, grid, dim3(256), 0, st, argmax, (const float*)dy, (const float*)x, scale, shift, mean, invstd, (float*)dz, partials, H, W, C, Ho, Wo, N / views, rows, tbx, tby, dhw, dw),
+               hipLaunchKernelGGL(maxpool_bn_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, argmax, (const bf16_t*)dy, (const bf16_t*)x, scale, shift, mean, invstd, (bf16_t*)dz, partials, H, W, C, Ho, Wo, N / views, rows, tbx, tby, dhw, dw));
     SM3_CHECK_LAUNCH();
     return 0;
 }

@@ -1,0 +1,392 @@
+// Direct 7x7 / stride 2 / pad 3 stem convolution on MFMA (gfx950), forward and weight gradient, straight from the
+// NCHW fp32 image batch the loader delivers -- no im2col matrix in HBM (the round-1 path wrote and re-read a
+// [N*Ho*Wo, 192] matrix: 1.2 GB per view at B = 256, the largest tensor of the step and the one that capped the
+// two-views-in-one-batch mode at B <= 256).
+//
+//   y[n, oy, ox, co] = sum_{kh, kw, c} x[n, c, 2*oy - 3 + kh, 2*ox - 3 + kw] * w[co][kh][kw][c]
+//
+// One tile = up to 128 consecutive output pixels of one output row (n, oy).  Its 7 x 3 input rows ("groups"
+// g = kh*3 + c) are staged in LDS as fp32 with zero padding; group g's row holds columns ix = 2*x0 - 3 + j.
+// K is ordered (g, kw) with kw padded to 8: the 8 k-values of one MFMA operand fragment are then 8 CONSECUTIVE
+// floats of a staged row (A[pixel][8h + j] = row[g = 2*ks + h][2*px + j]), read with four ds_read_b64 and rounded
+// to bf16 in registers -- the im2col matrix exists only as those fragments.  The filter bank (64 x 176 bf16 in the
+// same K order, the 8th tap and the 22nd group zero) lives in registers for the whole kernel.
+// Forward epilogue: bf16 NHWC rows + per-tile BatchNorm partial sums, as the gather-GEMM's.
+//
+// Weight gradient: dW[co][k] = sum_pixels dxo[pix][co] * patch[pix][k] with the pixel axis as the MFMA K; the
+// dxo operand is the stem BatchNorm's input gradient, computed on the fly from dz and the saved pre-BN output
+// (dx = g*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)): sm3_bn_bwd_apply's arithmetic) while the tile is staged --
+// the stem has no data gradient, so that tensor has exactly one consumer and is never written to HBM.
+//
+// Reference call sites replaced: nn.Conv2d(3, 64, 7, 2, 3) forward (src/models/resnet.py:208-210,294) and its
+// autograd weight gradient, plus phase 2 of bn1's backward (resnet.py:211,295).
+#include "common.h"
+
+namespace {
+
+constexpr int PW = 264;   // floats per staged row: 2*127 + 8 = 262 needed
+constexpr int NG = 21;    // (kh, c) groups
+constexpr int KS = 11;    // MFMA K-steps of 16 = two groups; group 21 does not exist (zero fragment)
+constexpr int KPAD = KS * 16;  // 176
+constexpr int OUT_PITCH = 144;  // bytes per pixel row of the staged output tile (64 bf16 + 16: bank spread)
+
+struct StemTile {
+    int n, oy, x0;
+};
+__device__ __forceinline__ StemTile decode_tile(long t, int xblocks, int Ho) {
+    StemTile s;
+    const int xb = (int)(t % xblocks);
+    const long r = t / xblocks;
+    s.oy = (int)(r % Ho);
+    s.n = (int)(r / Ho);
+    s.x0 = xb * 128;
+    return s;
+}
+
+// 7 x 3 input rows of a tile -> LDS (fp32, zero padded); row g = kh*3 + c, column j <-> ix = 2*x0 - 3 + j.
+// Thread t owns column t of every row (and, for t < 168, one of the 8 tail columns 256..263 of row t/8).  Split into
+// a load half (22 independent global loads into registers) and a store half: the kernels issue the loads of tile
+// i+1 before the MFMA loop of tile i and store them after its epilogue, so the memory latency of a tile (15 us when
+// the staging was a plain load-store loop: hipcc keeps ONE load in flight per thread there) hides under the
+// previous tile's compute.
+struct PatchRegs {
+    float v[NG];
+    float vt;
+};
+__device__ __forceinline__ void load_patch(PatchRegs& r, const float* __restrict__ x, const StemTile& t, int H, int W) {
+    const int tid = threadIdx.x;
+    const float* xn = x + (long)t.n * 3 * H * W;
+    const int ix = 2 * t.x0 - 3 + tid;
+    const bool okx = (unsigned)ix < (unsigned)W;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int kh = g / 3, c = g - 3 * kh;  // compile-time after unrolling
+        const int iy = 2 * t.oy - 3 + kh;
+        const bool ok = okx && (unsigned)iy < (unsigned)H;
+        r.v[g] = ok ? xn[((long)c * H + iy) * W + ix] : 0.f;
+    }
+    r.vt = 0.f;
+    if (tid < NG * 8) {
+        const int gt = tid >> 3, jt = 256 + (tid & 7);
+        const int kh = gt / 3, c = gt - 3 * kh;
+        const int iy = 2 * t.oy - 3 + kh, ixt = 2 * t.x0 - 3 + jt;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ixt < (unsigned)W) r.vt = xn[((long)c * H + iy) * W + ixt];
+    }
+}
+__device__ __forceinline__ void store_patch(float* patch, const PatchRegs& r) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) patch[g * PW + tid] = r.v[g];
+    if (tid < NG * 8) patch[(tid >> 3) * PW + 256 + (tid & 7)] = r.vt;
+}
+
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const uint4* __restrict__ w,
+                                                       bf16_t* __restrict__ y, float* __restrict__ partials, int N,
+                                                       int H, int W, int Ho, int Wo, int xblocks, long tiles) {
+    __shared__ __attribute__((aligned(16))) float patch[NG * PW];  // reused as the bf16 output tile
+    __shared__ float sStat[4][64][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+
+    // filter bank fragments: lane (col, h) holds w[nb*32 + col][ks*16 + 8h .. +8) for every (ks, nb)
+    uint4 bfrag[KS][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) bfrag[ks][nb] = w[((nb * 32 + col) * KPAD + ks * 16 + 8 * h) / 8];
+
+    PatchRegs pre;
+    if ((long)blockIdx.x < tiles) {
+        load_patch(pre, x, decode_tile(blockIdx.x, xblocks, Ho), H, W);
+        store_patch(patch, pre);
+    }
+    __syncthreads();
+    for (long t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const StemTile tl = decode_tile(t, xblocks, Ho);
+        const long tn = t + gridDim.x;
+        if (tn < tiles) load_patch(pre, x, decode_tile(tn, xblocks, Ho), H, W);  // lands during this tile's compute
+        f32x16 acc[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+        const int px = 32 * wave + col;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int g = 2 * ks + h;
+            uint4 a = make_uint4(0, 0, 0, 0);
+            if (g < NG) {
+                const float2* src = reinterpret_cast<const float2*>(patch + g * PW + 2 * px);
+                const float2 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+                a = make_uint4(pack_bf16x2(v0.x, v0.y), pack_bf16x2(v1.x, v1.y), pack_bf16x2(v2.x, v2.y),
+                               pack_bf16x2(v3.x, v3.y));
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                                 __builtin_bit_cast(bf16x8, bfrag[ks][nb]), acc[nb], 0, 0, 0);
+        }
+        __syncthreads();  // everyone is done reading the patch: its LDS becomes the output tile
+        char* sOut = reinterpret_cast<char*>(patch);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const uint16_t b = f32_to_bf16(acc[nb][r]);
+                *reinterpret_cast<uint16_t*>(sOut + row * OUT_PITCH + (nb * 32 + col) * 2) = b;
+                if (tl.x0 + row < Wo) {  // statistics of the stored (rounded) values of real pixels only
+                    const float v = bf16_to_f32(b);
+                    s1 += v;
+                    s2 += v * v;
+                }
+            }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 32) {
+                sStat[wave][nb * 32 + lane][0] = s1;
+                sStat[wave][nb * 32 + lane][1] = s2;
+            }
+        }
+        __syncthreads();
+        if (partials && tid < 128) {
+            const int c = tid & 63, st = tid >> 6;
+            partials[(t * 2 + st) * 64 + c] = (sStat[0][c][st] + sStat[1][c][st]) + (sStat[2][c][st] + sStat[3][c][st]);
+        }
+        {
+            const int ch = tid & 7, r0 = tid >> 3;
+            const long pix0 = ((long)tl.n * Ho + tl.oy) * Wo + tl.x0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = r0 + 32 * k;
+                if (tl.x0 + row < Wo)
+                    stg16<true>(y + (pix0 + row) * 64 + ch * 8,
+                                *reinterpret_cast<const uint4*>(sOut + row * OUT_PITCH + ch * 16));
+            }
+        }
+        __syncthreads();  // the output tile has been read: the next tile's patch may overwrite it
+        if (tn < tiles) store_patch(patch, pre);
+        __syncthreads();
+    }
+}
+
+// ---- weight gradient with the BatchNorm-backward apply fused into the dxo operand -----------------------------
+struct StemWgradParams {
+    const float* x;
+    const bf16_t* dz;
+    const bf16_t* xo;
+    const float *mean, *invstd, *gamma;       // [views][64], [views][64], [64] (nullable)
+    const double *gsums, *lsums;              // [views][128]
+    float *dgamma, *dbeta;                    // nullable
+    float* dw;                                // [64][147] fp32, accumulated into
+    double inv_count;
+    int N, H, W, Ho, Wo, xblocks, n_per_view, views;
+    long tiles;
+};
+
+__device__ __forceinline__ uint32_t swz128(int row) { return (uint32_t)((row >> 1) & 1) << 6; }
+
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradParams p) {
+    __shared__ __attribute__((aligned(16))) float patch[NG * PW];
+    __shared__ __attribute__((aligned(16))) char sD[128 * 128];  // dxo tile [pixel][64 co] bf16, swizzled for tr reads
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cb = wave & 1, kb0 = 3 * (wave >> 1);  // this wave: co block cb, k blocks kb0 .. kb0+2
+
+    if (blockIdx.x == 0 && tid < 64 && p.lsums) {  // parameter gradients of bn1 from the LOCAL sums, once
+        for (int v = 0; v < p.views; ++v) {
+            if (p.dbeta) atomicAdd(&p.dbeta[tid], (float)p.lsums[v * 128 + tid]);
+            if (p.dgamma) atomicAdd(&p.dgamma[tid], (float)p.lsums[v * 128 + 64 + tid]);
+        }
+    }
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // staging role: 16-byte channel vector ch of rows r0 + 32k
+    const int ch = tid & 7, r0 = tid >> 3;
+    float mu[8], k0[8], k1[8], q[8];
+    int cur_view = -1;
+
+    // transposing-read addressing of the dxo tile (as conv_wgrad.hip): 16-lane group g16 reads a 4(k) x 16(co) block
+    const int g16 = lane >> 4, ii = lane & 15, qq = ii >> 2, pq = ii & 3, hh = g16 >> 1;
+    const uint32_t ra_off = (uint32_t)(8 * hh + qq) * 128u + ((((uint32_t)(cb * 32 + 16 * (g16 & 1) + 4 * pq)) * 2u) ^ swz128(qq));
+    // B operand: lane (n = lane & 31, half h) of k block kb supplies k = 32*kb + n -> (group, kw)
+    const int bn = lane & 31, bh = lane >> 5;
+
+    // operand loads of a tile: its patch and the (dz, xo) rows of this thread's channel vector
+    PatchRegs pre;
+    uint4 gu[4], xu[4];
+    auto load_tile = [&](const StemTile& tl) {
+        const long pix0 = ((long)tl.n * p.Ho + tl.oy) * p.Wo + tl.x0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = r0 + 32 * k;
+            const bool ok = tl.x0 + row < p.Wo;
+            gu[k] = ok ? ldg16<true>(p.dz + (pix0 + row) * 64 + ch * 8) : make_uint4(0, 0, 0, 0);
+            xu[k] = ok ? ldg16<true>(p.xo + (pix0 + row) * 64 + ch * 8) : make_uint4(0, 0, 0, 0);
+        }
+        load_patch(pre, p.x, tl, p.H, p.W);
+    };
+    auto store_tile = [&](const StemTile& tl) {
+        const int view = tl.n / p.n_per_view;
+        if (view != cur_view) {  // tiles are view-major: happens once or twice per workgroup
+            cur_view = view;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = ch * 8 + e;
+                mu[e] = p.mean[view * 64 + c];
+                const float is = p.invstd[view * 64 + c];
+                const float g = p.gamma ? p.gamma[c] : 1.f;
+                k0[e] = g * is;
+                k1[e] = (float)(p.gsums[view * 128 + c] * p.inv_count);
+                q[e] = k0[e] * is * (float)(p.gsums[view * 128 + 64 + c] * p.inv_count);
+            }
+        }
+        store_patch(patch, pre);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = r0 + 32 * k;
+            uint4 out = make_uint4(0, 0, 0, 0);
+            if (tl.x0 + row < p.Wo) {
+                float g[8], xv[8];
+                unpack16<bf16_t>(gu[k], g);
+                unpack16<bf16_t>(xu[k], xv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] = k0[e] * (g[e] - k1[e]) - (xv[e] - mu[e]) * q[e];
+                out = pack16<bf16_t>(g);
+            }
+            *reinterpret_cast<uint4*>(sD + row * 128 + (((uint32_t)ch * 16u) ^ swz128(row))) = out;
+        }
+    };
+    if ((long)blockIdx.x < p.tiles) {
+        const StemTile t0 = decode_tile(blockIdx.x, p.xblocks, p.Ho);
+        load_tile(t0);
+        store_tile(t0);
+    }
+    for (long t = blockIdx.x; t < p.tiles; t += gridDim.x) {
+        const long tn = t + gridDim.x;
+        StemTile nx = {0, 0, 0};
+        if (tn < p.tiles) {
+            nx = decode_tile(tn, p.xblocks, p.Ho);
+            load_tile(nx);  // in flight during this tile's MFMA loop
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {  // 16 pixels per step
+            const char* a0 = sD + ra_off + s * 16 * 128;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * 128));
+            const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+            const uint4 fa = make_uint4(l2.x, l2.y, h2.x, h2.y);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int k = 32 * (kb0 + j) + bn;
+                const int g = k >> 3, kw = k & 7;
+                uint4 fb = make_uint4(0, 0, 0, 0);
+                if (g < NG) {
+                    const float* src = patch + g * PW + 2 * (16 * s + 8 * bh) + kw;
+                    fb = make_uint4(pack_bf16x2(src[0], src[2]), pack_bf16x2(src[4], src[6]), pack_bf16x2(src[8], src[10]),
+                                    pack_bf16x2(src[12], src[14]));
+                }
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa),
+                                                                __builtin_bit_cast(bf16x8, fb), acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();  // everyone is done reading this tile's operands
+        if (tn < p.tiles) store_tile(nx);
+    }
+
+    const int frow = lane & 31, fh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int k = 32 * (kb0 + j) + frow;
+        const int g = k >> 3, kw = k & 7;
+        if (g >= NG || kw >= 7) continue;
+        const int kh = g / 3, c = g - 3 * kh;
+        const int kcol = (kh * 7 + kw) * 3 + c;  // master layout [co][kh][kw][c]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            atomicAdd(p.dw + co * 147 + kcol, acc[j][r]);
+        }
+    }
+}
+
+// master [64][kh][kw][c] fp32 -> bf16 [64][176], k = (kh*3 + c)*8 + kw, zero where kw == 7 or k >= 168
+__global__ void stem_weight_prep_kernel(const float* __restrict__ w, bf16_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 64 * KPAD) return;
+    const int co = i / KPAD, k = i - co * KPAD;
+    const int g = k >> 3, kw = k & 7;
+    float v = 0.f;
+    if (g < NG && kw < 7) {
+        const int kh = g / 3, c = g - 3 * kh;
+        v = w[co * 147 + (kh * 7 + kw) * 3 + c];
+    }
+    out[i].v = f32_to_bf16(v);
+}
+
+int stem_geometry(int N, int H, int W, int& Ho, int& Wo, int& xblocks, long& tiles) {
+    if (N <= 0 || H <= 0 || W <= 0) return SM3_EINVAL;
+    Ho = (H - 1) / 2 + 1;
+    Wo = (W - 1) / 2 + 1;
+    xblocks = (Wo + 127) / 128;
+    tiles = (long)N * Ho * xblocks;
+    if ((long)N * 3 * H * W >= 0x7fffffffL || (long)N * Ho * Wo >= 0x7fffffffL / 64) return SM3_EINVAL;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int sm3_stem_partial_rows(int N, int H, int W) {
+    int Ho, Wo, xb;
+    long tiles;
+    if (stem_geometry(N, H, W, Ho, Wo, xb, tiles)) return SM3_EINVAL;
+    return tiles > 0x7fffffffL ? SM3_EINVAL : (int)tiles;
+}
+
+extern "C" int sm3_stem_weight_prep(int dtype, const float* w_master, void* w_stem, void* stream) {
+    if (!w_master || !w_stem) return SM3_EINVAL;
+    if (dtype != SM3_BF16) return SM3_EDTYPE;
+    hipLaunchKernelGGL(stem_weight_prep_kernel, dim3((64 * KPAD + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_master,
+                       (bf16_t*)w_stem);
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_stem_conv_fwd(int dtype, const float* x_nchw, const void* w_stem, void* y, float* stat_partials, int N,
+                                 int H, int W, void* stream) {
+    if (!x_nchw || !w_stem || !y) return SM3_EINVAL;
+    if (dtype != SM3_BF16) return SM3_EDTYPE;  // the exact-f32 parity mode keeps the im2col + gather-GEMM path
+    int Ho, Wo, xb;
+    long tiles;
+    if (int rc = stem_geometry(N, H, W, Ho, Wo, xb, tiles)) return rc;
+    const unsigned grid = (unsigned)(tiles < 768 ? tiles : 768);  // persistent: 3 workgroups per CU (136 VGPRs)
+    hipLaunchKernelGGL(stem_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x_nchw, (const uint4*)w_stem,
+                       (bf16_t*)y, stat_partials, N, H, W, Ho, Wo, xb, tiles);
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_stem_wgrad_bn(int dtype, const float* x_nchw, const void* dz, const void* xo, const float* mean,
+                                 const float* invstd, const float* gamma, const double* global_sums, double count,
+                                 const double* local_sums, float* dgamma, float* dbeta, float* dw, int N, int H, int W,
+                                 int views, void* stream) {
+    if (!x_nchw || !dz || !xo || !mean || !invstd || !global_sums || !dw || count <= 0 || views < 1 || N % views)
+        return SM3_EINVAL;
+    if (dtype != SM3_BF16) return SM3_EDTYPE;
+    StemWgradParams p;
+    if (int rc = stem_geometry(N, H, W, p.Ho, p.Wo, p.xblocks, p.tiles)) return rc;
+    p.x = x_nchw; p.dz = (const bf16_t*)dz; p.xo = (const bf16_t*)xo;
+    p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.gsums = global_sums; p.lsums = local_sums;
+    p.dgamma = dgamma; p.dbeta = dbeta; p.dw = dw; p.inv_count = 1.0 / count;
+    p.N = N; p.H = H; p.W = W; p.n_per_view = N / views; p.views = views;
+    const unsigned grid = (unsigned)(p.tiles < 768 ? p.tiles : 768);
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    SM3_CHECK_LAUNCH();
+    return 0;
+}

@@ -32,6 +32,12 @@ class BnBwdFuse(C.Structure):
                 ("partial_row_offset_view1", C.c_int32)]
 
 
+class BnApplySide(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("gamma", C.c_void_p),
+                ("global_sums", C.c_void_p), ("local_sums", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+                ("dx", C.c_void_p)]
+
+
 class WPrepItem(C.Structure):
     _fields_ = [("w", C.c_void_p), ("w_fwd", C.c_void_p), ("w_dgrad", C.c_void_p),
                 ("Co", C.c_int32), ("taps", C.c_int32), ("Ci", C.c_int32), ("ld_fwd", C.c_int32)]
@@ -54,10 +60,19 @@ SIGNATURES = {
     "sm3_bn_finalize": [_P, _I, _I, _D, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
     "sm3_bn_eval_scale_shift": [_P, _P, _P, _P, _F, _I, _P, _P, _P],
     "sm3_bn_act": [_I, _P, _P, _P, _P, _I, _I, _P, _P, _L, _I, _I, _P],
+    "sm3_bn_add_bn_act": [_I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P],
+    "sm3_bn_bwd_apply2": [_I, _P, _D, _P, _P, _L, _I, _I, _P],
+    "sm3_bn_relu_maxpool_fwd": [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "sm3_maxpool_bn_bwd_partial_rows": [_I, _I, _I, _I],
+    "sm3_maxpool_bn_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "sm3_bn_bwd_partial_rows": [_L, _I],
     "sm3_bn_bwd_reduce": [_I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _I, _P],
     "sm3_bn_bwd_apply": [_I, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _P, _L, _I, _I, _P],
     "sm3_stem_im2col": [_I, _P, _P, _I, _I, _I, _I, _P],
+    "sm3_stem_partial_rows": [_I, _I, _I],
+    "sm3_stem_weight_prep": [_I, _P, _P, _P],
+    "sm3_stem_conv_fwd": [_I, _P, _P, _P, _P, _I, _I, _I, _P],
+    "sm3_stem_wgrad_bn": [_I, _P, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "sm3_maxpool3x3s2_fwd": [_I, _P, _P, _P, _I, _I, _I, _I, _P],
     "sm3_maxpool3x3s2_bwd": [_I, _P, _P, _P, _I, _I, _I, _I, _P],
     "sm3_weight_prep_batch": [_I, _P, _I, _P],

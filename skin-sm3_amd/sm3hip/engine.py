@@ -104,10 +104,10 @@ class ConvUnit:
         self.w_fwd = self.w_dgrad = None
         self._fd, self._dd = {}, {}
 
-    def alloc(self, dtype, device, need_dgrad=True):
+    def alloc(self, dtype, device, need_dgrad=True, direct_stem=False):
         tdt = ops.TORCH_DTYPE[dtype]
         if self.stem:
-            self.w_fwd = torch.empty(self.Co, STEM_KPAD, dtype=tdt, device=device)
+            self.w_fwd = torch.empty(self.Co, ops.STEM_KDIRECT if direct_stem else STEM_KPAD, dtype=tdt, device=device)
         else:
             self.w_fwd = torch.empty(self.Co, self.taps * self.Ci, dtype=tdt, device=device)
             if need_dgrad:
@@ -155,7 +155,7 @@ class BNUnit:
 class Rec:
     """What one conv+BN(+act) application saves for backward."""
     __slots__ = ("cu", "bu", "N", "H", "W", "Ho", "Wo", "x_in", "xo", "mean", "invstd", "y", "relu", "mask", "V",
-                 "frozen_stats")
+                 "frozen_stats", "scale", "shift")
 
 
 class EncoderPlan:
@@ -272,6 +272,9 @@ class SM3Engine:
         self._side = {}
         self.two_streams = True
         self._streams, self._streams_dev = None, None
+        # 7x7 stem straight from the NCHW images (csrc/stem.hip): no im2col matrix, BN-backward apply fused into the
+        # stem weight gradient.  bf16 only; the exact-f32 parity mode keeps im2col + gather-GEMM.
+        self.direct_stem = self.dtype == SM3_BF16 and _os.environ.get("SM3_DIRECT_STEM", "1") != "0"
 
     # ---- setup ---------------------------------------------------------------------------
     def _all_conv_units(self):
@@ -293,7 +296,7 @@ class SM3Engine:
             self.store.rebind_if_needed()
         if not self._allocated:
             for cu in self._all_conv_units():
-                cu.alloc(self.dtype, device)
+                cu.alloc(self.dtype, device, direct_stem=self.direct_stem)
             self._allocated = True
         self.buffers = dict(self.module.named_buffers())
         for name, b in self.buffers.items():
@@ -304,19 +307,23 @@ class SM3Engine:
         """fp32 master -> `dtype` filter banks (forward and data-gradient order); once per step, one launch."""
         key = (self.store.flat_p.data_ptr(), len(self.store.names))
         if getattr(self, "_wprep_key", None) != key:
-            items = []
+            items, self._direct_stems = [], []
             for cu in self._all_conv_units():
                 wname = cu.name + ".weight"
                 if wname not in self.store.offsets:
                     continue  # projector dropped by the caller (mlc_train.py:344-346 sets them to None)
                 m = self.store.flat2d(self.store.flat_p, wname)
-                if cu.stem:
+                if cu.stem and self.direct_stem:
+                    self._direct_stems.append((m, cu.w_fwd))
+                elif cu.stem:
                     items.append((m, cu.w_fwd, None, cu.Co, 1, 147, STEM_KPAD))
                 else:
                     items.append((m, cu.w_fwd, cu.w_dgrad, cu.Co, cu.taps, cu.Ci, cu.taps * cu.Ci))
             self._wprep_table = ops.weight_prep_table(items, self.store.flat_p.device)
             self._wprep_key = key
         ops.weight_prep_batch(self.dtype, self._wprep_table)
+        for m, w in self._direct_stems:
+            ops.stem_weight_prep(self.dtype, m, w)
 
     def _work(self, key, numel, dtype=torch.float32):
         """Stream-ordered scratch; one set per execution lane (branch stream) so concurrent branches never share."""
@@ -392,28 +399,43 @@ class SM3Engine:
         return self.store.flat2d(self.store.flat_g, name)
 
     # ---- conv + BN (+residual) (+ReLU) ---------------------------------------------------
-    def conv_bn(self, cu, bu, x, N, H, W, relu, residual=None, train=True, save=None, out_f32=False, y_out=None):
+    def conv_bn(self, cu, bu, x, N, H, W, relu, residual=None, train=True, save=None, out_f32=False, y_out=None,
+                apply=True, scale_shift=None, res_affine=None):
         """One conv + BatchNorm (+residual) (+ReLU) unit on N images.  With self._V == 2 the batch is two views back
-        to back (N = 2B): one convolution launch, BatchNorm statistics / running-statistics updates per view."""
+        to back (N = 2B): one convolution launch, BatchNorm statistics / running-statistics updates per view.
+        apply=False: stop after the statistics -- returns the pre-BatchNorm tensor, scale/shift are left in
+        `scale_shift` for the consumer that applies them (the join of a downsample block, the stem's fused
+        BN+ReLU+maxpool).  res_affine=(scale2, shift2): `residual` is such a pre-BatchNorm tensor and is normalised
+        inside this unit's apply pass."""
         dev = x.device
-        d = cu.fwd_desc(self.dtype, N, H, W)
-        Ho, Wo = (1, 1) if cu.stem else (d.Ho, d.Wo)
-        rows = N if cu.stem else N * Ho * Wo
+        direct = cu.stem and self.direct_stem  # x is the NCHW fp32 image batch, N / H / W its geometry
+        if direct:
+            d = None
+            Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+            rows = N * Ho * Wo
+        else:
+            d = cu.fwd_desc(self.dtype, N, H, W)
+            Ho, Wo = (1, 1) if cu.stem else (d.Ho, d.Wo)
+            rows = N if cu.stem else N * Ho * Wo
         C = cu.Co
         V = self._V if train else 1
         rows_v = rows // V
         xo = torch.empty(rows, C, dtype=self.tdt, device=dev)
-        scale, shift = self._work("scale", 2 * 2048), self._work("shift", 2 * 2048)
+        scale, shift = scale_shift if scale_shift is not None else (self._work("scale", 2 * 2048),
+                                                                    self._work("shift", 2 * 2048))
         gamma = self._p(bu.name + ".weight") if bu.affine else None
         beta = self._p(bu.name + ".bias") if bu.affine else None
         rm, rv = self.buffers[bu.name + ".running_mean"], self.buffers[bu.name + ".running_var"]
         mean = invstd = None
         if train:
-            prow = ops.conv_partial_rows(d)
-            if V > 1 and (rows_v % 128 or prow % V):
+            prow = ops.stem_partial_rows(N, H, W) if direct else ops.conv_partial_rows(d)
+            if V > 1 and ((rows_v % 128 and not direct) or prow % V):
                 raise ValueError("two views in one batch need a multiple of 128 rows per view")
             partials = self._work("partials", prow * 2 * C)
-            ops.conv_gemm(d, x, cu.w_fwd, xo, None, partials)
+            if direct:
+                ops.stem_conv_fwd(self.dtype, x, cu.w_fwd, xo, partials)
+            else:
+                ops.conv_gemm(d, x, cu.w_fwd, xo, None, partials)
             count, groups = rows_v, 1
             if self.stat_sync is not None:
                 sums = self._work("sums", 2 * 2 * 2048, torch.float64)
@@ -437,7 +459,7 @@ class SM3Engine:
                 if ev is None:
                     ev = self._bn_ev[bu.name] = torch.cuda.Event()
                 ev.record()
-        elif save is None and not out_f32:
+        elif save is None and not out_f32 and apply:
             # inference: conv + running-statistics BN (+residual) (+ReLU) in ONE launch, no pre-BN tensor in HBM
             ops.bn_eval_scale_shift(gamma, beta, rm, rv, BN_EPS, C, scale, shift)
             if y_out is None:
@@ -445,27 +467,39 @@ class SM3Engine:
             ops.conv_bn_act_eval(d, x, cu.w_fwd, scale, shift, residual, relu, y_out)
             return y_out, Ho, Wo
         else:
-            ops.conv_gemm(d, x, cu.w_fwd, xo, None, None)
+            if direct:
+                ops.stem_conv_fwd(self.dtype, x, cu.w_fwd, xo, None)
+            else:
+                ops.conv_gemm(d, x, cu.w_fwd, xo, None, None)
             ops.bn_eval_scale_shift(gamma, beta, rm, rv, BN_EPS, C, scale, shift)
             if save is not None:
                 # eval-mode BatchNorm inside an autograd graph (module.eval() with trainable parameters): the statistics
                 # are constants, so backward is dx = gamma * invstd * dz and d(gamma), d(beta) are the plain sums --
                 # bn_backward runs the same kernels with the batch-statistics terms zeroed (Rec.frozen_stats)
                 mean, invstd = rm.clone(), torch.rsqrt(rv + BN_EPS)
-        if y_out is None:
-            y_out = torch.empty(rows, C, dtype=torch.float32 if out_f32 else self.tdt, device=dev)
         mask = None
-        if save is not None and relu:  # 1 bit per element of (y > 0): what backward needs instead of re-reading y
-            mask = torch.empty(rows * C // (16 // ops._sz(self.dtype)), dtype=torch.uint8, device=dev)
-        ops.bn_act(self.dtype, xo, scale, shift, residual, relu, y_out, rows_v, C, out_f32=out_f32, mask=mask, views=V)
+        if not apply:  # the consumer applies scale/shift (and the ReLU, if any)
+            y_out = None
+        else:
+            if y_out is None:
+                y_out = torch.empty(rows, C, dtype=torch.float32 if out_f32 else self.tdt, device=dev)
+            if save is not None and relu:  # 1 bit per element of (y > 0): what backward needs instead of re-reading y
+                mask = torch.empty(rows * C // (16 // ops._sz(self.dtype)), dtype=torch.uint8, device=dev)
+            if res_affine is not None:
+                ops.bn_add_bn_act(self.dtype, xo, scale, shift, residual, res_affine[0], res_affine[1], relu, y_out,
+                                  rows_v, C, mask=mask, views=V)
+            else:
+                ops.bn_act(self.dtype, xo, scale, shift, residual, relu, y_out, rows_v, C, out_f32=out_f32, mask=mask,
+                           views=V)
         if save is not None:
             r = Rec()
             r.cu, r.bu, r.N, r.H, r.W, r.Ho, r.Wo = cu, bu, N, H, W, Ho, Wo
             r.x_in, r.xo, r.mean, r.invstd, r.y, r.relu, r.mask = x, xo, mean, invstd, y_out, relu, mask
             r.V = V
             r.frozen_stats = not train
+            r.scale = r.shift = None
             save.append(r)
-        return y_out, Ho, Wo
+        return (y_out if apply else xo), Ho, Wo
 
     def bn_backward(self, r, dy, keep_dz, fused_rows=None):
         """dy: gradient w.r.t. the unit's output (post-activation).  Masks it in place when the unit has a
@@ -482,6 +516,20 @@ class SM3Engine:
                               mask=r.mask if r.relu else None, views=V)
         else:  # [V][fused_rows][2][C], left by the data-gradient launches
             prow, bpart = fused_rows, self._ws[(self._lane, "fz_partials")]
+        lsums, gsums, count = self._bn_backward_sums(r, bpart, prow)
+        dxo = torch.empty_like(r.xo) if (keep_dz or _APPLY_OUT_OF_PLACE) else dy
+        gamma = self._p(r.bu.name + ".weight") if r.bu.affine else None
+        dgamma = self._g(r.bu.name + ".weight") if r.bu.affine else None
+        dbeta = self._g(r.bu.name + ".bias") if r.bu.affine else None
+        ops.bn_bwd_apply(self.dtype, dy, r.xo, r.mean, r.invstd, gamma, gsums, count, lsums, dgamma, dbeta, dxo,
+                         rows, C, views=V)
+        return dxo, dy
+
+    def _bn_backward_sums(self, r, bpart, prow):
+        """Partial sums [V][prow][2][C] of (dz, dz*xhat) -> (local sums, global sums, global count per channel): the
+        part of BatchNorm backward between its two passes, including the SyncBN exchange."""
+        C, V = r.cu.Co, r.V
+        rows = r.xo.shape[0] // V
         lsums = self._work("lsums", 2 * 2 * 2048, torch.float64)
         ops.bn_stats_reduce(bpart, prow, C, lsums, views=V)
         gsums, count = lsums, rows
@@ -493,13 +541,47 @@ class SM3Engine:
             gsums[: V * 2 * C].copy_(lsums[: V * 2 * C])
             self.stat_sync(gsums[: V * 2 * C])
             count = rows * self.world_size
-        dxo = torch.empty_like(r.xo) if (keep_dz or _APPLY_OUT_OF_PLACE) else dy
-        gamma = self._p(r.bu.name + ".weight") if r.bu.affine else None
-        dgamma = self._g(r.bu.name + ".weight") if r.bu.affine else None
-        dbeta = self._g(r.bu.name + ".bias") if r.bu.affine else None
-        ops.bn_bwd_apply(self.dtype, dy, r.xo, r.mean, r.invstd, gamma, gsums, count, lsums, dgamma, dbeta, dxo,
-                         rows, C, views=V)
-        return dxo, dy
+        return lsums, gsums, count
+
+    def bn_backward_join(self, r3, rd, dy, fused_rows=None):
+        """The two BatchNorms of a downsample block's join (out = relu(bn3(conv3) + bn_d(conv_d)), resnet.py:164-172)
+        receive the same masked gradient dz: phase 1 of both, ONE statistics exchange for both under SyncBN, and one
+        apply pass that reads dz once and writes both input gradients (the downsample one in place over dz).
+        Returns (d conv3 output, d downsample-conv output)."""
+        C, V = r3.cu.Co, r3.V
+        rows = r3.xo.shape[0] // V
+        if fused_rows is None:
+            prow = ops.bn_bwd_partial_rows(rows, C)
+            bpart = self._work("partials", V * prow * 2 * C)
+            ops.bn_bwd_reduce(self.dtype, dy, None, r3.xo, r3.mean, r3.invstd, dy, rows, C, bpart, mask=r3.mask, views=V)
+        else:
+            prow, bpart = fused_rows, self._ws[(self._lane, "fz_partials")]
+        n = V * 2 * C
+        lsums = self._work("lsums2", 2 * 2 * 2 * 2048, torch.float64)  # [bn3 | downsample][V][2C]
+        ops.bn_stats_reduce(bpart, prow, C, lsums, views=V)
+        prow_d = ops.bn_bwd_partial_rows(rows, C)
+        dpart = self._work("partials_d", V * prow_d * 2 * C)
+        ops.bn_bwd_reduce(self.dtype, dy, None, rd.xo, rd.mean, rd.invstd, None, rows, C, dpart, views=V)  # dy is dz now
+        ops.bn_stats_reduce(dpart, prow_d, C, lsums[n:], views=V)
+        gsums, count = lsums, rows
+        if r3.frozen_stats:
+            gsums = self._work("zsums2", 2 * 2 * 2 * 2048, torch.float64)
+            gsums.zero_()
+        elif self.stat_sync is not None:
+            gsums = self._work("gsums2", 2 * 2 * 2 * 2048, torch.float64)
+            gsums[: 2 * n].copy_(lsums[: 2 * n])
+            self.stat_sync(gsums[: 2 * n])  # one all-reduce for the two BatchNorms (and both views)
+            count = rows * self.world_size
+        dx3 = torch.empty_like(r3.xo)
+
+        def side(r, g, l, dx):
+            aff = r.bu.affine
+            return dict(x=r.xo, mean=r.mean, invstd=r.invstd, gamma=self._p(r.bu.name + ".weight") if aff else None,
+                        gsums=g, lsums=l, dgamma=self._g(r.bu.name + ".weight") if aff else None,
+                        dbeta=self._g(r.bu.name + ".bias") if aff else None, dx=dx)
+        ops.bn_bwd_apply2(self.dtype, dy, count, side(r3, gsums[:n], lsums[:n], dx3),
+                          side(rd, gsums[n: 2 * n], lsums[n: 2 * n], dy), rows, C, views=V)
+        return dx3, dy
 
     def _wgrad(self, cu, r, dxo):
         """Weight gradient on the lane's side stream: nothing on the critical path (data gradient -> BN backward ->
@@ -600,24 +682,50 @@ class SM3Engine:
         N, _, H, W = x.shape
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         recs = [] if save is not None else None
-        cols = torch.empty(N * Ho * Wo, STEM_KPAD, dtype=self.tdt, device=x.device)
-        ops.stem_im2col(self.dtype, x, cols, STEM_KPAD)
-        y, _, _ = self.conv_bn(plan.stem, plan.stem_bn, cols, N * Ho * Wo, 1, 1, True, None, train, recs)
+        if self.direct_stem:
+            stem_in, sN, sH, sW = x, N, H, W  # the 7x7 convolution reads the NCHW images directly
+        else:
+            cols = torch.empty(N * Ho * Wo, STEM_KPAD, dtype=self.tdt, device=x.device)
+            ops.stem_im2col(self.dtype, x, cols, STEM_KPAD)
+            stem_in, sN, sH, sW = cols, N * Ho * Wo, 1, 1
+            del cols
         Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
         p = torch.empty(N * Hp * Wp, 64, dtype=self.tdt, device=x.device)
         amax = torch.empty(N * Hp * Wp * 64, dtype=torch.uint8, device=x.device) if save is not None else None
-        ops.maxpool_fwd(self.dtype, y, p, N, Ho, Wo, 64, amax)
+        lazy = train or save is not None  # not the single-launch conv+evalBN inference path
+        if lazy or self.direct_stem:
+            # stem BatchNorm + ReLU + max-pool in ONE pass over the pre-BN stem output: the post-ReLU map (the largest
+            # activation of the network) and its ReLU mask are never stored; backward recomputes the mask
+            V = self._V if train else 1
+            sc = torch.empty(V * 64, dtype=torch.float32, device=x.device)
+            sh = torch.empty(V * 64, dtype=torch.float32, device=x.device)
+            xo, _, _ = self.conv_bn(plan.stem, plan.stem_bn, stem_in, sN, sH, sW, True, None, train, recs,
+                                    apply=False, scale_shift=(sc, sh))
+            if recs is not None:
+                recs[0].scale, recs[0].shift = sc, sh
+            ops.bn_relu_maxpool_fwd(self.dtype, xo, sc, sh, p, N, Ho, Wo, 64, amax, views=V)
+            del xo
+        else:
+            y, _, _ = self.conv_bn(plan.stem, plan.stem_bn, stem_in, sN, sH, sW, True, None, train, recs)
+            ops.maxpool_fwd(self.dtype, y, p, N, Ho, Wo, 64, amax)
+        del stem_in
         cur, h, w = p, Hp, Wp
         block_recs = []
         for blk in plan.blocks:
             br = [] if save is not None else None
             y1, h1, w1 = self.conv_bn(blk["c1"], blk["b1"], cur, N, h, w, True, None, train, br)
             y2, h2, w2 = self.conv_bn(blk["c2"], blk["b2"], y1, N, h1, w1, True, None, train, br)
-            if "cd" in blk:
+            ra = None
+            if "cd" in blk and lazy:
+                # downsample branch: convolution + statistics only; its BatchNorm is applied inside the join below
+                ra = (self._work("scale_d", 2 * 2048), self._work("shift_d", 2 * 2048))
+                idn, _, _ = self.conv_bn(blk["cd"], blk["bd"], cur, N, h, w, False, None, train, br, apply=False,
+                                         scale_shift=ra)
+            elif "cd" in blk:
                 idn, _, _ = self.conv_bn(blk["cd"], blk["bd"], cur, N, h, w, False, None, train, br)
             else:
                 idn = cur
-            y3, h3, w3 = self.conv_bn(blk["c3"], blk["b3"], y2, N, h2, w2, True, idn, train, br)
+            y3, h3, w3 = self.conv_bn(blk["c3"], blk["b3"], y2, N, h2, w2, True, idn, train, br, res_affine=ra)
             block_recs.append(br)
             cur, h, w = y3, h3, w3
         ops.avgpool_fwd(self.dtype, cur, feat_f32, feat_t, N, h * w, plan.out_dim)
@@ -640,7 +748,11 @@ class SM3Engine:
                 r1, r2, rd, r3 = br
             else:
                 (r1, r2, r3), rd = br, None
-            dx3, dz = self.bn_backward(r3, dcur, keep_dz=True, fused_rows=fr)
+            if rd is not None:
+                dx3, dxd = self.bn_backward_join(r3, rd, dcur, fused_rows=fr)
+                dz = None
+            else:
+                dx3, dz = self.bn_backward(r3, dcur, keep_dz=True, fused_rows=fr)
             dy2, fr2 = self.conv_backward(r3, dx3, fuse=r2)
             del dx3
             dx2, _ = self.bn_backward(r2, dy2, keep_dz=False, fused_rows=fr2)
@@ -648,7 +760,6 @@ class SM3Engine:
             del dx2, dy2
             dx1, _ = self.bn_backward(r1, dy1, keep_dz=False, fused_rows=fr1)
             if rd is not None:
-                dxd, _ = self.bn_backward(rd, dz, keep_dz=False)
                 din, _ = self.conv_backward(r1, dx1)
                 self.conv_backward(rd, dxd, into=din)
                 fr = None
@@ -663,10 +774,22 @@ class SM3Engine:
         # maxpool -> stem BN/ReLU -> stem weight gradient (no data gradient: the image needs none)
         Ho, Wo = ctx["stem_hw"]
         rs = ctx["stem"]
-        dy = torch.empty(N * Ho * Wo, 64, dtype=self.tdt, device=dfeat.device)
-        ops.maxpool_bwd(self.dtype, ctx["argmax"], dcur, dy, N, Ho, Wo, 64)
-        dxo, _ = self.bn_backward(rs, dy, keep_dz=False)
-        self.conv_backward(rs, dxo, need_dx=False)
+        # maxpool gradient gather + recomputed ReLU mask + BatchNorm-backward phase 1 in one pass
+        dz = torch.empty(N * Ho * Wo, 64, dtype=self.tdt, device=dfeat.device)
+        prow = ops.maxpool_bn_bwd_partial_rows(N, Ho, Wo, rs.V)
+        part = self._work("fz_partials", rs.V * prow * 2 * 64)
+        ops.maxpool_bn_bwd(self.dtype, ctx["argmax"], dcur, rs.xo, rs.scale, rs.shift, rs.mean, rs.invstd, dz, part,
+                           N, Ho, Wo, 64, views=rs.V)
+        if self.direct_stem:
+            # BatchNorm-backward apply inside the stem weight gradient's operand load: d(conv1 output) never reaches HBM
+            lsums, gsums, count = self._bn_backward_sums(rs, part, prow)
+            bn = rs.bu.name
+            ops.stem_wgrad_bn(self.dtype, rs.x_in, dz, rs.xo, rs.mean, rs.invstd, self._p(bn + ".weight"), gsums, count,
+                              lsums, self._g(bn + ".weight"), self._g(bn + ".bias"), self._g(rs.cu.name + ".weight"),
+                              views=rs.V)
+        else:
+            dxo, _ = self.bn_backward(rs, dz, keep_dz=False, fused_rows=prow)
+            self.conv_backward(rs, dxo, need_dx=False)
         if last_view:
             self._notify(plan.prefix + "conv1", plan.prefix + "layer1.")
 
@@ -723,9 +846,9 @@ class SM3Engine:
             pair = (self.pair_views and train and not split and len(imgs) == 2 and imgs[0].shape == imgs[1].shape
                     and self.pair_ok(B, imgs[0].shape[2], imgs[0].shape[3])
                     # the kernels address a tensor with 32-bit buffer offsets below 3 GB; the largest one is the stem's
-                    # im2col matrix
-                    and 2 * B * ((imgs[0].shape[2] - 1) // 2 + 1) * ((imgs[0].shape[3] - 1) // 2 + 1) * STEM_KPAD
-                    * ops._sz(self.dtype) < 0xC0000000)
+                    # im2col matrix (exact-f32 mode) or the 256-channel layer1 maps (direct stem)
+                    and 2 * B * ((imgs[0].shape[2] - 1) // 2 + 1) * ((imgs[0].shape[3] - 1) // 2 + 1)
+                    * (64 if self.direct_stem else STEM_KPAD) * ops._sz(self.dtype) < 0xC0000000)
             if pair:  # both views as one batch of 2B images (BatchNorm statistics still per view)
                 with self.lane(key, streams):
                     tmp = [] if want_grad else None

@@ -360,6 +360,107 @@ def bn_act(dtype, x, scale, shift, residual, relu, y, rows, Cn, out_f32=False, m
                                      int(out_f32), _ptr(y), _ptr(mask), rows, Cn, views, _stream()), "sm3_bn_act")
 
 
+def bn_add_bn_act(dtype, x, scale, shift, x2, scale2, shift2, relu, y, rows, Cn, mask=None, views=1):
+    """y = relu?(x*scale + shift + x2*scale2 + shift2): the join of a Bottleneck whose identity is a downsample
+    conv + BatchNorm, with BOTH normalisations applied in this one pass (sm3_bn_add_bn_act)."""
+    tdt = TORCH_DTYPE[dtype]
+    for t in (x, x2, y):
+        _chk(t, tdt)
+    for t in (scale, shift, scale2, shift2):
+        _chk(t, torch.float32)
+        if t.numel() < views * Cn:
+            raise ValueError("bn_add_bn_act: scale/shift too small")
+    n = views * rows * Cn
+    if x.numel() != n or x2.numel() != n or y.numel() != n:
+        raise ValueError("bn_add_bn_act: size mismatch")
+    _chk(mask, torch.uint8, "mask")
+    if mask is not None and mask.numel() != n // (16 // _sz(dtype)):
+        raise ValueError("bn_add_bn_act: mask size mismatch")
+    tag = "bn_act"
+    if _PROFILER is not None and getattr(_PROFILER, "detail", False):
+        tag += f"|rows{views * rows}_C{Cn}_res2"
+    with _prof(tag, 0.0, _sz(dtype) * n * 3):
+        check(_lib.load().sm3_bn_add_bn_act(dtype, _ptr(x), _ptr(scale), _ptr(shift), _ptr(x2), _ptr(scale2),
+                                            _ptr(shift2), int(relu), _ptr(y), _ptr(mask), rows, Cn, views, _stream()),
+              "sm3_bn_add_bn_act")
+
+
+def bn_bwd_apply2(dtype, dz, count, side_a, side_b, rows, Cn, views=1):
+    """One pass for two BatchNorms that received the same dz.  side = dict(x, mean, invstd, gamma, gsums, lsums, dgamma,
+    dbeta, dx)."""
+    tdt = TORCH_DTYPE[dtype]
+    _chk(dz, tdt, "dz")
+    n = views * rows * Cn
+    if dz.numel() != n:
+        raise ValueError("bn_bwd_apply2: dz size mismatch")
+    sides = []
+    for sd in (side_a, side_b):
+        for k in ("x", "dx"):
+            _chk(sd[k], tdt, k)
+            if sd[k].numel() != n:
+                raise ValueError(f"bn_bwd_apply2: {k} size mismatch")
+        for k in ("mean", "invstd", "gamma", "dgamma", "dbeta"):
+            _chk(sd.get(k), torch.float32, k)
+        for k in ("gsums", "lsums"):
+            _chk(sd.get(k), torch.float64, k)
+            if sd.get(k) is not None and sd[k].numel() < views * 2 * Cn:
+                raise ValueError("bn_bwd_apply2: sums too small")
+        if sd["mean"].numel() < views * Cn or sd["invstd"].numel() < views * Cn:
+            raise ValueError("bn_bwd_apply2: mean/invstd too small")
+        a = _lib.BnApplySide()
+        a.x, a.mean, a.invstd, a.dx = sd["x"].data_ptr(), sd["mean"].data_ptr(), sd["invstd"].data_ptr(), sd["dx"].data_ptr()
+        a.global_sums = sd["gsums"].data_ptr()
+        for k, f in (("gamma", "gamma"), ("lsums", "local_sums"), ("dgamma", "dgamma"), ("dbeta", "dbeta")):
+            setattr(a, f, sd[k].data_ptr() if sd.get(k) is not None else None)
+        sides.append(a)
+    tag = "bn_bwd_apply"
+    if _PROFILER is not None and getattr(_PROFILER, "detail", False):
+        tag += f"|rows{views * rows}_C{Cn}_dual"
+    with _prof(tag, 0.0, _sz(dtype) * n * 5):
+        check(_lib.load().sm3_bn_bwd_apply2(dtype, _ptr(dz), float(count), C.byref(sides[0]), C.byref(sides[1]), rows, Cn,
+                                            views, _stream()), "sm3_bn_bwd_apply2")
+
+
+def bn_relu_maxpool_fwd(dtype, x, scale, shift, y, N, H, W, Cn, argmax=None, views=1):
+    """Stem: y = maxpool3x3s2(relu(x*scale + shift)) in one pass (sm3_bn_relu_maxpool_fwd)."""
+    tdt = TORCH_DTYPE[dtype]
+    _chk(x, tdt, "x"); _chk(y, tdt, "y"); _chk(scale, torch.float32); _chk(shift, torch.float32); _chk(argmax, torch.uint8)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if x.numel() != N * H * W * Cn or y.numel() != N * Ho * Wo * Cn or N % views:
+        raise ValueError("bn_relu_maxpool_fwd: size mismatch")
+    if scale.numel() < views * Cn or shift.numel() < views * Cn:
+        raise ValueError("bn_relu_maxpool_fwd: scale/shift too small")
+    if argmax is not None and argmax.numel() != y.numel():
+        raise ValueError("bn_relu_maxpool_fwd: argmax size mismatch")
+    with _prof("bn_relu_maxpool", 0.0, _sz(dtype) * (x.numel() + y.numel()) + (y.numel() if argmax is not None else 0)):
+        check(_lib.load().sm3_bn_relu_maxpool_fwd(dtype, _ptr(x), _ptr(scale), _ptr(shift), _ptr(y), _ptr(argmax), N, H, W,
+                                                  Cn, views, _stream()), "sm3_bn_relu_maxpool_fwd")
+
+
+def maxpool_bn_bwd_partial_rows(N, H, W, views=1):
+    return _lib.load().sm3_maxpool_bn_bwd_partial_rows(N, H, W, views)
+
+
+def maxpool_bn_bwd(dtype, argmax, dy, x, scale, shift, mean, invstd, dz, partials, N, H, W, Cn, views=1):
+    """Stem backward: maxpool gradient gather + recomputed ReLU mask + BatchNorm-backward phase 1 (sm3_maxpool_bn_bwd)."""
+    tdt = TORCH_DTYPE[dtype]
+    _chk(argmax, torch.uint8); _chk(dy, tdt, "dy"); _chk(x, tdt, "x"); _chk(dz, tdt, "dz"); _chk(partials, torch.float32)
+    for t in (scale, shift, mean, invstd):
+        _chk(t, torch.float32)
+        if t.numel() < views * Cn:
+            raise ValueError("maxpool_bn_bwd: per-channel vector too small")
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if x.numel() != N * H * W * Cn or dz.numel() != x.numel() or dy.numel() != N * Ho * Wo * Cn or \
+            argmax.numel() != dy.numel() or N % views:
+        raise ValueError("maxpool_bn_bwd: size mismatch")
+    if partials.numel() < views * maxpool_bn_bwd_partial_rows(N, H, W, views) * 2 * Cn:
+        raise ValueError("maxpool_bn_bwd: partials too small")
+    with _prof("maxpool_bn_bwd", 0.0, _sz(dtype) * (2 * x.numel() + dy.numel()) + argmax.numel()):
+        check(_lib.load().sm3_maxpool_bn_bwd(dtype, _ptr(argmax), _ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), _ptr(mean),
+                                             _ptr(invstd), _ptr(dz), _ptr(partials), N, H, W, Cn, views, _stream()),
+              "sm3_maxpool_bn_bwd")
+
+
 def bn_bwd_partial_rows(rows, Cn):
     return _lib.load().sm3_bn_bwd_partial_rows(rows, Cn)
 
@@ -419,6 +520,57 @@ def stem_im2col(dtype, x_nchw, cols, Kpad):
         raise ValueError("cols size mismatch")
     with _prof("stem_im2col", 0.0, 4.0 * x_nchw.numel() + _sz(dtype) * cols.numel()):
         check(_lib.load().sm3_stem_im2col(dtype, _ptr(x_nchw), _ptr(cols), N, H, W, Kpad, _stream()), "sm3_stem_im2col")
+
+
+STEM_KDIRECT = 176  # K of the direct stem's filter bank: (kh, c) groups x 8 (kw padded), 22nd group zero
+
+
+def stem_partial_rows(N, H, W):
+    return _lib.load().sm3_stem_partial_rows(N, H, W)
+
+
+def stem_weight_prep(dtype, w_master, w_stem):
+    _chk(w_master, torch.float32, "w_master"); _chk(w_stem, TORCH_DTYPE[dtype], "w_stem")
+    if w_master.numel() != 64 * 147 or w_stem.numel() != 64 * STEM_KDIRECT:
+        raise ValueError("stem_weight_prep: size mismatch")
+    check(_lib.load().sm3_stem_weight_prep(dtype, _ptr(w_master), _ptr(w_stem), _stream()), "sm3_stem_weight_prep")
+
+
+def stem_conv_fwd(dtype, x_nchw, w_stem, y, partials=None):
+    """Direct 7x7/2 stem convolution from the NCHW fp32 batch (sm3_stem_conv_fwd; bf16 only)."""
+    _chk(x_nchw, torch.float32, "x"); _chk(w_stem, TORCH_DTYPE[dtype], "w_stem"); _chk(y, TORCH_DTYPE[dtype], "y")
+    _chk(partials, torch.float32, "partials")
+    N, Cc, H, W = x_nchw.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if Cc != 3 or w_stem.numel() != 64 * STEM_KDIRECT or y.numel() != N * Ho * Wo * 64:
+        raise ValueError("stem_conv_fwd: size mismatch")
+    if partials is not None and partials.numel() < stem_partial_rows(N, H, W) * 2 * 64:
+        raise ValueError("stem_conv_fwd: partials too small")
+    M = N * Ho * Wo
+    with _prof("stem_conv_fwd", 2.0 * M * 64 * 147, 4.0 * x_nchw.numel() + _sz(dtype) * y.numel()):
+        check(_lib.load().sm3_stem_conv_fwd(dtype, _ptr(x_nchw), _ptr(w_stem), _ptr(y), _ptr(partials), N, H, W, _stream()),
+              "sm3_stem_conv_fwd")
+
+
+def stem_wgrad_bn(dtype, x_nchw, dz, xo, mean, invstd, gamma, gsums, count, lsums, dgamma, dbeta, dw, views=1):
+    """Stem weight gradient with bn1's backward apply fused into the operand load (sm3_stem_wgrad_bn; bf16 only)."""
+    tdt = TORCH_DTYPE[dtype]
+    _chk(x_nchw, torch.float32, "x"); _chk(dz, tdt, "dz"); _chk(xo, tdt, "xo"); _chk(dw, torch.float32, "dw")
+    for t in (mean, invstd, gamma, dgamma, dbeta):
+        _chk(t, torch.float32)
+    _chk(gsums, torch.float64); _chk(lsums, torch.float64)
+    N, Cc, H, W = x_nchw.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if Cc != 3 or dz.numel() != N * Ho * Wo * 64 or xo.numel() != dz.numel() or dw.numel() < 64 * 147 or N % views:
+        raise ValueError("stem_wgrad_bn: size mismatch")
+    if mean.numel() < views * 64 or invstd.numel() < views * 64 or gsums.numel() < views * 128 or \
+            (lsums is not None and lsums.numel() < views * 128):
+        raise ValueError("stem_wgrad_bn: per-channel vector too small")
+    M = N * Ho * Wo
+    with _prof("stem_wgrad_bn", 2.0 * M * 64 * 147, 4.0 * x_nchw.numel() + 2 * _sz(dtype) * dz.numel()):
+        check(_lib.load().sm3_stem_wgrad_bn(dtype, _ptr(x_nchw), _ptr(dz), _ptr(xo), _ptr(mean), _ptr(invstd), _ptr(gamma),
+                                            _ptr(gsums), float(count), _ptr(lsums), _ptr(dgamma), _ptr(dbeta), _ptr(dw),
+                                            N, H, W, views, _stream()), "sm3_stem_wgrad_bn")
 
 
 def maxpool_fwd(dtype, x, y, N, H, W, Cn, argmax=None):

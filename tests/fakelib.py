@@ -18,8 +18,14 @@ class _FakeFn:
             return (d.N * d.Ho * d.Wo + 127) // 128
         if self.name == "sm3_bn_bwd_partial_rows":
             return max(1, min(1024, (int(args[0]) + 63) // 64))
+        if self.name == "sm3_maxpool_bn_bwd_partial_rows":
+            n, h, w, v = (int(a) for a in args)
+            return max(1, min(1024, (n // v * h * w + 63) // 64))
+        if self.name == "sm3_stem_partial_rows":
+            n, h, w = (int(a) for a in args)
+            return n * ((h - 1) // 2 + 1) * (((w - 1) // 2 + 1 + 127) // 128)
         if self.name == "sm3_abi_version":
-            return 2
+            return 3
         return 0
 
 

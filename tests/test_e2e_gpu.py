@@ -115,7 +115,7 @@ def test_gradients(compat_run, golden_dir):
         assert np.linalg.norm(got - ref) <= compat_run["l2_rtol"] * np.linalg.norm(ref), k
         # a ReLU whose pre-activation sits at rounding distance from 0 flips its mask and moves single
         # elements of a BN-bias gradient by a whole dy: bound the bulk, not the outliers
-        assert np.quantile(np.abs(got - ref), 0.99) <= 0.1 * np.abs(ref).max(), k
+        assert np.quantile(np.abs(got - ref), 0.99) <= (0.15 if compat_run["gn_rtol"] > 0.1 else 0.1) * np.abs(ref).max(), k
 
 
 def test_buffers_and_adamw(compat_run, golden_dir):

@@ -80,10 +80,17 @@ def test_engine_dry_run_sequences_and_bucket_schedule(model):
         calls = Counter(fake.calls)
     # 53 convs x 4 encoder passes + 3 linears x (2 in-modal + 4 cross) projector passes
     assert calls["sm3_bn_finalize"] == 53 * 4 + 3 * 6 == 230  # 212 BN2d + 18 BN1d per step
-    assert calls["sm3_conv_wgrad"] == 230
-    assert calls["sm3_bn_bwd_apply"] == 230
+    assert calls["sm3_conv_wgrad"] == 230 - 4 and calls["sm3_stem_wgrad_bn"] == 4  # bf16: direct stem (csrc/stem.hip)
+    # every BatchNorm gets its backward apply: the bn3 / downsample pair of a downsample block in one dual launch
+    # (the stem's is fused into its weight gradient)
+    assert calls["sm3_bn_bwd_apply2"] == 4 * 4 and calls["sm3_bn_bwd_apply"] == 230 - 2 * 16 - 4
+    # ... and its forward apply, except where the consumer applies it: the 16 downsample BatchNorms inside their
+    # block's join (sm3_bn_add_bn_act), the 4 stem BatchNorms inside the fused BN + ReLU + max-pool pass
+    assert calls["sm3_bn_add_bn_act"] == 16 and calls["sm3_bn_act"] == 230 - 16 - 16 - 4
     assert calls["sm3_ntxent_fused"] == 4 and calls["sm3_adamw"] == 1
-    assert calls["sm3_stem_im2col"] == 4 and calls["sm3_maxpool3x3s2_bwd"] == 4
+    assert calls["sm3_stem_conv_fwd"] == 4 and calls["sm3_stem_im2col"] == 0
+    assert calls["sm3_bn_relu_maxpool_fwd"] == 4 and calls["sm3_maxpool_bn_bwd"] == 4
+    assert calls["sm3_maxpool3x3s2_fwd"] == 0 and calls["sm3_maxpool3x3s2_bwd"] == 0
     # bucket coverage
     names = eng.store.names
     covered = Counter()

@@ -50,6 +50,11 @@ CONV_CASES = [
     (16, 64, 256, 56, 56, 1, 1, 0),
     (13, 128, 256, 41, 37, 3, 1, 1),
     (9, 256, 384, 50, 46, 1, 2, 0),
+    # 3x3 / stride 1 with >= 1024 rows and W <= 56: the input-patch kernel (conv3x3_patch.hip): four channel chunks,
+    # the widest map it takes with 64-column tiles, an M tail on an odd map
+    (8, 256, 256, 14, 14, 3, 1, 1),
+    (2, 64, 64, 56, 56, 3, 1, 1),
+    (3, 128, 320, 29, 23, 3, 1, 1),
 ]
 
 
@@ -120,7 +125,9 @@ def test_conv_fwd_dgrad_wgrad(case, dt):
 
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", [(2, 64, 128, 9, 11, 1, 1, 0), (3, 128, 64, 10, 8, 3, 1, 1), (2, 64, 192, 13, 11, 3, 2, 1),
-                                  (12, 256, 128, 57, 50, 1, 1, 0), (8, 128, 64, 66, 62, 3, 2, 1)])
+                                  (12, 256, 128, 57, 50, 1, 1, 0), (8, 128, 64, 66, 62, 3, 2, 1),
+                                  # input-patch kernel, general epilogue: 64- and 128-column tiles, M tails
+                                  (6, 64, 128, 30, 28, 3, 1, 1), (2, 128, 128, 56, 56, 3, 1, 1), (5, 128, 192, 19, 21, 3, 1, 1)])
 def test_dgrad_with_fused_bn_backward_phase1(case, dt):
     """sm3_conv_dgrad_bnfuse == sm3_conv_gather_gemm followed by sm3_bn_bwd_reduce (dz bit-exact, sums equal)."""
     ops = _ops()
@@ -530,3 +537,204 @@ def test_fused_dgrad_two_views_equal_two_launches(case, dt):
     torch.cuda.synchronize()
     assert torch.equal(out2, out1)
     assert torch.equal(part2, part1)
+
+
+# ------------------------------------------------------------------------------------------
+# round 2: BatchNorm passes folded into their consumers
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("views", [1, 2])
+def test_join_with_downsample_bn_in_one_pass(dt, views):
+    """sm3_bn_add_bn_act == sm3_bn_act on the downsample output followed by sm3_bn_act(+residual) on bn3's (to the
+    one extra rounding the materialised identity costs), and against fp64; sm3_bn_bwd_apply2 == two sm3_bn_bwd_apply."""
+    ops = _ops()
+    code = ops.dtype_code(dt)
+    rows, Cn = 384, 256
+    E = 4 if dt == torch.float32 else 8
+    g = torch.Generator().manual_seed(11 + views)
+    D = dev()
+    x = rnd(torch.randn(views * rows, Cn, generator=g) * 2, dt)
+    x2 = rnd(torch.randn(views * rows, Cn, generator=g) + 0.3, dt)
+    sc, sh = torch.rand(views, Cn, generator=g) + 0.5, torch.randn(views, Cn, generator=g) * 0.2
+    sc2, sh2 = torch.rand(views, Cn, generator=g) + 0.5, torch.randn(views, Cn, generator=g) * 0.2
+    ref = torch.cat([F.relu(x[v * rows:(v + 1) * rows].double() * sc[v].double() + sh[v].double()
+                            + x2[v * rows:(v + 1) * rows].double() * sc2[v].double() + sh2[v].double())
+                     for v in range(views)])
+    xd, x2d = x.to(dt).to(D), x2.to(dt).to(D)
+    y = torch.empty(views * rows, Cn, dtype=dt, device=D)
+    mask = torch.empty(views * rows * Cn // E, dtype=torch.uint8, device=D)
+    ops.bn_add_bn_act(code, xd, sc.to(D), sh.to(D), x2d, sc2.to(D), sh2.to(D), True, y, rows, Cn, mask=mask, views=views)
+    torch.cuda.synchronize()
+    assert (y.float().cpu().double() - ref).abs().max().item() < tol(dt, ref.abs().max().item())
+    bits = ((mask.cpu().unsqueeze(1) >> torch.arange(E, dtype=torch.uint8)) & 1).reshape(views * rows, Cn).bool()
+    assert torch.equal(bits, y.float().cpu() > 0)
+    # two-pass form
+    idn = torch.empty_like(y)
+    ops.bn_act(code, x2d, sc2.to(D), sh2.to(D), None, False, idn, rows, Cn, views=views)
+    y2 = torch.empty_like(y)
+    ops.bn_act(code, xd, sc.to(D), sh.to(D), idn, True, y2, rows, Cn, views=views)
+    torch.cuda.synchronize()
+    assert (y.float() - y2.float()).abs().max().item() <= tol(dt, ref.abs().max().item())
+
+    # backward: the same dz into both BatchNorms
+    dz = rnd(torch.randn(views * rows, Cn, generator=g), dt).to(dt).to(D)
+    sides = []
+    for xx in (xd, x2d):
+        mean = torch.randn(views, Cn, generator=g).to(D) * 0.1
+        invstd = (torch.rand(views, Cn, generator=g) + 0.5).to(D)
+        gamma = (torch.rand(Cn, generator=g) + 0.5).to(D)
+        gs = torch.randn(views, 2 * Cn, generator=g, dtype=torch.float64).to(D)
+        ls = torch.randn(views, 2 * Cn, generator=g, dtype=torch.float64).to(D)
+        sides.append(dict(x=xx, mean=mean, invstd=invstd, gamma=gamma, gsums=gs, lsums=ls))
+    out = {}
+    for mode in ("single", "dual"):
+        dx = [torch.empty_like(dz), torch.empty_like(dz)]
+        dg = [torch.zeros(Cn, device=D), torch.zeros(Cn, device=D)]
+        db = [torch.zeros(Cn, device=D), torch.zeros(Cn, device=D)]
+        if mode == "single":
+            for i, sd in enumerate(sides):
+                ops.bn_bwd_apply(code, dz, sd["x"], sd["mean"], sd["invstd"], sd["gamma"], sd["gsums"], rows, sd["lsums"],
+                                 dg[i], db[i], dx[i], rows, Cn, views=views)
+        else:
+            a, b = (dict(sd, dgamma=dg[i], dbeta=db[i], dx=dx[i]) for i, sd in enumerate(sides))
+            ops.bn_bwd_apply2(code, dz, rows, a, b, rows, Cn, views=views)
+        torch.cuda.synchronize()
+        out[mode] = (dx, dg, db)
+    for i in range(2):
+        if dt == torch.bfloat16:
+            assert torch.equal(out["single"][0][i], out["dual"][0][i])
+        else:  # f32: the two kernels contract k0*(dz-k1) - (x-mu)*q into FMAs differently (1 ulp)
+            assert torch.allclose(out["single"][0][i], out["dual"][0][i], rtol=2e-6, atol=2e-6)
+        assert torch.allclose(out["single"][1][i], out["dual"][1][i], rtol=1e-6, atol=1e-6)
+        assert torch.allclose(out["single"][2][i], out["dual"][2][i], rtol=1e-6, atol=1e-6)
+    # in place over dz on the second side (how the engine calls it)
+    dzc = dz.clone()
+    dx0 = torch.empty_like(dz)
+    a, b = (dict(sd, dgamma=None, dbeta=None, lsums=None, dx=d) for sd, d in zip(sides, (dx0, dzc)))
+    ops.bn_bwd_apply2(code, dzc, rows, a, b, rows, Cn, views=views)
+    torch.cuda.synchronize()
+    assert torch.equal(dx0, out["dual"][0][0]) and torch.equal(dzc, out["dual"][0][1])
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("geom", [(2, 13, 11, 1), (4, 16, 16, 2), (6, 9, 14, 2)])
+def test_stem_bn_relu_maxpool_fused_equals_separate_kernels(dt, geom):
+    """sm3_bn_relu_maxpool_fwd == sm3_bn_act + sm3_maxpool3x3s2_fwd (values and argmax bit for bit);
+    sm3_maxpool_bn_bwd == sm3_maxpool3x3s2_bwd + sm3_bn_bwd_reduce with the stored ReLU mask (dz bit for bit, sums equal)."""
+    ops = _ops()
+    code = ops.dtype_code(dt)
+    N, H, W, views = geom
+    Cn = 64
+    E = 4 if dt == torch.float32 else 8
+    D = dev()
+    g = torch.Generator().manual_seed(N * 100 + H)
+    x = rnd(torch.randn(N, H, W, Cn, generator=g) * 1.5, dt).to(dt).to(D)
+    sc = (torch.randn(views, Cn, generator=g) * 0.8).to(D)  # negative scales too
+    sh = (torch.randn(views, Cn, generator=g) * 0.3).to(D)
+    mean = (torch.randn(views, Cn, generator=g) * 0.1).to(D)
+    invstd = (torch.rand(views, Cn, generator=g) + 0.5).to(D)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    rows = N // views * H * W
+    # separate kernels
+    y = torch.empty(N * H * W, Cn, dtype=dt, device=D)
+    mask = torch.empty(N * H * W * Cn // E, dtype=torch.uint8, device=D)
+    ops.bn_act(code, x.reshape(-1, Cn), sc, sh, None, True, y, rows, Cn, mask=mask, views=views)
+    p_ref = torch.empty(N * Ho * Wo, Cn, dtype=dt, device=D)
+    a_ref = torch.empty(N * Ho * Wo * Cn, dtype=torch.uint8, device=D)
+    ops.maxpool_fwd(code, y, p_ref, N, H, W, Cn, a_ref)
+    # fused
+    p = torch.empty_like(p_ref)
+    a = torch.empty_like(a_ref)
+    ops.bn_relu_maxpool_fwd(code, x.reshape(-1, Cn), sc, sh, p, N, H, W, Cn, a, views=views)
+    torch.cuda.synchronize()
+    assert torch.equal(p, p_ref) and torch.equal(a, a_ref)
+    # against torch (fp64)
+    ref = torch.cat([F.relu(x[v * (N // views):(v + 1) * (N // views)].double().cpu() * sc[v].double().cpu()
+                            + sh[v].double().cpu()) for v in range(views)])
+    ref_p = F.max_pool2d(ref.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).reshape(-1, Cn)
+    assert (p.float().cpu().double() - ref_p).abs().max().item() < tol(dt, ref_p.abs().max().item())
+
+    # backward
+    dyp = rnd(torch.randn(N * Ho * Wo, Cn, generator=g), dt).to(dt).to(D)
+    dy_full = torch.empty(N * H * W, Cn, dtype=dt, device=D)
+    ops.maxpool_bwd(code, a_ref, dyp, dy_full, N, H, W, Cn)
+    prow_ref = ops.bn_bwd_partial_rows(rows, Cn)
+    part_ref = torch.zeros(views * prow_ref * 2 * Cn, device=D)
+    dz_ref = torch.empty_like(dy_full)
+    ops.bn_bwd_reduce(code, dy_full, None, x.reshape(-1, Cn), mean, invstd, dz_ref, rows, Cn, part_ref, mask=mask, views=views)
+    prow = ops.maxpool_bn_bwd_partial_rows(N, H, W, views)
+    part = torch.full((views * prow * 2 * Cn,), float("nan"), device=D)
+    dz = torch.empty_like(dy_full)
+    ops.maxpool_bn_bwd(code, a, dyp, x.reshape(-1, Cn), sc, sh, mean, invstd, dz, part, N, H, W, Cn, views=views)
+    torch.cuda.synchronize()
+    assert torch.equal(dz, dz_ref)
+    s_ref = part_ref.reshape(views, prow_ref, 2, Cn).double().sum(1).cpu()
+    s_new = part.reshape(views, prow, 2, Cn).double().sum(1).cpu()
+    assert torch.allclose(s_new, s_ref, rtol=1e-4, atol=1e-3 * float(s_ref.abs().max()))
+
+
+@pytest.mark.parametrize("geom", [(3, 30, 26, 1), (4, 64, 64, 2), (2, 45, 270, 1)])
+def test_direct_stem_forward_and_fused_weight_gradient(geom):
+    """csrc/stem.hip (bf16): sm3_stem_conv_fwd against F.conv2d(7x7/2/3) in fp64 on bf16-rounded operands, its BatchNorm
+    partial sums against the stored output; sm3_stem_wgrad_bn against conv2d_weight of the BatchNorm input gradient
+    computed in fp64 from the same (dz, xo, sums).  Odd sizes, two views, and an image wider than one 128-pixel tile."""
+    ops = _ops()
+    dt = torch.bfloat16
+    code = ops.dtype_code(dt)
+    N, H, W, views = geom
+    D = dev()
+    g = torch.Generator().manual_seed(N * 1000 + H)
+    x = torch.randn(N, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) / math.sqrt(147)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    w_master = w.permute(0, 2, 3, 1).contiguous().to(D)  # [64][kh][kw][c]
+    w_stem = torch.empty(64, ops.STEM_KDIRECT, dtype=dt, device=D)
+    ops.stem_weight_prep(code, w_master.reshape(64, 147), w_stem)
+    y = torch.empty(N * Ho * Wo, 64, dtype=dt, device=D)
+    prow = ops.stem_partial_rows(N, H, W)
+    part = torch.full((prow, 2, 64), float("nan"), device=D)
+    ops.stem_conv_fwd(code, x.to(D), w_stem, y, part)
+    torch.cuda.synchronize()
+    ref = F.conv2d(rnd(x, dt).double(), rnd(w, dt).double(), stride=2, padding=3)
+    got = y.float().cpu().reshape(N, Ho, Wo, 64).permute(0, 3, 1, 2).double()
+    assert (got - ref).abs().max().item() < tol(dt, ref.abs().max().item())
+    yv = y.float().double()
+    ps = part.double().sum(0)
+    assert torch.allclose(ps[0], yv.sum(0), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(ps[1], (yv * yv).sum(0), rtol=1e-4, atol=1e-3)
+    # per-view partial rows are contiguous (tiles are image-major)
+    pv = part.reshape(views, prow // views, 2, 64).double().sum(1)
+    rows_v = N // views * Ho * Wo
+    for v in range(views):
+        assert torch.allclose(pv[v, 0], yv[v * rows_v:(v + 1) * rows_v].sum(0), rtol=1e-4, atol=1e-3)
+
+    # weight gradient with the BatchNorm-backward apply on the operand path
+    dz = rnd(torch.randn(N * Ho * Wo, 64, generator=g), dt)
+    xo = rnd(torch.randn(N * Ho * Wo, 64, generator=g) * 2 + 0.3, dt)
+    mean = torch.randn(views, 64, generator=g) * 0.2
+    invstd = torch.rand(views, 64, generator=g) + 0.5
+    gamma = torch.rand(64, generator=g) + 0.5
+    count = float(rows_v)
+    gs = torch.empty(views, 128, dtype=torch.float64)
+    for v in range(views):
+        dzv, xov = dz[v * rows_v:(v + 1) * rows_v].double(), xo[v * rows_v:(v + 1) * rows_v].double()
+        gs[v, :64] = dzv.sum(0)
+        gs[v, 64:] = (dzv * (xov - mean[v].double()) * invstd[v].double()).sum(0)
+    dxo = torch.empty(N * Ho * Wo, 64, dtype=torch.float64)
+    for v in range(views):
+        sl = slice(v * rows_v, (v + 1) * rows_v)
+        xh = (xo[sl].double() - mean[v].double()) * invstd[v].double()
+        dxo[sl] = gamma.double() * invstd[v].double() * (dz[sl].double() - gs[v, :64] / count - xh * gs[v, 64:] / count)
+    dxo_r = rnd(dxo.float(), dt).double()  # the kernel rounds the operand to bf16 before the MFMA
+    ref_dw = torch.nn.grad.conv2d_weight(rnd(x, dt).double(), (64, 3, 7, 7),
+                                         dxo_r.reshape(N, Ho, Wo, 64).permute(0, 3, 1, 2), stride=2, padding=3)
+    dw = torch.zeros(64, 147, device=D)
+    dgam, dbet = torch.zeros(64, device=D), torch.zeros(64, device=D)
+    ops.stem_wgrad_bn(code, x.to(D), dz.to(dt).to(D), xo.to(dt).to(D), mean.to(D), invstd.to(D), gamma.to(D), gs.to(D), count,
+                      gs.to(D), dgam, dbet, dw, views=views)
+    torch.cuda.synchronize()
+    got_dw = dw.cpu().reshape(64, 7, 7, 3).permute(0, 3, 1, 2).double()
+    sc = ref_dw.abs().max().item()
+    assert (got_dw - ref_dw).abs().max().item() < 2 * tol(dt, sc), ((got_dw - ref_dw).abs().max().item(), sc)
+    assert torch.allclose(dbet.cpu().double(), gs[:, :64].sum(0), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(dgam.cpu().double(), gs[:, 64:].sum(0), rtol=1e-5, atol=1e-4)
