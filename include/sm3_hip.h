@@ -83,6 +83,10 @@ typedef struct sm3_bn_bwd_fuse {
     int32_t views;               /* 0 or 1: one BatchNorm batch.  2: the launch covers two views back to back (rows
                                   * [0, M/2) and [M/2, M), M/2 a multiple of 128), each with its own mean / invstd ... */
     int32_t partial_row_offset_view1; /* ... and view 1's tiles write their partial rows from here */
+    int32_t addend_sp_h, addend_sp_w; /* > 0: `addend` is a COMPACT [N, addend_sp_h, addend_sp_w, Co] tensor holding values for
+                                  * the even (y, x) output positions only (= (Ho+1)/2 x (Wo+1)/2) and zero elsewhere: the data
+                                  * gradient of a Bottleneck's stride-2 1x1 downsample convolution (resnet.py:260), joined with
+                                  * conv1's data gradient here instead of by a second pass over the block-input gradient */
 } sm3_bn_bwd_fuse;
 int sm3_conv_dgrad_bnfuse(const sm3_conv_desc* d, const void* dy_in, const void* w_dgrad, void* dz_out,
                           const void* addend, const sm3_bn_bwd_fuse* fuse, void* stream);

@@ -30,6 +30,9 @@ struct ConvParams {
     int fz_row_off;
     int fz_view_tiles;          // 0: one BatchNorm batch; else tiles (of 128 rows) per view, two views back to back
     int fz_row_off1;            // first partial row of view 1
+    // addend given only at the even (y, x) positions of the output, as a compact [N, add_sp_h, add_sp_w, Co] tensor
+    // (the data gradient of a stride-2 1x1 downsample convolution); 0 = dense addend
+    int add_sp_h, add_sp_w;
     // optional inference epilogue: y = relu?(acc * ep_scale[co] + ep_shift[co] (+ addend))  (eval-mode BatchNorm)
     const float* ep_scale;
     const float* ep_shift;

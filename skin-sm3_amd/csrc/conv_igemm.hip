@@ -330,7 +330,18 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
                     opix = (long)nn * p.HWout + (long)(oy * p.osy + p.ooy) * p.Wout + (ox * p.osx + p.oox);
                 }
                 e_off[k] = opix * p.Co + ncol;
-                if (p.addend) pre_add[k] = ldg16<true>(p.addend + e_off[k] * SZ);
+                if (p.addend) {
+                    if (p.add_sp_h) {  // compact stride-2 addend: present at even (y, x) only (dense output)
+                        const int nn = fdiv(m, p.div_HoWo);
+                        const int rem = m - nn * p.HoWo;
+                        const int oy = fdiv(rem, p.div_Wo);
+                        const int ox = rem - oy * p.Wo;
+                        if (((oy | ox) & 1) == 0)
+                            pre_add[k] = ldg16<true>(p.addend + ((((long)nn * p.add_sp_h + (oy >> 1)) * p.add_sp_w + (ox >> 1)) * p.Co + ncol) * SZ);
+                    } else {
+                        pre_add[k] = ldg16<true>(p.addend + e_off[k] * SZ);
+                    }
+                }
                 if (fz) {
                     pre_x[k] = ldg16<true>(p.fz_x + e_off[k] * SZ);
                     if (p.fz_mask) pre_mk[k] = p.fz_mask[e_off[k] / EPC];
@@ -533,6 +544,13 @@ static int conv_gather_gemm_impl(const sm3_conv_desc* d, const void* x, const vo
     p.fz_row_off = fuse ? fuse->partial_row_offset : 0;
     p.fz_view_tiles = 0;
     p.fz_row_off1 = 0;
+    p.add_sp_h = p.add_sp_w = 0;
+    if (fuse && fuse->addend_sp_h > 0) {
+        const bool dense = d->osy == 1 && d->osx == 1 && d->ooy == 0 && d->oox == 0 && d->Hout == d->Ho && d->Wout == d->Wo;
+        if (!addend || !dense || fuse->addend_sp_h != (d->Ho + 1) / 2 || fuse->addend_sp_w != (d->Wo + 1) / 2) return SM3_EINVAL;
+        p.add_sp_h = fuse->addend_sp_h;
+        p.add_sp_w = fuse->addend_sp_w;
+    }
     if (fuse && fuse->views > 1) {
         if (fuse->views != 2 || (p.M % 2) || ((p.M / 2) % kBM) || fuse->partial_row_offset_view1 < 0) return SM3_EALIGN;
         p.fz_view_tiles = p.M / 2 / kBM;

@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
 class BnBwdFuse(C.Structure):
     _fields_ = [("relu_mask", C.c_void_p), ("x", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
                 ("partials", C.c_void_p), ("partial_row_offset", C.c_int32), ("views", C.c_int32),
-                ("partial_row_offset_view1", C.c_int32)]
+                ("partial_row_offset_view1", C.c_int32), ("addend_sp_h", C.c_int32), ("addend_sp_w", C.c_int32)]
 
 
 class BnApplySide(C.Structure):

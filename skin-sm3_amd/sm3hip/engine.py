@@ -140,6 +140,14 @@ class ConvUnit:
             self._fd[key] = d
         return self._fd[key]
 
+    def compact_dgrad_desc(self, dtype, N, Hs, Ws):
+        """Data gradient of a 1x1 / stride-2 convolution at the pixels it touches only: a plain GEMM over the
+        [N, Hs, Ws, Co] output gradient with the transposed filter bank."""
+        key = ("cdg", dtype, N, Hs, Ws)
+        if key not in self._dd:
+            self._dd[key] = ops.fwd_desc(dtype, N, Hs, Ws, self.Co, self.Ci, 1, 1, 0)
+        return self._dd[key]
+
     def dgrad_descs(self, dtype, N, H, W):
         key = (dtype, N, H, W)
         if key not in self._dd:
@@ -614,7 +622,7 @@ class SM3Engine:
         if st is not None:
             torch.cuda.current_stream().wait_stream(st)
 
-    def conv_backward(self, r, dxo, need_dx=True, addend=None, into=None, fuse=None):
+    def conv_backward(self, r, dxo, need_dx=True, addend=None, into=None, fuse=None, addend_sparse=None):
         """Weight gradient (accumulated into the flat gradient buffer) and, if need_dx, the data gradient.
         fuse: the Rec of the conv+BN unit whose OUTPUT this data gradient is the gradient of; its BN-backward
         phase 1 (ReLU mask + partial sums) then runs inside the data-gradient epilogue.
@@ -640,9 +648,11 @@ class SM3Engine:
                 for dd in descs:
                     n = ops.conv_dgrad_bnfuse(dd, dxo, cu.w_dgrad, dx, addend, fuse.mask if fuse.relu else None,
                                               fuse.xo, fuse.mean, fuse.invstd, part, off, views=V,
-                                              row_offset_view1=per_view + off)
+                                              row_offset_view1=per_view + off, addend_sparse=addend_sparse)
                     off += n // V
                 return dx, off
+            if addend_sparse is not None:
+                raise RuntimeError("a compact addend needs the fused data-gradient epilogue")
             for dd in descs:
                 ops.conv_gemm(dd, dxo, cu.w_dgrad, dx, addend, None)
             return dx, None
@@ -760,9 +770,26 @@ class SM3Engine:
             del dx2, dy2
             dx1, _ = self.bn_backward(r1, dy1, keep_dz=False, fused_rows=fr1)
             if rd is not None:
-                din, _ = self.conv_backward(r1, dx1)
-                self.conv_backward(rd, dxd, into=din)
-                fr = None
+                prev_r3 = ctx["blocks"][bi - 1][-1] if bi > 0 else None
+                cd = rd.cu
+                V = prev_r3.V if prev_r3 is not None else 1
+                if (prev_r3 is not None and self.fuse_bn_bwd and cd.stride == 2
+                        and (V == 1 or (r1.N * r1.H * r1.W) % 256 == 0)):
+                    # Join of the two data gradients of a stride-2 downsample block WITHOUT a second pass over the
+                    # block-input gradient: the downsample convolution's data gradient is computed first, compact (it
+                    # only exists at the even pixels), and conv1's data gradient takes it as a sparse addend -- so that
+                    # launch sees the complete gradient of the previous block's output and runs that block's
+                    # BatchNorm-backward phase 1 in its epilogue, like every other block boundary.
+                    self._wgrad(cd, rd, dxd)
+                    hs, ws = rd.Ho, rd.Wo
+                    dd = cd.compact_dgrad_desc(self.dtype, rd.N, hs, ws)
+                    dsp = torch.empty(rd.N * hs * ws, cd.Ci, dtype=self.tdt, device=dxd.device)
+                    ops.conv_gemm(dd, dxd, cd.w_dgrad, dsp, None, None)
+                    din, fr = self.conv_backward(r1, dx1, addend=dsp, fuse=prev_r3, addend_sparse=(hs, ws))
+                else:
+                    din, _ = self.conv_backward(r1, dx1)
+                    self.conv_backward(rd, dxd, into=din)
+                    fr = None
             else:
                 # din is the gradient of the previous block's output = of its bn3 (+residual, ReLU) unit
                 prev_r3 = ctx["blocks"][bi - 1][-1] if bi > 0 else None

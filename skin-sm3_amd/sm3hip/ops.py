@@ -190,7 +190,7 @@ def conv_gemm(desc, x, w, y, addend=None, partials=None):
 
 
 def conv_dgrad_bnfuse(desc, dy_in, w_dgrad, dz_out, addend, mask, bn_x, mean, invstd, partials, row_offset,
-                      views=1, row_offset_view1=0):
+                      views=1, row_offset_view1=0, addend_sparse=None):
     """Data-gradient launch that also masks with the producer BN's ReLU bits and emits its backward partial sums
     (see sm3_conv_dgrad_bnfuse).  Returns the number of partial rows this launch wrote (both views together).
     views=2: the launch's rows are two views back to back (each a multiple of 128 rows), mean/invstd are [2][C],
@@ -202,8 +202,15 @@ def conv_dgrad_bnfuse(desc, dy_in, w_dgrad, dz_out, addend, mask, bn_x, mean, in
     if dy_in.numel() != desc.N * desc.Hi * desc.Wi * desc.Ci:
         raise ValueError("dy_in size does not match descriptor")
     n_out = desc.N * desc.Hout * desc.Wout * desc.Co
-    if dz_out.numel() != n_out or bn_x.numel() != n_out or (addend is not None and addend.numel() != n_out):
-        raise ValueError("dz_out / bn_x / addend size does not match descriptor")
+    if dz_out.numel() != n_out or bn_x.numel() != n_out:
+        raise ValueError("dz_out / bn_x size does not match descriptor")
+    if addend_sparse is not None:  # compact [N, Hs, Ws, Co] addend for the even output positions
+        hs, ws = addend_sparse
+        if addend is None or (hs, ws) != ((desc.Ho + 1) // 2, (desc.Wo + 1) // 2) or \
+                addend.numel() != desc.N * hs * ws * desc.Co:
+            raise ValueError("sparse addend size does not match descriptor")
+    elif addend is not None and addend.numel() != n_out:
+        raise ValueError("addend size does not match descriptor")
     if mask is not None and mask.numel() != n_out // (16 // _sz(desc.dtype)):
         raise ValueError("mask size mismatch")
     if mean.numel() < views * desc.Co or invstd.numel() < views * desc.Co:
@@ -224,6 +231,7 @@ def conv_dgrad_bnfuse(desc, dy_in, w_dgrad, dz_out, addend, mask, bn_x, mean, in
     f.x, f.mean, f.invstd, f.partials = bn_x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), partials.data_ptr()
     f.partial_row_offset = row_offset
     f.views, f.partial_row_offset_view1 = views, row_offset_view1
+    f.addend_sp_h, f.addend_sp_w = addend_sparse if addend_sparse is not None else (0, 0)
     M = desc.N * desc.Ho * desc.Wo
     sz = _sz(desc.dtype)
     tag = "conv_gemm_128x64" if desc.Co <= 64 else "conv_gemm_128x128"

@@ -50,8 +50,8 @@ CONV_CASES = [
     (16, 64, 256, 56, 56, 1, 1, 0),
     (13, 128, 256, 41, 37, 3, 1, 1),
     (9, 256, 384, 50, 46, 1, 2, 0),
-    # 3x3 / stride 1 with >= 1024 rows and W <= 56: the input-patch kernel (conv3x3_patch.hip): four channel chunks,
-    # the widest map it takes with 64-column tiles, an M tail on an odd map
+    # 3x3 / stride 1 with many row tiles: four channel chunks, 64-column tiles on a wide map, an M tail on an odd map
+
     (8, 256, 256, 14, 14, 3, 1, 1),
     (2, 64, 64, 56, 56, 3, 1, 1),
     (3, 128, 320, 29, 23, 3, 1, 1),
@@ -126,7 +126,7 @@ def test_conv_fwd_dgrad_wgrad(case, dt):
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", [(2, 64, 128, 9, 11, 1, 1, 0), (3, 128, 64, 10, 8, 3, 1, 1), (2, 64, 192, 13, 11, 3, 2, 1),
                                   (12, 256, 128, 57, 50, 1, 1, 0), (8, 128, 64, 66, 62, 3, 2, 1),
-                                  # input-patch kernel, general epilogue: 64- and 128-column tiles, M tails
+                                  # 3x3 stride 1 with many row tiles, 64- and 128-column tiles, M tails
                                   (6, 64, 128, 30, 28, 3, 1, 1), (2, 128, 128, 56, 56, 3, 1, 1), (5, 128, 192, 19, 21, 3, 1, 1)])
 def test_dgrad_with_fused_bn_backward_phase1(case, dt):
     """sm3_conv_dgrad_bnfuse == sm3_conv_gather_gemm followed by sm3_bn_bwd_reduce (dz bit-exact, sums equal)."""
@@ -738,3 +738,41 @@ def test_direct_stem_forward_and_fused_weight_gradient(geom):
     assert (got_dw - ref_dw).abs().max().item() < 2 * tol(dt, sc), ((got_dw - ref_dw).abs().max().item(), sc)
     assert torch.allclose(dbet.cpu().double(), gs[:, :64].sum(0), rtol=1e-5, atol=1e-4)
     assert torch.allclose(dgam.cpu().double(), gs[:, 64:].sum(0), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("geom", [(4, 10, 12), (3, 9, 7)])
+def test_fused_dgrad_with_compact_stride2_addend(dt, geom):
+    """sm3_conv_dgrad_bnfuse with the addend given only at the even output pixels (compact tensor) == the same launch
+    with that addend scattered into a dense zero tensor: dz bit for bit, partial sums bit for bit."""
+    ops = _ops()
+    code = ops.dtype_code(dt)
+    N, H, W = geom
+    Ci, Co = 128, 64  # forward conv1: Ci -> Co (1x1); its data gradient has Ci output channels
+    E = 4 if dt == torch.float32 else 8
+    D = dev()
+    g = torch.Generator().manual_seed(N * 10 + H)
+    dy = torch.randn(N, H, W, Co, generator=g).to(dt).to(D)
+    w_dg = (torch.randn(Ci, 1, Co, generator=g) / math.sqrt(Co)).to(dt).to(D)
+    Hs, Ws = (H + 1) // 2, (W + 1) // 2
+    sp = torch.randn(N, Hs, Ws, Ci, generator=g).to(dt).to(D)
+    dense = torch.zeros(N, H, W, Ci, dtype=dt, device=D)
+    dense[:, ::2, ::2, :] = sp
+    bn_x = torch.randn(N * H * W, Ci, generator=g).to(dt).to(D)
+    mask = torch.randint(0, 256, (N * H * W * Ci // E,), generator=g, dtype=torch.uint8).to(D)
+    mean = (torch.randn(Ci, generator=g) * 0.1).to(D)
+    invstd = (torch.rand(Ci, generator=g) + 0.5).to(D)
+    descs, full = ops.dgrad_descs(code, N, H, W, Ci, Co, 1, 1, 0)
+    assert full and len(descs) == 1
+    prow = ops.conv_partial_rows(descs[0])
+    outs = []
+    for addend, sparse in ((dense, None), (sp, (Hs, Ws))):
+        out = torch.empty(N * H * W, Ci, dtype=dt, device=D)
+        part = torch.full((prow, 2, Ci), float("nan"), device=D)
+        ops.conv_dgrad_bnfuse(descs[0], dy, w_dg, out, addend, mask, bn_x, mean, invstd, part, 0, addend_sparse=sparse)
+        torch.cuda.synchronize()
+        outs.append((out, part))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    with pytest.raises(ValueError):
+        ops.conv_dgrad_bnfuse(descs[0], dy, w_dg, outs[0][0], sp, mask, bn_x, mean, invstd, outs[0][1], 0,
+                              addend_sparse=(Hs + 1, Ws))
