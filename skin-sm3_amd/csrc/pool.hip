@@ -412,27 +412,44 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, int Co, int taps
     }
 }
 
-// all filter banks of a model in one launch: blockIdx.y = bank, grid-stride over its elements
+// all filter banks of a model in one launch: blockIdx.y = bank.  Forward copy: grid-stride, coalesced both ways.
+// Data-gradient bank wd[ci][t][co] = w[co][t][ci]: a transpose per tap, done through 32 x 33 LDS tiles so that both the
+// fp32 reads (along ci) and the T writes (along co) are coalesced -- the element-wise form read w with a stride of
+// taps*Ci floats per lane and ran at 0.8 TB/s (0.8 ms per step for 47 M weights).
 template <typename T>
 __global__ __launch_bounds__(256) void weight_prep_batch_kernel(const sm3_wprep_item* __restrict__ items) {
+    __shared__ float tile[32][33];
     const sm3_wprep_item it = items[blockIdx.y];
     const float* __restrict__ w = it.w;
     T* __restrict__ wf = reinterpret_cast<T*>(it.w_fwd);
     T* __restrict__ wd = reinterpret_cast<T*>(it.w_dgrad);
     const int Co = it.Co, taps = it.taps, Ci = it.Ci, ld = it.ld_fwd, K = taps * Ci;
-    const int64_t nf = wf ? (int64_t)Co * ld : 0;
-    const int64_t nd = wd ? (int64_t)Co * K : 0;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nf + nd;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        if (idx < nf) {
+    if (wf) {
+        const int64_t nf = (int64_t)Co * ld;
+        for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nf; idx += (int64_t)gridDim.x * blockDim.x) {
             const int co = (int)(idx / ld), k = (int)(idx % ld);
             store_elem<T>(wf + idx, k < K ? w[(int64_t)co * K + k] : 0.f);
-        } else {
-            const int64_t j = idx - nf;
-            const int co = (int)(j % Co);
-            const int t = (int)((j / Co) % taps);
-            const int ci = (int)(j / ((int64_t)Co * taps));
-            store_elem<T>(wd + j, w[((int64_t)co * taps + t) * Ci + ci]);
+        }
+    }
+    if (wd) {
+        const int tco = (Co + 31) / 32, tci = (Ci + 31) / 32;
+        const int ntiles = taps * tco * tci;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+        for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+            const int t = tl / (tco * tci), r = tl - t * tco * tci;
+            const int co0 = (r / tci) * 32, ci0 = (r % tci) * 32;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // read rows co0 + ty + 8j, columns ci0 + tx (contiguous along ci)
+                const int co = co0 + ty + 8 * j, ci = ci0 + tx;
+                tile[ty + 8 * j][tx] = (co < Co && ci < Ci) ? w[((int64_t)co * taps + t) * Ci + ci] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // write rows ci0 + ty + 8j, columns co0 + tx (contiguous along co)
+                const int ci = ci0 + ty + 8 * j, co = co0 + tx;
+                if (ci < Ci && co < Co) store_elem<T>(wd + ((int64_t)ci * taps + t) * Co + co, tile[tx][ty + 8 * j]);
+            }
+            __syncthreads();
         }
     }
 }
