@@ -4,7 +4,7 @@
 set -e
 TAG=$1; OUT=gpurun_out/prof_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
-python3 bench.py --steps 10 --warmup 3 --breakdown $OUT/breakdown_two_lanes.txt > $OUT/bench.json 2> $OUT/bench.err
+python3 bench.py --steps 20 --warmup 3 --breakdown $OUT/breakdown_two_lanes.txt > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done"; tail -c 600 $OUT/bench.json; echo
 python3 scratch/prof_detail.py 256 > $OUT/per_shape_single_lane.txt 2>/dev/null
 echo "detail done"
@@ -17,4 +17,9 @@ rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmcW -o pmc -- python3 be
 echo "write pass done"
 python3 scratch/collect_traffic.py $OUT/pmcF $OUT/pmcW $OUT/pmc_traffic.json
 rm -rf $OUT/kt $OUT/pmcF $OUT/pmcW
+ls -la $OUT
+python3 bench.py --single-lane --steps 4 --warmup 2 --no-cpu-baseline --breakdown $OUT/breakdown_single_lane.txt > $OUT/bench_single_lane.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kts -o kt -- python3 bench.py --single-lane --steps 2 --warmup 1 --no-cpu-baseline > $OUT/kts.log 2>&1
+cp $(find $OUT/kts -name "*kernel_stats.csv" | head -1) $OUT/rocprofv3_kernel_stats_single_lane.csv
+rm -rf $OUT/kts
 ls -la $OUT
