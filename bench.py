@@ -29,7 +29,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_BYTES = 8.0e12  # MI355X_MICROARCH.md: HBM3E spec peak
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense, MI355X_MICROARCH.md "Chip-level parameters"
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}  # dense, MI355X_MICROARCH.md "Chip-level parameters"
 FLOP_PER_PAIR_224 = 98.5e9
 
 
@@ -65,7 +65,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="pairs per GPU")
     ap.add_argument("--img", type=int, default=224)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"],
+                    help="bf16 = BASELINE.json configs[1] (default); f16 = the reference's AMP type, with dynamic loss scaling "
+                         "(configs[4]); f32 = exact-f32 MFMA parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -138,7 +140,7 @@ def linear_probe_bench(args):
     m = Baseline("resnet50", None)
     m.freeze_backbone()
     for bb in (m.derm_backbone, m.clinic_backbone):
-        bb.sm3_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+        bb.sm3_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     m.to(dev).eval()
     opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3, weight_decay=5e-2)
     crit = torch.nn.CrossEntropyLoss()
@@ -191,7 +193,7 @@ def inference_bench(args):
     B, S = (128 if args.batch == 256 else args.batch), args.img
     m = inference.build_model()
     for bb in (m.extractor.derm_backbone, m.extractor.clinic_backbone):
-        bb.sm3_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+        bb.sm3_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     m.to(dev).eval()
     g = torch.Generator(device=dev).manual_seed(3407)
     derm = torch.randn(B, 3, S, S, device=dev, generator=g)
@@ -278,7 +280,7 @@ def main():
     from sm3hip.trainer import SM3Trainer
     from src.models.simclr import SimCLRSkinV32
 
-    tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     torch.manual_seed(3407)  # identical random-init weights on every rank (Kaiming fan_out, resnet.py:227-232)
     model = SimCLRSkinV32("resnet50", None, 128, 0.1)
     model.sm3_dtype = tdt
@@ -353,7 +355,7 @@ def main():
                 "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "frac_in_timed_region_two_lanes": round(in_region["flops"] / max(in_region["ms"] * 1e-3, 1e-9) / 1e12 / peak, 4),
                 "by_regime": by_regime,
-                "kernel": f"conv_igemm_kernel<{'bf16_t' if args.dtype == 'bf16' else 'float'},128,128,2,2,*>",
+                "kernel": f"conv_igemm_kernel<{ {'bf16': 'bf16_t', 'f16': 'f16_t', 'f32': 'float'}[args.dtype] },128,128,2,2,*>",
                 "algorithmic_bytes_per_launch": round(dom["bytes"] / max(dom["launches"], 1)),
                 "launches_per_step": dom["launches"],
                 "avg_launch_us": round(1e3 * dom["ms"] / max(dom["launches"], 1), 2),

@@ -7,7 +7,8 @@
  * pointers, sizes, a hipStream_t passed as void*.  All tensors are dense; activations are NHWC
  * ("rows x channels", channels contiguous), weights are [Cout][taps][Cin] (= the memory order of a
  * torch channels_last OIHW tensor).  `dtype` selects the storage/MFMA type of activations and
- * weight copies: SM3_F32 (exact-f32 MFMA, parity mode) or SM3_BF16 (bf16 MFMA, fp32 accumulate).
+ * weight copies: SM3_F32 (exact-f32 MFMA, parity mode), SM3_BF16 or SM3_F16 (16-bit MFMA, fp32 accumulate; SM3_F16
+ * needs the caller's loss scaling: sm3_loss_scale_update).
  * Statistics, master weights, gradients of weights and optimizer state are always fp32 (BN sums fp64).
  *
  * Every function returns 0 on success, a positive hipError_t on a runtime failure, or a negative
@@ -25,6 +26,7 @@ extern "C" {
 
 #define SM3_F32 0
 #define SM3_BF16 1
+#define SM3_F16 2   /* IEEE half storage + f16 MFMA, fp32 accumulate: the reference's AMP type (backbone_train.py:27,98) */
 
 #define SM3_EINVAL (-1)   /* bad size / null pointer */
 #define SM3_EALIGN (-2)   /* channel count not a multiple of the kernel's K chunk */
@@ -257,6 +259,11 @@ int sm3_ce_label0(const float* logits, int R, int Cc, float weight, float* loss,
 int sm3_ntxent_fused(int dtype, const float* z, int R, int D, float temperature, float weight,
                      float* workspace, float* loss, void* dz, void* stream);
 
+/* the same with dz additionally multiplied by the device scalar dz_scale[0] (loss scaling of the fp16 mode; the loss itself
+ * stays unscaled) */
+int sm3_ntxent_fused_scaled(int dtype, const float* z, int R, int D, float temperature, float weight,
+                            const float* dz_scale, float* workspace, float* loss, void* dz, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * AdamW over a flat fp32 buffer.  replaces torch.optim.AdamW(eps=1e-5, wd) + GradScaler unscale
  * (tools/backbone_train.py:124-127, 525-527).  g is multiplied by grad_scale first.
@@ -265,6 +272,17 @@ int sm3_ntxent_fused(int dtype, const float* z, int R, int D, float temperature,
 int sm3_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
               float eps, float weight_decay, int step, float grad_scale, const int32_t* found_inf,
               void* stream);
+/* The fp16 mode's dynamic loss scaling (torch.cuda.amp.GradScaler, backbone_train.py:125-127,480) with the scaler's state
+ * on the DEVICE, so that a step needs no host synchronisation: loss_scale[1] (the factor sm3_ntxent_fused_scaled applied to
+ * dz), steps_taken[1] (optimizer steps actually taken: a skipped step does not advance Adam's bias correction).
+ * sm3_adamw_dynamic: as sm3_adamw with g multiplied by grad_scale / loss_scale[0] and step = steps_taken[0] + 1; skipped when
+ * found_inf[0] != 0.  sm3_loss_scale_update: GradScaler.update() -- on overflow scale *= backoff and the growth tracker
+ * restarts, else steps_taken += 1 and after growth_interval clean steps scale *= growth; clears found_inf. */
+int sm3_adamw_dynamic(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, float grad_scale, const float* loss_scale,
+                      const int32_t* steps_taken, const int32_t* found_inf, void* stream);
+int sm3_loss_scale_update(float* loss_scale, int32_t* found_inf, int32_t* growth_tracker, int32_t* steps_taken,
+                          float growth_factor, float backoff_factor, int growth_interval, void* stream);
 /* found_inf[0] |= any(!isfinite(g)) */
 int sm3_check_finite(const float* g, int64_t n, int32_t* found_inf, void* stream);
 

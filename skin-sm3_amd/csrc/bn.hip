@@ -589,26 +589,26 @@ static int bn_act_impl(int dtype, const void* x, const float* scale, const float
                        uint8_t* relu_mask, int64_t rows, int C, int views, void* stream) {
     if (!x || !scale || !shift || !y || rows <= 0 || C <= 0 || views < 1) return SM3_EINVAL;
     if ((res_scale != nullptr) != (res_shift != nullptr) || (res_scale && !residual)) return SM3_EINVAL;
-    if (dtype != SM3_F32 && dtype != SM3_BF16) return SM3_EDTYPE;
+    if (!SM3_DTYPE_OK(dtype)) return SM3_EDTYPE;
     const int E = dtype == SM3_F32 ? 4 : 8;
     if (C % E) return SM3_EALIGN;
     const RowWalk w = make_walk(rows, C / E, 8192, views);
     dim3 grid(w.gx, w.gy, views), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define SM3_ACT(U, NT)                                                                                            \
-    if (dtype == SM3_F32) /* f32 storage: the two output forms coincide */                                        \
-        hipLaunchKernelGGL((bn_act_kernel<float, false, U, NT>), grid, block, 0, st, (const float*)x, scale, shift, \
-                           (const float*)residual, res_scale, res_shift, relu, y, relu_mask, rows, C, w.tbx, w.tby); \
-    else if (out_f32)                                                                                             \
-        hipLaunchKernelGGL((bn_act_kernel<bf16_t, true, U, NT>), grid, block, 0, st, (const bf16_t*)x, scale,     \
-                           shift, (const bf16_t*)residual, res_scale, res_shift, relu, y, relu_mask, rows, C,     \
-                           w.tbx, w.tby);                                                                         \
-    else                                                                                                          \
-        hipLaunchKernelGGL((bn_act_kernel<bf16_t, false, U, NT>), grid, block, 0, st, (const bf16_t*)x, scale,    \
-                           shift, (const bf16_t*)residual, res_scale, res_shift, relu, y, relu_mask, rows, C,     \
-                           w.tbx, w.tby)
+#define SM3_ACT_T(T, U, NT)                                                                                          \
+    if (out_f32 && sizeof(T) == 2)                                                                                      \
+        hipLaunchKernelGGL((bn_act_kernel<T, true, U, NT>), grid, block, 0, st, (const T*)x, scale, shift,              \
+                           (const T*)residual, res_scale, res_shift, relu, y, relu_mask, rows, C, w.tbx, w.tby);        \
+    else /* f32 storage: the two output forms coincide */                                                               \
+        hipLaunchKernelGGL((bn_act_kernel<T, false, U, NT>), grid, block, 0, st, (const T*)x, scale, shift,             \
+                           (const T*)residual, res_scale, res_shift, relu, y, relu_mask, rows, C, w.tbx, w.tby)
+#define SM3_ACT(U, NT)                                            \
+    if (dtype == SM3_F32) { SM3_ACT_T(float, U, NT); }            \
+    else if (dtype == SM3_BF16) { SM3_ACT_T(bf16_t, U, NT); }     \
+    else { SM3_ACT_T(f16_t, U, NT); }
     SM3_BN_DISPATCH(0, SM3_ACT);
 #undef SM3_ACT
+#undef SM3_ACT_T
     SM3_CHECK_LAUNCH();
     return 0;
 }
@@ -643,24 +643,23 @@ extern "C" int sm3_bn_bwd_reduce(int dtype, const void* dy, const void* y, const
                                  const float* mean, const float* invstd, void* dz, int64_t rows, int C,
                                  float* partials, int views, void* stream) {
     if (!dy || !x || !mean || !invstd || !partials || rows <= 0 || C <= 0 || views < 1) return SM3_EINVAL;
-    if (dtype != SM3_F32 && dtype != SM3_BF16) return SM3_EDTYPE;
+    if (!SM3_DTYPE_OK(dtype)) return SM3_EDTYPE;
     const int E = dtype == SM3_F32 ? 4 : 8;
     if (C % E) return SM3_EALIGN;
     RowWalk w = make_walk(rows, C / E, 1 << 30);
     w.gy = bwd_gy(rows);
     dim3 grid(w.gx, w.gy, views), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define SM3_RED(U, NT)                                                                                              \
-    if (dtype == SM3_F32)                                                                                           \
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, U, NT>), grid, block, 0, st, (const float*)dy,              \
-                           (const float*)y, relu_mask, (const float*)x, mean, invstd, (float*)dz, rows, C, partials, \
-                           w.tbx, w.tby);                                                                           \
-    else                                                                                                            \
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, U, NT>), grid, block, 0, st, (const bf16_t*)dy,            \
-                           (const bf16_t*)y, relu_mask, (const bf16_t*)x, mean, invstd, (bf16_t*)dz, rows, C,       \
-                           partials, w.tbx, w.tby)
+#define SM3_RED_T(T, U, NT)                                                                                      \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, U, NT>), grid, block, 0, st, (const T*)dy, (const T*)y, relu_mask,  \
+                       (const T*)x, mean, invstd, (T*)dz, rows, C, partials, w.tbx, w.tby)
+#define SM3_RED(U, NT)                                        \
+    if (dtype == SM3_F32) { SM3_RED_T(float, U, NT); }        \
+    else if (dtype == SM3_BF16) { SM3_RED_T(bf16_t, U, NT); } \
+    else { SM3_RED_T(f16_t, U, NT); }
     SM3_BN_DISPATCH(1, SM3_RED);
 #undef SM3_RED
+#undef SM3_RED_T
     SM3_CHECK_LAUNCH();
     return 0;
 }
@@ -671,23 +670,22 @@ extern "C" int sm3_bn_bwd_apply(int dtype, const void* dz, const void* x, const 
                                 int views, void* stream) {
     if (!dz || !x || !mean || !invstd || !global_sums || !dx || rows <= 0 || C <= 0 || count <= 0 || views < 1)
         return SM3_EINVAL;
-    if (dtype != SM3_F32 && dtype != SM3_BF16) return SM3_EDTYPE;
+    if (!SM3_DTYPE_OK(dtype)) return SM3_EDTYPE;
     const int E = dtype == SM3_F32 ? 4 : 8;
     if (C % E) return SM3_EALIGN;
     const RowWalk w = make_walk(rows, C / E, 8192, views);
     dim3 grid(w.gx, w.gy, views), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define SM3_APP(U, NT)                                                                                             \
-    if (dtype == SM3_F32)                                                                                          \
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<float, U, NT>), grid, block, 0, st, (const float*)dz,              \
-                           (const float*)x, mean, invstd, gamma, global_sums, 1.0 / count, local_sums, dgamma,     \
-                           dbeta, (float*)dx, rows, C, w.tbx, w.tby);                                              \
-    else                                                                                                           \
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, U, NT>), grid, block, 0, st, (const bf16_t*)dz,            \
-                           (const bf16_t*)x, mean, invstd, gamma, global_sums, 1.0 / count, local_sums, dgamma,    \
-                           dbeta, (bf16_t*)dx, rows, C, w.tbx, w.tby)
+#define SM3_APP_T(T, U, NT)                                                                                       \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, U, NT>), grid, block, 0, st, (const T*)dz, (const T*)x, mean, invstd, \
+                       gamma, global_sums, 1.0 / count, local_sums, dgamma, dbeta, (T*)dx, rows, C, w.tbx, w.tby)
+#define SM3_APP(U, NT)                                        \
+    if (dtype == SM3_F32) { SM3_APP_T(float, U, NT); }        \
+    else if (dtype == SM3_BF16) { SM3_APP_T(bf16_t, U, NT); } \
+    else { SM3_APP_T(f16_t, U, NT); }
     SM3_BN_DISPATCH(2, SM3_APP);
 #undef SM3_APP
+#undef SM3_APP_T
     SM3_CHECK_LAUNCH();
     return 0;
 }
@@ -697,7 +695,7 @@ extern "C" int sm3_bn_bwd_apply2(int dtype, const void* dz, double count, const 
     if (!dz || !a || !b || rows <= 0 || C <= 0 || count <= 0 || views < 1) return SM3_EINVAL;
     for (const sm3_bn_apply_side* s : {a, b})
         if (!s->x || !s->mean || !s->invstd || !s->global_sums || !s->dx) return SM3_EINVAL;
-    if (dtype != SM3_F32 && dtype != SM3_BF16) return SM3_EDTYPE;
+    if (!SM3_DTYPE_OK(dtype)) return SM3_EDTYPE;
     const int E = dtype == SM3_F32 ? 4 : 8;
     if (C % E) return SM3_EALIGN;
     const RowWalk w = make_walk(rows, C / E, 8192, views);
@@ -706,15 +704,16 @@ extern "C" int sm3_bn_bwd_apply2(int dtype, const void* dz, double count, const 
     const BnApplySide sa = {a->x, a->mean, a->invstd, a->gamma, a->global_sums, a->local_sums, a->dgamma, a->dbeta, a->dx};
     const BnApplySide sb = {b->x, b->mean, b->invstd, b->gamma, b->global_sums, b->local_sums, b->dgamma, b->dbeta, b->dx};
     // half the unroll of the single form: three input streams per row instead of two
-#define SM3_APP2(U, NT)                                                                                            \
-    if (dtype == SM3_F32)                                                                                          \
-        hipLaunchKernelGGL((bn_bwd_apply2_kernel<float, (U > 4 ? 4 : U), NT>), grid, block, 0, st, (const float*)dz, sa, sb, \
-                           1.0 / count, rows, C, w.tbx, w.tby);                                                    \
-    else                                                                                                           \
-        hipLaunchKernelGGL((bn_bwd_apply2_kernel<bf16_t, (U > 4 ? 4 : U), NT>), grid, block, 0, st, (const bf16_t*)dz, sa, sb, \
-                           1.0 / count, rows, C, w.tbx, w.tby)
+#define SM3_APP2_T(T, U, NT)                                                                                   \
+    hipLaunchKernelGGL((bn_bwd_apply2_kernel<T, (U > 4 ? 4 : U), NT>), grid, block, 0, st, (const T*)dz, sa, sb,  \
+                       1.0 / count, rows, C, w.tbx, w.tby)
+#define SM3_APP2(U, NT)                                        \
+    if (dtype == SM3_F32) { SM3_APP2_T(float, U, NT); }        \
+    else if (dtype == SM3_BF16) { SM3_APP2_T(bf16_t, U, NT); } \
+    else { SM3_APP2_T(f16_t, U, NT); }
     SM3_BN_DISPATCH(2, SM3_APP2);
 #undef SM3_APP2
+#undef SM3_APP2_T
     SM3_CHECK_LAUNCH();
     return 0;
 }

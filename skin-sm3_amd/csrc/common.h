@@ -14,6 +14,13 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 struct bf16_t {
     uint16_t v;
 };
+// IEEE half: the reference's own AMP storage type (torch.cuda.amp.autocast(), tools/backbone_train.py:27,98) -- 11 bits of
+// significand against bf16's 8, at the price of a narrow exponent (dynamic loss scaling: sm3_loss_scale_update)
+struct f16_t {
+    uint16_t v;
+};
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
 
@@ -25,6 +32,15 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+__device__ __forceinline__ float f16_to_f32(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+__device__ __forceinline__ uint16_t f32_to_f16(float f) {  // round-to-nearest-even (v_cvt_f16_f32); overflow -> inf
+    _Float16 h = (_Float16)f;
+    return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+    return (uint32_t)f32_to_f16(lo) | ((uint32_t)f32_to_f16(hi) << 16);
 }
 
 template <typename T>
@@ -41,6 +57,37 @@ struct ElemTraits<bf16_t> {
     __device__ static __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(p->v); }
     __device__ static __forceinline__ float round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
 };
+
+template <>
+struct ElemTraits<f16_t> {
+    static constexpr int kPer16B = 8;
+    __device__ static __forceinline__ float load(const f16_t* p) { return f16_to_f32(p->v); }
+    __device__ static __forceinline__ float round(float v) { return f16_to_f32(f32_to_f16(v)); }
+};
+
+// two floats -> one dword of T (16-bit types), and v_dot2 on such dwords: what the lean convolution epilogue needs
+template <typename T>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi);
+template <>
+__device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi) { return pack_bf16x2(lo, hi); }
+template <>
+__device__ __forceinline__ uint32_t pack2<f16_t>(float lo, float hi) { return pack_f16x2(lo, hi); }
+template <typename T>
+__device__ __forceinline__ float dot2acc(uint32_t a, uint32_t b, float acc);
+template <>
+__device__ __forceinline__ float dot2acc<bf16_t>(uint32_t a, uint32_t b, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), acc, false);
+}
+template <>
+__device__ __forceinline__ float dot2acc<f16_t>(uint32_t a, uint32_t b, float acc) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a), __builtin_bit_cast(f16x2_t, b), acc, false);
+}
+template <typename T>
+__device__ __forceinline__ uint32_t ones2();  // (1, 1) as a dword of T
+template <>
+__device__ __forceinline__ uint32_t ones2<bf16_t>() { return 0x3f803f80u; }
+template <>
+__device__ __forceinline__ uint32_t ones2<f16_t>() { return 0x3c003c00u; }
 
 // 16 bytes of T -> floats
 template <typename T>
@@ -63,6 +110,15 @@ __device__ __forceinline__ void unpack16<bf16_t>(const uint4& u, float* f) {
     f[6] = __uint_as_float(u.w << 16);
     f[7] = __uint_as_float(u.w & 0xffff0000u);
 }
+template <>
+__device__ __forceinline__ void unpack16<f16_t>(const uint4& u, float* f) {
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = f16_to_f32((uint16_t)(w[i] & 0xffffu));
+        f[2 * i + 1] = f16_to_f32((uint16_t)(w[i] >> 16));
+    }
+}
 template <typename T>
 __device__ __forceinline__ uint4 pack16(const float* f);
 template <>
@@ -73,6 +129,11 @@ template <>
 __device__ __forceinline__ uint4 pack16<bf16_t>(const float* f) {
     return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
                       pack_bf16x2(f[6], f[7]));
+}
+
+template <>
+__device__ __forceinline__ uint4 pack16<f16_t>(const float* f) {
+    return make_uint4(pack_f16x2(f[0], f[1]), pack_f16x2(f[2], f[3]), pack_f16x2(f[4], f[5]), pack_f16x2(f[6], f[7]));
 }
 
 // 16-byte global accesses for the streaming kernels.  NT = non-temporal: the data is touched once per kernel,
@@ -131,6 +192,16 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// expands CALL(T) for the element type of `dtype`; returns SM3_EDTYPE for anything else
+#define SM3_DISPATCH_DTYPE(dtype, CALL)          \
+    do {                                         \
+        if ((dtype) == SM3_F32) { CALL(float); } \
+        else if ((dtype) == SM3_BF16) { CALL(bf16_t); } \
+        else if ((dtype) == SM3_F16) { CALL(f16_t); }   \
+        else return SM3_EDTYPE;                  \
+    } while (0)
+#define SM3_DTYPE_OK(dtype) ((dtype) == SM3_F32 || (dtype) == SM3_BF16 || (dtype) == SM3_F16)
 
 #define SM3_CHECK_LAUNCH()                          \
     do {                                            \

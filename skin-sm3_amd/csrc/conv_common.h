@@ -47,6 +47,10 @@ __device__ __forceinline__ void mma_frag<bf16_t>(const uint4& a, const uint4& b,
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 template <>
+__device__ __forceinline__ void mma_frag<f16_t>(const uint4& a, const uint4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <>
 __device__ __forceinline__ void mma_frag<float>(const uint4& a, const uint4& b, f32x16& c) {
     // lane (r, h) holds k = 8*kk + 4*h + {0,1,2,3}: the j-th MFMA uses element j of both fragments,
     // so A and B agree on k and the four instructions together cover 8 consecutive k.

@@ -187,11 +187,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
     // (v_cvt_pk_bf16_f32); BatchNorm sums of the ROUNDED values with two v_dot2c_f32_bf16 per pair; the whole
     // tile staged once in LDS as bf16; read back as 16-byte vectors and stored with no arithmetic in between.
     if constexpr (LEAN) {
-        static_assert(sizeof(T) == 2, "lean epilogue is bf16 only");
+        static_assert(sizeof(T) == 2, "lean epilogue is for the 16-bit types");
         constexpr int CPR = BN / 8, RSTEP = NT / CPR, NPASS = BM / RSTEP;
         char* sC = smem;
         float* sStat = reinterpret_cast<float*>(smem + MAIN_BYTES);  // [WM][BN][2]
-        const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+        const uint32_t ones = ones2<T>();
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float s1 = 0.f, s2 = 0.f;
@@ -211,10 +211,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
                         v0 = fmaxf(v0 * esc + esh, elo);
                         v1 = fmaxf(v1 * esc + esh, elo);
                     }
-                    const uint32_t pk = pack_bf16x2(v0, v1);
-                    const bf16x2_t pv = __builtin_bit_cast(bf16x2_t, pk);
-                    s1 = __builtin_amdgcn_fdot2_f32_bf16(pv, ones, s1, false);
-                    s2 = __builtin_amdgcn_fdot2_f32_bf16(pv, pv, s2, false);
+                    const uint32_t pk = pack2<T>(v0, v1);
+                    s1 = dot2acc<T>(pk, ones, s1);
+                    s2 = dot2acc<T>(pk, pk, s2);
                     const int R = i * 32 + (q & 1) * 2 + 8 * (q >> 1);
                     *reinterpret_cast<uint16_t*>(colp + R * LEAN_PITCH) = (uint16_t)pk;
                     *reinterpret_cast<uint16_t*>(colp + (R + 1) * LEAN_PITCH) = (uint16_t)(pk >> 16);
@@ -529,7 +528,7 @@ static int conv_gather_gemm_impl(const sm3_conv_desc* d, const void* x, const vo
     if (!d || !x || !w || !y) return SM3_EINVAL;
     if (fuse && (!fuse->x || !fuse->mean || !fuse->invstd || !fuse->partials || fuse->partial_row_offset < 0))
         return SM3_EINVAL;
-    if (d->dtype != SM3_F32 && d->dtype != SM3_BF16) return SM3_EDTYPE;
+    if (!SM3_DTYPE_OK(d->dtype)) return SM3_EDTYPE;
     ConvParams p;
     const int sz = d->dtype == SM3_F32 ? 4 : 2;
     int rc = fill_params(d, p, sz);
@@ -563,6 +562,8 @@ static int conv_gather_gemm_impl(const sm3_conv_desc* d, const void* x, const vo
     const bool narrow = d->Co <= 64;
     if (d->dtype == SM3_BF16)
         return narrow ? launch_conv<bf16_t, kBM, 64, 2, 2>(p, st) : launch_conv<bf16_t, kBM, 128, 2, 2>(p, st);
+    if (d->dtype == SM3_F16)
+        return narrow ? launch_conv<f16_t, kBM, 64, 2, 2>(p, st) : launch_conv<f16_t, kBM, 128, 2, 2>(p, st);
     return narrow ? launch_conv<float, kBM, 64, 2, 2>(p, st) : launch_conv<float, kBM, 128, 2, 2>(p, st);
 }
 

@@ -217,8 +217,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+                        sm3conv::mma_frag<T>(fa[i], fb[j], acc[i][j]);
             }
         } else {
 #pragma unroll 4
@@ -309,7 +308,7 @@ int launch_wgrad(WgradParams p, hipStream_t st) {
 
 extern "C" int sm3_conv_wgrad(const sm3_conv_desc* d, const void* x, const void* dy, float* dw, void* stream) {
     if (!d || !x || !dy || !dw) return SM3_EINVAL;
-    if (d->dtype != SM3_F32 && d->dtype != SM3_BF16) return SM3_EDTYPE;
+    if (!SM3_DTYPE_OK(d->dtype)) return SM3_EDTYPE;
     const int sz = d->dtype == SM3_F32 ? 4 : 2;
     if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ci <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Co <= 0) return SM3_EINVAL;
     if (d->ntaps < 1 || d->ntaps > SM3_MAX_TAPS) return SM3_EINVAL;
@@ -337,6 +336,12 @@ extern "C" int sm3_conv_wgrad(const sm3_conv_desc* d, const void* x, const void*
         if (nco) return launch_wgrad<bf16_t, 64, 128>(p, st);
         if (nci) return launch_wgrad<bf16_t, 128, 64>(p, st);
         return launch_wgrad<bf16_t, 128, 128>(p, st);
+    }
+    if (d->dtype == SM3_F16) {
+        if (nco && nci) return launch_wgrad<f16_t, 64, 64>(p, st);
+        if (nco) return launch_wgrad<f16_t, 64, 128>(p, st);
+        if (nci) return launch_wgrad<f16_t, 128, 64>(p, st);
+        return launch_wgrad<f16_t, 128, 128>(p, st);
     }
     if (nco && nci) return launch_wgrad<float, 64, 64>(p, st);
     if (nco) return launch_wgrad<float, 64, 128>(p, st);

@@ -18,12 +18,16 @@ template <>
 __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
 template <>
 __device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p) { return bf16_to_f32(p->v); }
+template <>
+__device__ __forceinline__ float ld1<f16_t>(const f16_t* p) { return f16_to_f32(p->v); }
 template <typename T>
 __device__ __forceinline__ void st1(T* p, float v);
 template <>
 __device__ __forceinline__ void st1<float>(float* p, float v) { *p = v; }
 template <>
 __device__ __forceinline__ void st1<bf16_t>(bf16_t* p, float v) { p->v = f32_to_bf16(v); }
+template <>
+__device__ __forceinline__ void st1<f16_t>(f16_t* p, float v) { p->v = f32_to_f16(v); }
 
 constexpr int kMaxS = 8;
 
@@ -140,12 +144,11 @@ __global__ __launch_bounds__(256) void token_heads_kernel(const T* __restrict__ 
 
 extern "C" int sm3_token_attention(int dtype, const void* qkv, void* out, int B, int S, int D, int nhead, void* stream) {
     if (!qkv || !out || B <= 0 || S <= 0 || S > kMaxS || D <= 0 || nhead <= 0 || nhead > 8 || D % nhead) return SM3_EINVAL;
-    if (dtype != SM3_F32 && dtype != SM3_BF16) return SM3_EDTYPE;
+    if (!SM3_DTYPE_OK(dtype)) return SM3_EDTYPE;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == SM3_F32)
-        hipLaunchKernelGGL(token_attention_kernel<float>, dim3(B), dim3(256), 0, st, (const float*)qkv, (float*)out, S, D, nhead);
-    else
-        hipLaunchKernelGGL(token_attention_kernel<bf16_t>, dim3(B), dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)out, S, D, nhead);
+#define SM3_TA(T) hipLaunchKernelGGL(token_attention_kernel<T>, dim3(B), dim3(256), 0, st, (const T*)qkv, (T*)out, S, D, nhead)
+    SM3_DISPATCH_DTYPE(dtype, SM3_TA);
+#undef SM3_TA
     SM3_CHECK_LAUNCH();
     return 0;
 }
@@ -153,13 +156,13 @@ extern "C" int sm3_token_attention(int dtype, const void* qkv, void* out, int B,
 extern "C" int sm3_add_layernorm(int dtype, const void* a, const void* b, const float* gamma, const float* beta,
                                  float eps, void* out, int64_t rows, int D, void* stream) {
     if (!a || !gamma || !beta || !out || rows <= 0 || D <= 0 || D > 1024) return SM3_EINVAL;
-    if (dtype != SM3_F32 && dtype != SM3_BF16) return SM3_EDTYPE;
+    if (!SM3_DTYPE_OK(dtype)) return SM3_EDTYPE;
     hipStream_t st = (hipStream_t)stream;
     const unsigned g = (unsigned)((rows + 3) / 4);
-    if (dtype == SM3_F32)
-        hipLaunchKernelGGL(add_layernorm_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)a, (const float*)b, gamma, beta, eps, (float*)out, rows, D);
-    else
-        hipLaunchKernelGGL(add_layernorm_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, gamma, beta, eps, (bf16_t*)out, rows, D);
+#define SM3_LN(T) \
+    hipLaunchKernelGGL(add_layernorm_kernel<T>, dim3(g), dim3(256), 0, st, (const T*)a, (const T*)b, gamma, beta, eps, (T*)out, rows, D)
+    SM3_DISPATCH_DTYPE(dtype, SM3_LN);
+#undef SM3_LN
     SM3_CHECK_LAUNCH();
     return 0;
 }
@@ -167,12 +170,12 @@ extern "C" int sm3_add_layernorm(int dtype, const void* a, const void* b, const 
 extern "C" int sm3_token_heads(int dtype, const void* x, const float* W, const float* bias, const int* token_of,
                                int l2_norm, float* out, int B, int S, int D, int T, void* stream) {
     if (!x || !W || !bias || !token_of || !out || B <= 0 || S <= 0 || S > kMaxS || D <= 0 || T <= 0) return SM3_EINVAL;
-    if (dtype != SM3_F32 && dtype != SM3_BF16) return SM3_EDTYPE;
+    if (!SM3_DTYPE_OK(dtype)) return SM3_EDTYPE;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == SM3_F32)
-        hipLaunchKernelGGL(token_heads_kernel<float>, dim3(B), dim3(256), 0, st, (const float*)x, W, bias, token_of, l2_norm, out, S, D, T);
-    else
-        hipLaunchKernelGGL(token_heads_kernel<bf16_t>, dim3(B), dim3(256), 0, st, (const bf16_t*)x, W, bias, token_of, l2_norm, out, S, D, T);
+#define SM3_TH(ET) \
+    hipLaunchKernelGGL(token_heads_kernel<ET>, dim3(B), dim3(256), 0, st, (const ET*)x, W, bias, token_of, l2_norm, out, S, D, T)
+    SM3_DISPATCH_DTYPE(dtype, SM3_TH);
+#undef SM3_TH
     SM3_CHECK_LAUNCH();
     return 0;
 }

@@ -16,6 +16,8 @@ template <>
 __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
 template <>
 __device__ __forceinline__ void store_out<bf16_t>(bf16_t* p, float v) { p->v = f32_to_bf16(v); }
+template <>
+__device__ __forceinline__ void store_out<f16_t>(f16_t* p, float v) { p->v = f32_to_f16(v); }
 
 // one wave per row: zn = z / max(||z||, 1e-12)
 __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ z, int R, int D,
@@ -182,7 +184,8 @@ __global__ __launch_bounds__(256) void fused_lse_kernel(const float* __restrict_
 template <typename T>
 __global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict__ zn, const float* __restrict__ inv_norm,
                                                         const float* __restrict__ lse, int R, int D, float inv_t,
-                                                        float weight, T* __restrict__ dz) {
+                                                        float weight, const float* __restrict__ dz_scale,
+                                                        T* __restrict__ dz) {
     extern __shared__ float sm[];  // zi[D] + coef[R] + red[4]
     float* zi = sm;
     float* coef = sm + D;
@@ -191,7 +194,8 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict_
     for (int d = threadIdx.x; d < D; d += 256) zi[d] = zn[(int64_t)i * D + d];
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const float k = weight * inv_t / (float)R;
+    // dz_scale: the dynamic loss scale of the fp16 mode (device scalar; GradScaler.scale(loss), backbone_train.py:125)
+    const float k = weight * (dz_scale ? dz_scale[0] : 1.f) * inv_t / (float)R;
     const float lse_i = lse[i];
     for (int j = wv; j < R; j += 4) {
         float a = 0.f;
@@ -242,16 +246,14 @@ extern "C" int sm3_ntxent_logits(const float* z, int R, int D, float temperature
 extern "C" int sm3_ntxent_logits_bwd(int dtype, const float* dlogits, const float* zn, const float* inv_norm, int R,
                                      int D, float temperature, void* dz, void* stream) {
     if (!dlogits || !zn || !inv_norm || !dz || R < 2 || (R & 1) || D <= 0 || temperature <= 0) return SM3_EINVAL;
-    if (dtype != SM3_F32 && dtype != SM3_BF16) return SM3_EDTYPE;
+    if (!SM3_DTYPE_OK(dtype)) return SM3_EDTYPE;
     const size_t lds = (size_t)(R + 4) * 4;
     if (lds > 60000) return SM3_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == SM3_F32)
-        hipLaunchKernelGGL(logits_bwd_kernel<float>, dim3(R), dim3(256), lds, st, dlogits, zn, inv_norm, R, D,
-                           1.f / temperature, (float*)dz);
-    else
-        hipLaunchKernelGGL(logits_bwd_kernel<bf16_t>, dim3(R), dim3(256), lds, st, dlogits, zn, inv_norm, R, D,
-                           1.f / temperature, (bf16_t*)dz);
+#define SM3_LB(T) \
+    hipLaunchKernelGGL(logits_bwd_kernel<T>, dim3(R), dim3(256), lds, st, dlogits, zn, inv_norm, R, D, 1.f / temperature, (T*)dz)
+    SM3_DISPATCH_DTYPE(dtype, SM3_LB);
+#undef SM3_LB
     SM3_CHECK_LAUNCH();
     return 0;
 }
@@ -265,10 +267,10 @@ extern "C" int sm3_ce_label0(const float* logits, int R, int Cc, float weight, f
     return 0;
 }
 
-extern "C" int sm3_ntxent_fused(int dtype, const float* z, int R, int D, float temperature, float weight,
-                                float* workspace, float* loss, void* dz, void* stream) {
+static int ntxent_fused_impl(int dtype, const float* z, int R, int D, float temperature, float weight,
+                             const float* dz_scale, float* workspace, float* loss, void* dz, void* stream) {
     if (!z || !workspace || !dz || R < 2 || (R & 1) || D <= 0 || temperature <= 0) return SM3_EINVAL;
-    if (dtype != SM3_F32 && dtype != SM3_BF16) return SM3_EDTYPE;
+    if (!SM3_DTYPE_OK(dtype)) return SM3_EDTYPE;
     const size_t lds = (size_t)(D + R + 8) * 4;
     if (lds > 60000) return SM3_EINVAL;
     float* zn = workspace;                    // [R][D]
@@ -280,12 +282,22 @@ extern "C" int sm3_ntxent_fused(int dtype, const float* z, int R, int D, float t
     SM3_CHECK_LAUNCH();
     hipLaunchKernelGGL(fused_lse_kernel, dim3(R), dim3(256), lds, st, zn, R, D, inv_t, weight, lse, loss);
     SM3_CHECK_LAUNCH();
-    if (dtype == SM3_F32)
-        hipLaunchKernelGGL(fused_bwd_kernel<float>, dim3(R), dim3(256), lds, st, zn, inv_norm, lse, R, D, inv_t, weight,
-                           (float*)dz);
-    else
-        hipLaunchKernelGGL(fused_bwd_kernel<bf16_t>, dim3(R), dim3(256), lds, st, zn, inv_norm, lse, R, D, inv_t, weight,
-                           (bf16_t*)dz);
+#define SM3_NTX(T)                                                                                                       \
+    hipLaunchKernelGGL(fused_bwd_kernel<T>, dim3(R), dim3(256), lds, st, zn, inv_norm, lse, R, D, inv_t, weight, dz_scale, \
+                       (T*)dz)
+    SM3_DISPATCH_DTYPE(dtype, SM3_NTX);
+#undef SM3_NTX
     SM3_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int sm3_ntxent_fused(int dtype, const float* z, int R, int D, float temperature, float weight,
+                                float* workspace, float* loss, void* dz, void* stream) {
+    return ntxent_fused_impl(dtype, z, R, D, temperature, weight, nullptr, workspace, loss, dz, stream);
+}
+
+extern "C" int sm3_ntxent_fused_scaled(int dtype, const float* z, int R, int D, float temperature, float weight,
+                                       const float* dz_scale, float* workspace, float* loss, void* dz, void* stream) {
+    if (!dz_scale) return SM3_EINVAL;
+    return ntxent_fused_impl(dtype, z, R, D, temperature, weight, dz_scale, workspace, loss, dz, stream);
 }

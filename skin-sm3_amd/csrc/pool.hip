@@ -13,6 +13,8 @@ template <>
 __device__ __forceinline__ void store_elem<float>(float* p, float v) { *p = v; }
 template <>
 __device__ __forceinline__ void store_elem<bf16_t>(bf16_t* p, float v) { p->v = f32_to_bf16(v); }
+template <>
+__device__ __forceinline__ void store_elem<f16_t>(f16_t* p, float v) { p->v = f32_to_f16(v); }
 
 // cols[m][k], m = (n, oy, ox), k = (kh*7 + kw)*3 + c ; one thread per 16-byte chunk of a row
 // Index decomposition of the element-wise kernels below: 32-bit with precomputed multipliers (the host rejects
@@ -474,9 +476,10 @@ inline unsigned grid_for(int64_t total, int per_block = 256, int64_t cap = 8192)
 
 }  // namespace
 
-#define DISPATCH_T(dtype, CALL_F32, CALL_BF16)  \
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16, CALL_F16)  \
     if ((dtype) == SM3_F32) { CALL_F32; }       \
     else if ((dtype) == SM3_BF16) { CALL_BF16; } \
+    else if ((dtype) == SM3_F16) { CALL_F16; } \
     else return SM3_EDTYPE;
 
 extern "C" int sm3_stem_im2col(int dtype, const float* x_nchw, void* cols, int N, int H, int W, int Kpad,
@@ -492,7 +495,8 @@ extern "C" int sm3_stem_im2col(int dtype, const float* x_nchw, void* cols, int N
     const FastDiv dc = make_fastdiv((uint32_t)(Kpad / E));
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(N * Ho), dim3(256), lds, st, x_nchw, (float*)cols, H, W, Ho, Wo, Kpad, dc),
-               hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, dim3(N * Ho), dim3(256), lds, st, x_nchw, (bf16_t*)cols, H, W, Ho, Wo, Kpad, dc));
+               hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, dim3(N * Ho), dim3(256), lds, st, x_nchw, (bf16_t*)cols, H, W, Ho, Wo, Kpad, dc),
+               hipLaunchKernelGGL(stem_im2col_kernel<f16_t>, dim3(N * Ho), dim3(256), lds, st, x_nchw, (f16_t*)cols, H, W, Ho, Wo, Kpad, dc));
     SM3_CHECK_LAUNCH();
     return 0;
 }
@@ -510,7 +514,8 @@ extern "C" int sm3_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* 
     const PixDiv dv = make_pixdiv(C / E, Wo, Ho);
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, (float*)y, argmax, N, H, W, C, Ho, Wo, (uint32_t)total, dv),
-               hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, argmax, N, H, W, C, Ho, Wo, (uint32_t)total, dv));
+               hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, argmax, N, H, W, C, Ho, Wo, (uint32_t)total, dv),
+               hipLaunchKernelGGL(maxpool_fwd_kernel<f16_t>, dim3(g), dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, argmax, N, H, W, C, Ho, Wo, (uint32_t)total, dv));
     SM3_CHECK_LAUNCH();
     return 0;
 }
@@ -528,7 +533,8 @@ extern "C" int sm3_maxpool3x3s2_bwd(int dtype, const uint8_t* argmax, const void
     const PixDiv dv = make_pixdiv(C / E, W, H);
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(g), dim3(256), 0, st, argmax, (const float*)dy, (float*)dx, N, H, W, C, Ho, Wo, (uint32_t)total, dv),
-               hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, argmax, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo, (uint32_t)total, dv));
+               hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, argmax, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo, (uint32_t)total, dv),
+               hipLaunchKernelGGL(maxpool_bwd_kernel<f16_t>, dim3(g), dim3(256), 0, st, argmax, (const f16_t*)dy, (f16_t*)dx, N, H, W, C, Ho, Wo, (uint32_t)total, dv));
     SM3_CHECK_LAUNCH();
     return 0;
 }
@@ -536,7 +542,7 @@ extern "C" int sm3_maxpool3x3s2_bwd(int dtype, const uint8_t* argmax, const void
 extern "C" int sm3_bn_relu_maxpool_fwd(int dtype, const void* x, const float* scale, const float* shift, void* y,
                                        uint8_t* argmax, int N, int H, int W, int C, int views, void* stream) {
     if (!x || !scale || !shift || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || views < 1 || N % views) return SM3_EINVAL;
-    if (dtype != SM3_F32 && dtype != SM3_BF16) return SM3_EDTYPE;
+    if (!SM3_DTYPE_OK(dtype)) return SM3_EDTYPE;
     const int E = dtype == SM3_F32 ? 4 : 8;
     if (C % E) return SM3_EALIGN;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
@@ -547,7 +553,8 @@ extern "C" int sm3_bn_relu_maxpool_fwd(int dtype, const void* x, const float* sc
     const PixDiv dv = make_pixdiv(C / E, Wo, Ho);
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, scale, shift, (float*)y, argmax, N, H, W, C, Ho, Wo, N / views, (uint32_t)total, dv),
-               hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, scale, shift, (bf16_t*)y, argmax, N, H, W, C, Ho, Wo, N / views, (uint32_t)total, dv));
+               hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, scale, shift, (bf16_t*)y, argmax, N, H, W, C, Ho, Wo, N / views, (uint32_t)total, dv),
+               hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<f16_t>, dim3(g), dim3(256), 0, st, (const f16_t*)x, scale, shift, (f16_t*)y, argmax, N, H, W, C, Ho, Wo, N / views, (uint32_t)total, dv));
     SM3_CHECK_LAUNCH();
     return 0;
 }
@@ -563,7 +570,7 @@ extern "C" int sm3_maxpool_bn_bwd(int dtype, const uint8_t* argmax, const void* 
                                   float* partials, int N, int H, int W, int C, int views, void* stream) {
     if (!argmax || !dy || !x || !scale || !shift || !mean || !invstd || !dz || !partials) return SM3_EINVAL;
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || views < 1 || N % views) return SM3_EINVAL;
-    if (dtype != SM3_F32 && dtype != SM3_BF16) return SM3_EDTYPE;
+    if (!SM3_DTYPE_OK(dtype)) return SM3_EDTYPE;
     const int E = dtype == SM3_F32 ? 4 : 8;
     if (C % E || C / E > 256) return SM3_EALIGN;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
@@ -580,7 +587,8 @@ extern "C" int sm3_maxpool_bn_bwd(int dtype, const uint8_t* argmax, const void* 
     dim3 grid(gx, gy, views);
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(maxpool_bn_bwd_kernel<float>, grid, dim3(256), 0, st, argmax, (const float*)dy, (const float*)x, scale, shift, mean, invstd, (float*)dz, partials, H, W, C, Ho, Wo, N / views, rows, tbx, tby, dhw, dw),
-               hipLaunchKernelGGL(maxpool_bn_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, argmax, (const bf16_t*)dy, (const bf16_t*)x, scale, shift, mean, invstd, (bf16_t*)dz, partials, H, W, C, Ho, Wo, N / views, rows, tbx, tby, dhw, dw));
+               hipLaunchKernelGGL(maxpool_bn_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, argmax, (const bf16_t*)dy, (const bf16_t*)x, scale, shift, mean, invstd, (bf16_t*)dz, partials, H, W, C, Ho, Wo, N / views, rows, tbx, tby, dhw, dw),
+               hipLaunchKernelGGL(maxpool_bn_bwd_kernel<f16_t>, grid, dim3(256), 0, st, argmax, (const f16_t*)dy, (const f16_t*)x, scale, shift, mean, invstd, (f16_t*)dz, partials, H, W, C, Ho, Wo, N / views, rows, tbx, tby, dhw, dw));
     SM3_CHECK_LAUNCH();
     return 0;
 }
@@ -595,7 +603,8 @@ extern "C" int sm3_avgpool_fwd(int dtype, const void* x, float* feat_f32, void* 
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(avgpool_fwd_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, feat_f32, (float*)feat_t, N, HW, C),
-               hipLaunchKernelGGL(avgpool_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, feat_f32, (bf16_t*)feat_t, N, HW, C));
+               hipLaunchKernelGGL(avgpool_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, feat_f32, (bf16_t*)feat_t, N, HW, C),
+               hipLaunchKernelGGL(avgpool_fwd_kernel<f16_t>, dim3(g), dim3(256), 0, st, (const f16_t*)x, feat_f32, (f16_t*)feat_t, N, HW, C));
     SM3_CHECK_LAUNCH();
     return 0;
 }
@@ -608,7 +617,8 @@ extern "C" int sm3_avgpool_bwd(int dtype, const void* dfeat, void* dx, int N, in
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)dfeat, (float*)dx, N, HW, C),
-               hipLaunchKernelGGL(avgpool_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)dfeat, (bf16_t*)dx, N, HW, C));
+               hipLaunchKernelGGL(avgpool_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)dfeat, (bf16_t*)dx, N, HW, C),
+               hipLaunchKernelGGL(avgpool_bwd_kernel<f16_t>, dim3(g), dim3(256), 0, st, (const f16_t*)dfeat, (f16_t*)dx, N, HW, C));
     SM3_CHECK_LAUNCH();
     return 0;
 }
@@ -622,7 +632,8 @@ extern "C" int sm3_weight_prep(int dtype, const float* w, int Co, int taps, int 
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(weight_prep_kernel<float>, dim3(g), dim3(256), 0, st, w, Co, taps, Ci, (float*)w_fwd, ld_fwd, (float*)w_dgrad),
-               hipLaunchKernelGGL(weight_prep_kernel<bf16_t>, dim3(g), dim3(256), 0, st, w, Co, taps, Ci, (bf16_t*)w_fwd, ld_fwd, (bf16_t*)w_dgrad));
+               hipLaunchKernelGGL(weight_prep_kernel<bf16_t>, dim3(g), dim3(256), 0, st, w, Co, taps, Ci, (bf16_t*)w_fwd, ld_fwd, (bf16_t*)w_dgrad),
+               hipLaunchKernelGGL(weight_prep_kernel<f16_t>, dim3(g), dim3(256), 0, st, w, Co, taps, Ci, (f16_t*)w_fwd, ld_fwd, (f16_t*)w_dgrad));
     SM3_CHECK_LAUNCH();
     return 0;
 }
@@ -632,7 +643,8 @@ extern "C" int sm3_weight_prep_batch(int dtype, const sm3_wprep_item* items_devi
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(weight_prep_batch_kernel<float>, dim3(96, n), dim3(256), 0, st, items_device),
-               hipLaunchKernelGGL(weight_prep_batch_kernel<bf16_t>, dim3(96, n), dim3(256), 0, st, items_device));
+               hipLaunchKernelGGL(weight_prep_batch_kernel<bf16_t>, dim3(96, n), dim3(256), 0, st, items_device),
+               hipLaunchKernelGGL(weight_prep_batch_kernel<f16_t>, dim3(96, n), dim3(256), 0, st, items_device));
     SM3_CHECK_LAUNCH();
     return 0;
 }
@@ -643,7 +655,8 @@ extern "C" int sm3_cast_from_f32(int dtype, const float* src, void* dst, int64_t
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(cast_from_f32_kernel<float>, dim3(g), dim3(256), 0, st, src, (float*)dst, n),
-               hipLaunchKernelGGL(cast_from_f32_kernel<bf16_t>, dim3(g), dim3(256), 0, st, src, (bf16_t*)dst, n));
+               hipLaunchKernelGGL(cast_from_f32_kernel<bf16_t>, dim3(g), dim3(256), 0, st, src, (bf16_t*)dst, n),
+               hipLaunchKernelGGL(cast_from_f32_kernel<f16_t>, dim3(g), dim3(256), 0, st, src, (f16_t*)dst, n));
     SM3_CHECK_LAUNCH();
     return 0;
 }
@@ -654,7 +667,8 @@ extern "C" int sm3_cast_to_f32(int dtype, const void* src, float* dst, int64_t n
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(cast_to_f32_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)src, dst, n),
-               hipLaunchKernelGGL(cast_to_f32_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)src, dst, n));
+               hipLaunchKernelGGL(cast_to_f32_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)src, dst, n),
+               hipLaunchKernelGGL(cast_to_f32_kernel<f16_t>, dim3(g), dim3(256), 0, st, (const f16_t*)src, dst, n));
     SM3_CHECK_LAUNCH();
     return 0;
 }

@@ -20,7 +20,7 @@
 //
 // Reference call sites replaced: nn.Conv2d(3, 64, 7, 2, 3) forward (src/models/resnet.py:208-210,294) and its
 // autograd weight gradient, plus phase 2 of bn1's backward (resnet.py:211,295).
-#include "common.h"
+#include "conv_common.h"
 
 namespace {
 
@@ -80,8 +80,9 @@ __device__ __forceinline__ void store_patch(float* patch, const PatchRegs& r) {
     if (tid < NG * 8) patch[(tid >> 3) * PW + 256 + (tid & 7)] = r.vt;
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const uint4* __restrict__ w,
-                                                       bf16_t* __restrict__ y, float* __restrict__ partials, int N,
+                                                       T* __restrict__ y, float* __restrict__ partials, int N,
                                                        int H, int W, int Ho, int Wo, int xblocks, long tiles) {
     __shared__ __attribute__((aligned(16))) float patch[NG * PW];  // reused as the bf16 output tile
     __shared__ float sStat[4][64][2];
@@ -118,13 +119,10 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
             if (g < NG) {
                 const float2* src = reinterpret_cast<const float2*>(patch + g * PW + 2 * px);
                 const float2 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-                a = make_uint4(pack_bf16x2(v0.x, v0.y), pack_bf16x2(v1.x, v1.y), pack_bf16x2(v2.x, v2.y),
-                               pack_bf16x2(v3.x, v3.y));
+                a = make_uint4(pack2<T>(v0.x, v0.y), pack2<T>(v1.x, v1.y), pack2<T>(v2.x, v2.y), pack2<T>(v3.x, v3.y));
             }
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
-                                                                 __builtin_bit_cast(bf16x8, bfrag[ks][nb]), acc[nb], 0, 0, 0);
+            for (int nb = 0; nb < 2; ++nb) sm3conv::mma_frag<T>(a, bfrag[ks][nb], acc[nb]);
         }
         __syncthreads();  // everyone is done reading the patch: its LDS becomes the output tile
         char* sOut = reinterpret_cast<char*>(patch);
@@ -134,10 +132,10 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const uint16_t b = f32_to_bf16(acc[nb][r]);
+                const uint16_t b = (uint16_t)pack2<T>(acc[nb][r], 0.f);
                 *reinterpret_cast<uint16_t*>(sOut + row * OUT_PITCH + (nb * 32 + col) * 2) = b;
                 if (tl.x0 + row < Wo) {  // statistics of the stored (rounded) values of real pixels only
-                    const float v = bf16_to_f32(b);
+                    const float v = ElemTraits<T>::round(acc[nb][r]);
                     s1 += v;
                     s2 += v * v;
                 }
@@ -174,8 +172,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 // ---- weight gradient with the BatchNorm-backward apply fused into the dxo operand -----------------------------
 struct StemWgradParams {
     const float* x;
-    const bf16_t* dz;
-    const bf16_t* xo;
+    const char* dz;
+    const char* xo;
     const float *mean, *invstd, *gamma;       // [views][64], [views][64], [64] (nullable)
     const double *gsums, *lsums;              // [views][128]
     float *dgamma, *dbeta;                    // nullable
@@ -187,6 +185,7 @@ struct StemWgradParams {
 
 __device__ __forceinline__ uint32_t swz128(int row) { return (uint32_t)((row >> 1) & 1) << 6; }
 
+template <typename T>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradParams p) {
     __shared__ __attribute__((aligned(16))) float patch[NG * PW];
     __shared__ __attribute__((aligned(16))) char sD[128 * 128];  // dxo tile [pixel][64 co] bf16, swizzled for tr reads
@@ -226,8 +225,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradParams p
         for (int k = 0; k < 4; ++k) {
             const int row = r0 + 32 * k;
             const bool ok = tl.x0 + row < p.Wo;
-            gu[k] = ok ? ldg16<true>(p.dz + (pix0 + row) * 64 + ch * 8) : make_uint4(0, 0, 0, 0);
-            xu[k] = ok ? ldg16<true>(p.xo + (pix0 + row) * 64 + ch * 8) : make_uint4(0, 0, 0, 0);
+            gu[k] = ok ? ldg16<true>(p.dz + ((pix0 + row) * 64 + ch * 8) * 2) : make_uint4(0, 0, 0, 0);
+            xu[k] = ok ? ldg16<true>(p.xo + ((pix0 + row) * 64 + ch * 8) * 2) : make_uint4(0, 0, 0, 0);
         }
         load_patch(pre, p.x, tl, p.H, p.W);
     };
@@ -253,11 +252,11 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradParams p
             uint4 out = make_uint4(0, 0, 0, 0);
             if (tl.x0 + row < p.Wo) {
                 float g[8], xv[8];
-                unpack16<bf16_t>(gu[k], g);
-                unpack16<bf16_t>(xu[k], xv);
+                unpack16<T>(gu[k], g);
+                unpack16<T>(xu[k], xv);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) g[e] = k0[e] * (g[e] - k1[e]) - (xv[e] - mu[e]) * q[e];
-                out = pack16<bf16_t>(g);
+                out = pack16<T>(g);
             }
             *reinterpret_cast<uint4*>(sD + row * 128 + (((uint32_t)ch * 16u) ^ swz128(row))) = out;
         }
@@ -289,11 +288,10 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradParams p
                 uint4 fb = make_uint4(0, 0, 0, 0);
                 if (g < NG) {
                     const float* src = patch + g * PW + 2 * (16 * s + 8 * bh) + kw;
-                    fb = make_uint4(pack_bf16x2(src[0], src[2]), pack_bf16x2(src[4], src[6]), pack_bf16x2(src[8], src[10]),
-                                    pack_bf16x2(src[12], src[14]));
+                    fb = make_uint4(pack2<T>(src[0], src[2]), pack2<T>(src[4], src[6]), pack2<T>(src[8], src[10]),
+                                    pack2<T>(src[12], src[14]));
                 }
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa),
-                                                                __builtin_bit_cast(bf16x8, fb), acc[j], 0, 0, 0);
+                sm3conv::mma_frag<T>(fa, fb, acc[j]);
             }
         }
         __syncthreads();  // everyone is done reading this tile's operands
@@ -317,7 +315,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradParams p
 }
 
 // master [64][kh][kw][c] fp32 -> bf16 [64][176], k = (kh*3 + c)*8 + kw, zero where kw == 7 or k >= 168
-__global__ void stem_weight_prep_kernel(const float* __restrict__ w, bf16_t* __restrict__ out) {
+template <typename T>
+__global__ void stem_weight_prep_kernel(const float* __restrict__ w, T* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 64 * KPAD) return;
     const int co = i / KPAD, k = i - co * KPAD;
@@ -327,7 +326,7 @@ __global__ void stem_weight_prep_kernel(const float* __restrict__ w, bf16_t* __r
         const int kh = g / 3, c = g - 3 * kh;
         v = w[co * 147 + (kh * 7 + kw) * 3 + c];
     }
-    out[i].v = f32_to_bf16(v);
+    out[i].v = (uint16_t)pack2<T>(v, 0.f);
 }
 
 int stem_geometry(int N, int H, int W, int& Ho, int& Wo, int& xblocks, long& tiles) {
@@ -351,9 +350,14 @@ extern "C" int sm3_stem_partial_rows(int N, int H, int W) {
 
 extern "C" int sm3_stem_weight_prep(int dtype, const float* w_master, void* w_stem, void* stream) {
     if (!w_master || !w_stem) return SM3_EINVAL;
-    if (dtype != SM3_BF16) return SM3_EDTYPE;
-    hipLaunchKernelGGL(stem_weight_prep_kernel, dim3((64 * KPAD + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_master,
-                       (bf16_t*)w_stem);
+    if (dtype == SM3_BF16)
+        hipLaunchKernelGGL(stem_weight_prep_kernel<bf16_t>, dim3((64 * KPAD + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                           w_master, (bf16_t*)w_stem);
+    else if (dtype == SM3_F16)
+        hipLaunchKernelGGL(stem_weight_prep_kernel<f16_t>, dim3((64 * KPAD + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                           w_master, (f16_t*)w_stem);
+    else
+        return SM3_EDTYPE;
     SM3_CHECK_LAUNCH();
     return 0;
 }
@@ -361,13 +365,17 @@ extern "C" int sm3_stem_weight_prep(int dtype, const float* w_master, void* w_st
 extern "C" int sm3_stem_conv_fwd(int dtype, const float* x_nchw, const void* w_stem, void* y, float* stat_partials, int N,
                                  int H, int W, void* stream) {
     if (!x_nchw || !w_stem || !y) return SM3_EINVAL;
-    if (dtype != SM3_BF16) return SM3_EDTYPE;  // the exact-f32 parity mode keeps the im2col + gather-GEMM path
+    if (dtype != SM3_BF16 && dtype != SM3_F16) return SM3_EDTYPE;  // the exact-f32 parity mode keeps im2col + gather-GEMM
     int Ho, Wo, xb;
     long tiles;
     if (int rc = stem_geometry(N, H, W, Ho, Wo, xb, tiles)) return rc;
     const unsigned grid = (unsigned)(tiles < 768 ? tiles : 768);  // persistent: 3 workgroups per CU (136 VGPRs)
-    hipLaunchKernelGGL(stem_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x_nchw, (const uint4*)w_stem,
-                       (bf16_t*)y, stat_partials, N, H, W, Ho, Wo, xb, tiles);
+    if (dtype == SM3_BF16)
+        hipLaunchKernelGGL(stem_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x_nchw,
+                           (const uint4*)w_stem, (bf16_t*)y, stat_partials, N, H, W, Ho, Wo, xb, tiles);
+    else
+        hipLaunchKernelGGL(stem_fwd_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x_nchw,
+                           (const uint4*)w_stem, (f16_t*)y, stat_partials, N, H, W, Ho, Wo, xb, tiles);
     SM3_CHECK_LAUNCH();
     return 0;
 }
@@ -378,15 +386,18 @@ extern "C" int sm3_stem_wgrad_bn(int dtype, const float* x_nchw, const void* dz,
                                  int views, void* stream) {
     if (!x_nchw || !dz || !xo || !mean || !invstd || !global_sums || !dw || count <= 0 || views < 1 || N % views)
         return SM3_EINVAL;
-    if (dtype != SM3_BF16) return SM3_EDTYPE;
+    if (dtype != SM3_BF16 && dtype != SM3_F16) return SM3_EDTYPE;
     StemWgradParams p;
     if (int rc = stem_geometry(N, H, W, p.Ho, p.Wo, p.xblocks, p.tiles)) return rc;
-    p.x = x_nchw; p.dz = (const bf16_t*)dz; p.xo = (const bf16_t*)xo;
+    p.x = x_nchw; p.dz = (const char*)dz; p.xo = (const char*)xo;
     p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.gsums = global_sums; p.lsums = local_sums;
     p.dgamma = dgamma; p.dbeta = dbeta; p.dw = dw; p.inv_count = 1.0 / count;
     p.N = N; p.H = H; p.W = W; p.n_per_view = N / views; p.views = views;
     const unsigned grid = (unsigned)(p.tiles < 768 ? p.tiles : 768);
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    if (dtype == SM3_BF16)
+        hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(stem_wgrad_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     SM3_CHECK_LAUNCH();
     return 0;
 }

@@ -7,17 +7,18 @@ import os
 
 import torch
 
-_DEFAULT_DTYPE = {"bf16": torch.bfloat16, "f32": torch.float32, "fp32": torch.float32}[
+_DEFAULT_DTYPE = {"bf16": torch.bfloat16, "f32": torch.float32, "fp32": torch.float32, "f16": torch.float16,
+                  "fp16": torch.float16}[
     os.environ.get("SM3_DTYPE", "bf16").lower()
 ]
 
 
 def set_default_dtype(dtype):
-    """Activation/MFMA dtype of engines created afterwards: torch.bfloat16 (throughput) or torch.float32
-    (exact-f32 MFMA parity mode)."""
+    """Activation/MFMA dtype of engines created afterwards: torch.bfloat16 (throughput), torch.float16 (the reference's
+    AMP storage type; the fused trainer then runs dynamic loss scaling) or torch.float32 (exact-f32 MFMA parity mode)."""
     global _DEFAULT_DTYPE
-    if dtype not in (torch.bfloat16, torch.float32):
-        raise ValueError("sm3hip supports torch.bfloat16 and torch.float32")
+    if dtype not in (torch.bfloat16, torch.float16, torch.float32):
+        raise ValueError("sm3hip supports torch.bfloat16, torch.float16 and torch.float32")
     _DEFAULT_DTYPE = dtype
 
 

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SM3_LIBRARY") or os.path.join(_HERE, "libsm3hip.so")  # override: A/B of two builds
 
-SM3_F32, SM3_BF16 = 0, 1
+SM3_F32, SM3_BF16, SM3_F16 = 0, 1, 2
 MAX_TAPS = 9
 
 
@@ -86,6 +86,9 @@ SIGNATURES = {
     "sm3_ce_label0": [_P, _I, _I, _F, _P, _P, _P],
     "sm3_ntxent_fused": [_I, _P, _I, _I, _F, _F, _P, _P, _P, _P],
     "sm3_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P, _P],
+    "sm3_adamw_dynamic": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P],
+    "sm3_loss_scale_update": [_P, _P, _P, _P, _F, _F, _I, _P],
+    "sm3_ntxent_fused_scaled": [_I, _P, _I, _I, _F, _F, _P, _P, _P, _P, _P],
     "sm3_check_finite": [_P, _L, _P, _P],
     "sm3_token_attention": [_I, _P, _P, _I, _I, _I, _I, _P],
     "sm3_add_layernorm": [_I, _P, _P, _P, _P, _F, _P, _L, _I, _P],

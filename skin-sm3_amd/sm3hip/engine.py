@@ -21,7 +21,7 @@ from collections import OrderedDict
 import torch
 
 from . import ops
-from ._lib import SM3_BF16, SM3_F32
+from ._lib import SM3_BF16, SM3_F16, SM3_F32
 
 import os as _os
 _APPLY_OUT_OF_PLACE = _os.environ.get("SM3_BN_APPLY_OOP", "0") == "1"
@@ -282,7 +282,7 @@ class SM3Engine:
         self._streams, self._streams_dev = None, None
         # 7x7 stem straight from the NCHW images (csrc/stem.hip): no im2col matrix, BN-backward apply fused into the
         # stem weight gradient.  bf16 only; the exact-f32 parity mode keeps im2col + gather-GEMM.
-        self.direct_stem = self.dtype == SM3_BF16 and _os.environ.get("SM3_DIRECT_STEM", "1") != "0"
+        self.direct_stem = self.dtype in (SM3_BF16, SM3_F16) and _os.environ.get("SM3_DIRECT_STEM", "1") != "0"
 
     # ---- setup ---------------------------------------------------------------------------
     def _all_conv_units(self):

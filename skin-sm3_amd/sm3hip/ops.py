@@ -8,10 +8,10 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, SM3_BF16, SM3_F32, check
+from ._lib import ConvDesc, SM3_BF16, SM3_F16, SM3_F32, check
 
-TORCH_DTYPE = {SM3_F32: torch.float32, SM3_BF16: torch.bfloat16}
-K_CHUNK = {SM3_F32: 32, SM3_BF16: 64}  # elements per 128-byte K chunk
+TORCH_DTYPE = {SM3_F32: torch.float32, SM3_BF16: torch.bfloat16, SM3_F16: torch.float16}
+K_CHUNK = {SM3_F32: 32, SM3_BF16: 64, SM3_F16: 64}  # elements per 128-byte K chunk
 
 
 _PROFILER = None
@@ -97,6 +97,8 @@ def dtype_code(torch_dtype):
         return SM3_F32
     if torch_dtype == torch.bfloat16:
         return SM3_BF16
+    if torch_dtype == torch.float16:
+        return SM3_F16
     raise ValueError(f"unsupported activation dtype {torch_dtype}")
 
 
@@ -705,14 +707,21 @@ def ce_label0(logits, weight, loss, dlogits):
     check(_lib.load().sm3_ce_label0(_ptr(logits), R, Cc, weight, _ptr(loss), _ptr(dlogits), _stream()), "sm3_ce_label0")
 
 
-def ntxent_fused(dtype, z, temperature, weight, workspace, loss, dz):
+def ntxent_fused(dtype, z, temperature, weight, workspace, loss, dz, dz_scale=None):
+    """dz_scale: optional 1-element fp32 device tensor multiplied into dz (dynamic loss scale of the fp16 mode)."""
     _chk(z, torch.float32); _chk(workspace, torch.float32); _chk(loss, torch.float32); _chk(dz, TORCH_DTYPE[dtype])
+    _chk(dz_scale, torch.float32, "dz_scale")
     R, D = z.shape
     if workspace.numel() < R * D + 2 * R or dz.numel() != R * D:
         raise ValueError("ntxent_fused: size mismatch")
     with _prof("ntxent_fused", 6.0 * R * R * D, 4.0 * R * D * 3):
-        check(_lib.load().sm3_ntxent_fused(dtype, _ptr(z), R, D, temperature, weight, _ptr(workspace), _ptr(loss),
-                                           _ptr(dz), _stream()), "sm3_ntxent_fused")
+        if dz_scale is None:
+            check(_lib.load().sm3_ntxent_fused(dtype, _ptr(z), R, D, temperature, weight, _ptr(workspace), _ptr(loss),
+                                               _ptr(dz), _stream()), "sm3_ntxent_fused")
+        else:
+            check(_lib.load().sm3_ntxent_fused_scaled(dtype, _ptr(z), R, D, temperature, weight, _ptr(dz_scale),
+                                                      _ptr(workspace), _ptr(loss), _ptr(dz), _stream()),
+                  "sm3_ntxent_fused_scaled")
 
 
 # ------------------------------------------------------------------------------------------
@@ -727,6 +736,29 @@ def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0,
     with _prof("adamw", 0.0, 28.0 * p.numel()):
         check(_lib.load().sm3_adamw(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay,
                                     step, grad_scale, _ptr(found_inf), _stream()), "sm3_adamw")
+
+
+def adamw_dynamic(p, g, m, v, lr, beta1, beta2, eps, weight_decay, grad_scale, loss_scale, steps_taken, found_inf):
+    """AdamW under device-resident dynamic loss scaling (sm3_adamw_dynamic)."""
+    for t in (p, g, m, v):
+        _chk(t, torch.float32)
+        if t.numel() != p.numel():
+            raise ValueError("adamw_dynamic: size mismatch")
+    _chk(loss_scale, torch.float32); _chk(steps_taken, torch.int32); _chk(found_inf, torch.int32)
+    with _prof("adamw", 0.0, 28.0 * p.numel()):
+        check(_lib.load().sm3_adamw_dynamic(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps,
+                                            weight_decay, grad_scale, _ptr(loss_scale), _ptr(steps_taken), _ptr(found_inf),
+                                            _stream()), "sm3_adamw_dynamic")
+
+
+def loss_scale_update(loss_scale, found_inf, growth_tracker, steps_taken, growth_factor=2.0, backoff_factor=0.5,
+                      growth_interval=2000):
+    """torch.cuda.amp.GradScaler.update() on device state (sm3_loss_scale_update)."""
+    _chk(loss_scale, torch.float32); _chk(found_inf, torch.int32); _chk(growth_tracker, torch.int32)
+    _chk(steps_taken, torch.int32)
+    check(_lib.load().sm3_loss_scale_update(_ptr(loss_scale), _ptr(found_inf), _ptr(growth_tracker), _ptr(steps_taken),
+                                            growth_factor, backoff_factor, int(growth_interval), _stream()),
+          "sm3_loss_scale_update")
 
 
 def check_finite(g, found_inf):

@@ -16,7 +16,10 @@ from .bridge import sm3_engine_for
 
 class SM3Trainer:
     def __init__(self, model, lr, weight_decay=5e-2, eps=1e-5, betas=(0.9, 0.999), style=0, data_parallel=None,
-                 sync_bn=None):
+                 sync_bn=None, loss_scale=None, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5,
+                 growth_interval=2000):
+        """loss_scale: None = on exactly when the model's arithmetic is fp16 (the reference's AMP recipe: autocast +
+        GradScaler with its defaults, tools/backbone_train.py:98,125-127,480); True / False force it."""
         self.model = model
         self.kind = model._KIND
         self.lr, self.wd, self.eps, self.betas, self.style = lr, weight_decay, eps, betas, style
@@ -29,6 +32,9 @@ class SM3Trainer:
         self._handles = []
         self._pending = []
         self.loss = None
+        self.loss_scale = loss_scale
+        self.scaler_cfg = (float(init_scale), float(growth_factor), float(backoff_factor), int(growth_interval))
+        self._scaler = None  # device state: scale, found_inf, growth tracker, optimizer steps taken
 
     # ---- loss weights: tools/backbone_train.py:99-121 -----------------------------------
     def _weights(self, names):
@@ -67,6 +73,35 @@ class SM3Trainer:
         b = st.offsets[names[hi]] + (st._view(st.flat_g, names[hi]).numel() + 15) // 16 * 16
         self._handles.append(dist.all_reduce(st.flat_g[a:b], async_op=True, group=self._groups["grads"]))
 
+    # ---- dynamic loss scaling (fp16): torch.cuda.amp.GradScaler with its state on the device ----------------
+    def _scaler_state(self, dev, dtype):
+        on = self.loss_scale if self.loss_scale is not None else (dtype == torch.float16)
+        if not on:
+            return None
+        if self._scaler is None or self._scaler["scale"].device != dev:
+            self._scaler = {"scale": torch.full((1,), self.scaler_cfg[0], dtype=torch.float32, device=dev),
+                            "found_inf": torch.zeros(1, dtype=torch.int32, device=dev),
+                            "tracker": torch.zeros(1, dtype=torch.int32, device=dev),
+                            "steps": torch.full((1,), self.step_count, dtype=torch.int32, device=dev)}
+        return self._scaler
+
+    def scaler_state_dict(self):
+        """The "scaler" entry of the reference's checkpoint (GradScaler.state_dict(), backbone_train.py:586)."""
+        if self._scaler is None:
+            return {}
+        return {"scale": float(self._scaler["scale"]), "growth_factor": self.scaler_cfg[1],
+                "backoff_factor": self.scaler_cfg[2], "growth_interval": self.scaler_cfg[3],
+                "_growth_tracker": int(self._scaler["tracker"])}
+
+    def load_scaler_state_dict(self, sd):
+        if not sd:
+            return
+        self.scaler_cfg = (float(sd["scale"]), float(sd["growth_factor"]), float(sd["backoff_factor"]),
+                           int(sd["growth_interval"]))
+        if self._scaler is not None:
+            self._scaler["scale"].fill_(float(sd["scale"]))
+            self._scaler["tracker"].fill_(int(sd.get("_growth_tracker", 0)))
+
     def step(self, derm_imgs, clinic_imgs):
         """One optimizer step on this rank's batch; returns the (device, fp32, 1-element) loss tensor."""
         with ops.stream_scope():  # launches outside the lanes go to the stream that is current now
@@ -87,22 +122,38 @@ class SM3Trainer:
         weights = self._weights(list(zs))
         dz = {}
         T = float(self.model.temperature)
+        sc = self._scaler_state(dev, eng.tdt)
         for name, z in zs.items():
             R, D = z.shape
             ws = eng._work("ntxent_ws", R * D + 2 * R)
             dz[name] = torch.empty(R, D, dtype=eng.tdt, device=dev)
-            ops.ntxent_fused(eng.dtype, z, T, weights[name], ws, loss, dz[name])
+            ops.ntxent_fused(eng.dtype, z, T, weights[name], ws, loss, dz[name],
+                             dz_scale=sc["scale"] if sc is not None else None)
         self._handles = []
         eng.grad_ready = (lambda f, l: self._bucket_ready(eng, f, l)) if self.dp else None
         eng.backward(saved, dz)
         eng.grad_ready = None
         for h in self._handles:
             h.wait()
-        self.step_count += 1
-        ops.adamw(st.flat_p, st.flat_g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
-                  self.step_count, 1.0 / self.world)
+        if sc is None:
+            self.step_count += 1
+            ops.adamw(st.flat_p, st.flat_g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                      self.step_count, 1.0 / self.world)
+        else:
+            # GradScaler.step() + update() (backbone_train.py:126-127) without a host synchronisation: inf / nan check
+            # of the (all-reduced, still scaled) gradients, unscale + AdamW skipped on overflow, scale update
+            ops.check_finite(st.flat_g, sc["found_inf"])
+            ops.adamw_dynamic(st.flat_p, st.flat_g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
+                              self.wd, 1.0 / self.world, sc["scale"], sc["steps"], sc["found_inf"])
+            ops.loss_scale_update(sc["scale"], sc["found_inf"], sc["tracker"], sc["steps"], self.scaler_cfg[1],
+                                  self.scaler_cfg[2], self.scaler_cfg[3])
+            self.step_count += 1  # calls made; the number of optimizer steps TAKEN lives on the device (steps_taken())
         self.loss = loss
         return loss
+
+    def steps_taken(self):
+        """Optimizer steps actually applied (a step skipped for an fp16 overflow does not count); synchronises."""
+        return int(self._scaler["steps"]) if self._scaler is not None else self.step_count
 
     # ---- checkpoint wire format: tools/backbone_train.py:578-587 ---------------------------
     def optimizer_state_dict(self):
@@ -113,7 +164,7 @@ class SM3Trainer:
         state = {}
         if self.m is not None:  # before the first step torch.optim.AdamW's state is empty too
             for i, n in enumerate(st.names):
-                state[i] = {"step": torch.tensor(float(self.step_count)),
+                state[i] = {"step": torch.tensor(float(self.steps_taken())),
                             "exp_avg": st._view(self.m, n).clone(), "exp_avg_sq": st._view(self.v, n).clone()}
         group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.wd, "amsgrad": False,
                  "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
@@ -134,5 +185,7 @@ class SM3Trainer:
             st._view(self.m, n).copy_(s["exp_avg"])
             st._view(self.v, n).copy_(s["exp_avg_sq"])
             self.step_count = int(s["step"])
+        if self._scaler is not None:
+            self._scaler["steps"].fill_(self.step_count)
         g = sd["param_groups"][0]
         self.lr, self.wd, self.eps, self.betas = g["lr"], g["weight_decay"], g["eps"], tuple(g["betas"])

@@ -9,8 +9,10 @@ Differences, stated: the derm7pt dataset and its PIL augmentation pipeline are h
 (SURVEY.md 2.1 #9-10), so `--data-name synthetic` generates normalised image pairs on the device; `--engine fused`
 (default) runs the fused step of sm3hip.trainer.SM3Trainer, `--engine compat` runs the reference's literal loop
 (model(...) -> CrossEntropyLoss -> backward -> torch.optim.AdamW, backbone_train.py:98-127) on the same kernels.
-`--amp` selects bf16 MFMA (the reference's fp16 autocast + GradScaler has no role with bf16's exponent range);
-without it the exact-f32 MFMA mode runs.
+`--amp` selects 16-bit MFMA arithmetic: `--amp-dtype bf16` (default; BASELINE.json's benchmark type, needs no loss
+scaling) or `--amp-dtype fp16` -- the reference's own AMP recipe (fp16 autocast + GradScaler, backbone_train.py:27,98,
+125-127,480): fp16 storage + f16 MFMA with dynamic loss scaling, on the device in the fused engine and through
+torch.cuda.amp.GradScaler itself in the compat engine; without `--amp` the exact-f32 MFMA mode runs.
 """
 import argparse
 import os
@@ -54,6 +56,7 @@ def get_parser():
     p.add_argument("--save-freq", type=int, default=50)
     p.add_argument("--print-freq", type=int, default=50)
     p.add_argument("--amp", action="store_true")
+    p.add_argument("--amp-dtype", default="bf16", choices=["bf16", "fp16"])
     p.add_argument("--resume-path", type=str, default=None)
     p.add_argument("--log-path", type=str, default="./logs")
     p.add_argument("--engine", default="fused", choices=["fused", "compat"])
@@ -96,7 +99,8 @@ def main(local_rank, args):
     cls = SimCLRSkinV3 if args.arch_version in ("v3", "v311", "v312") else SimCLRSkinV32
     model = cls(arch=args.arch, weights=args.arch_weights, proj_dim=args.proj_dim, temperature=args.temperature,
                 use_checkpoint=args.use_checkpoint)
-    model.sm3_dtype = torch.bfloat16 if args.amp else torch.float32
+    model.sm3_dtype = (torch.float16 if args.amp_dtype == "fp16" else torch.bfloat16) if args.amp else torch.float32
+    fp16 = args.amp and args.amp_dtype == "fp16"
     if world > 1:
         model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
     model = model.to(dev)
@@ -110,6 +114,7 @@ def main(local_rank, args):
         wrapped = nn.parallel.DistributedDataParallel(model, device_ids=[local_rank]) if world > 1 else model
         optimizer = torch.optim.AdamW(wrapped.parameters(), lr=args.base_lr, weight_decay=args.wd, eps=1e-5)
         criterion = nn.CrossEntropyLoss()
+        scaler = torch.amp.GradScaler("cuda", enabled=fp16)  # backbone_train.py:480
 
     if args.resume_path:
         ckpt = torch.load(args.resume_path, map_location=dev)
@@ -117,8 +122,11 @@ def main(local_rank, args):
         start_epoch = ckpt.get("epoch", 0)
         if args.engine == "fused" and "optimizer" in ckpt:
             trainer.load_optimizer_state_dict(ckpt["optimizer"])
+            trainer.load_scaler_state_dict(ckpt.get("scaler"))
         elif args.engine == "compat" and "optimizer" in ckpt:
             optimizer.load_state_dict(ckpt["optimizer"])
+            if ckpt.get("scaler"):
+                scaler.load_state_dict(ckpt["scaler"])
 
     gen = torch.Generator(device=dev).manual_seed(args.seed + local_rank)
     os.makedirs(args.log_path, exist_ok=True)
@@ -134,8 +142,9 @@ def main(local_rank, args):
                 w = 0.25 if style == 2 else 0.5
                 loss = criterion(*outputs[0]) + criterion(*outputs[1]) + sum(w * criterion(*o) for o in outputs[2])
                 optimizer.zero_grad(set_to_none=True)
-                loss.backward()
-                optimizer.step()
+                scaler.scale(loss).backward()  # backbone_train.py:125-127 (identity when not fp16)
+                scaler.step(optimizer)
+                scaler.update()
             seen += bs * world
             if local_rank == 0 and it % args.print_freq == 0:
                 running = float(loss)  # the only host sync, every print_freq steps
@@ -145,7 +154,7 @@ def main(local_rank, args):
         if local_rank == 0:
             state = {"epoch": epoch + 1, "state_dict": model.state_dict(),
                      "optimizer": trainer.optimizer_state_dict() if args.engine == "fused" else optimizer.state_dict(),
-                     "scaler": {}}
+                     "scaler": trainer.scaler_state_dict() if args.engine == "fused" else scaler.state_dict()}
             path = os.path.join(args.log_path, "checkpoint.pth.tar")
             torch.save(state, path)
             if (epoch + 1) % args.save_freq == 0:

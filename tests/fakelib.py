@@ -25,7 +25,7 @@ class _FakeFn:
             n, h, w = (int(a) for a in args)
             return n * ((h - 1) // 2 + 1) * (((w - 1) // 2 + 1 + 127) // 128)
         if self.name == "sm3_abi_version":
-            return 3
+            return 4
         return 0
 
 

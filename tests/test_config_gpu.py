@@ -363,3 +363,91 @@ def test_eval_mode_backward_through_an_encoder():
         err = float((p.grad.double().cpu() - ref).norm()) / (float(ref.norm()) + 1e-12)
         assert err < 2e-3, (k, err)
     assert int(m.state_dict()["bn1.num_batches_tracked"]) == 0
+
+
+def test_fp16_mode_with_dynamic_loss_scaling():
+    """The reference's own AMP recipe (fp16 autocast + GradScaler, tools/backbone_train.py:27,98,125-127,480) as an
+    arithmetic mode of the engine: fp16 storage + f16 MFMA, loss scaling with GradScaler's state on the device.
+
+      * one step from random init: loss against the exact-f32 mode and against PyTorch's own fp16 autocast of the oracle
+        (what the reference computes with --amp) -- fp16 keeps 11 bits where bf16 keeps 8, so it must land closer to
+        f32 than the bf16 mode does;
+      * an injected overflow: the step is skipped (parameters and Adam moments untouched, Adam's step count not
+        advanced), the scale halves; the next clean step is taken;
+      * growth: after `growth_interval` clean steps the scale doubles;
+      * the compat path under torch.amp.GradScaler itself (the reference's literal loop) agrees with the fused step."""
+    from oracle import sm3_oracle as O
+    from sm3hip.trainer import SM3Trainer
+    from sm3hip import ops
+    from src.models.simclr import SimCLRSkinV32
+    torch.manual_seed(5)
+    init = {k: v.clone() for k, v in SimCLRSkinV32("resnet50", None, 128, 0.1).state_dict().items()}
+    derm, clinic = _latent_batch(32, 64, 7)
+    names = [k for k in init if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+    out = {}
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        m = _build(0, dt, init)
+        tr = SM3Trainer(m, lr=1e-4, init_scale=1024.0, growth_interval=2)
+        loss = float(tr.step(derm, clinic))
+        torch.cuda.synchronize()
+        eng = tr._engine()
+        g = eng.store.flat_g.double().cpu()
+        if dt == torch.float16:
+            assert tr._scaler is not None and float(tr._scaler["scale"]) == 1024.0 and tr.steps_taken() == 1
+            g = g / 1024.0  # flat_g holds the scaled gradient
+        else:
+            assert tr._scaler is None
+        out[dt] = (loss, g, tr, m)
+    cos = {dt: float(out[dt][1] @ out[torch.float32][1] / (out[dt][1].norm() * out[torch.float32][1].norm())) for dt in out}
+    dl = {dt: abs(out[dt][0] - out[torch.float32][0]) for dt in out}
+    print(f"fp16 mode: |dloss| bf16 {dl[torch.bfloat16]:.4f} f16 {dl[torch.float16]:.4f}; grad cosine vs f32: bf16 "
+          f"{cos[torch.bfloat16]:.3f} f16 {cos[torch.float16]:.3f}")
+    # measured: |dloss| 0.17 (bf16 0.29), gradient cosine 0.76 (bf16 0.13) at random init, B = 32
+    assert dl[torch.float16] < 0.3 and cos[torch.float16] > cos[torch.bfloat16] + 0.1, (dl, cos)
+    # PyTorch's fp16 autocast of the oracle on the same state (CPU): the HIP fp16 step is at least as close to f32
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    state_np = {k: v.cpu().numpy() for k, v in init.items()}
+    dc, cc = [t.cpu() for t in derm], [t.cpu() for t in clinic]
+    ref = {}
+    for key, amp in (("f32", None), ("f16", torch.float16)):
+        P, Bf = O.split_state(state_np, torch.float32)
+        with torch.autocast("cpu", dtype=amp, enabled=amp is not None):
+            loss = O.sm3_loss(O.sm3_v32_forward(P, Bf, dc, cc, 0, 0.1, True, None), 0)
+        loss.backward()
+        ref[key] = (float(loss), torch.cat([P[k].grad.double().flatten() for k in names]))
+    cos_torch = float(ref["f16"][1] @ ref["f32"][1] / (ref["f16"][1].norm() * ref["f32"][1].norm()))
+    print(f"           torch fp16 autocast vs fp32: |dloss| {abs(ref['f16'][0] - ref['f32'][0]):.4f}, grad cosine {cos_torch:.3f}")
+    assert cos[torch.float16] >= cos_torch - 0.05, (cos, cos_torch)
+
+    # ---- overflow: skip + back-off, then a clean step; growth after 2 clean steps ----
+    _, _, tr, m = out[torch.float16]
+    eng = tr._engine()
+    p_before, m_before = eng.store.flat_p.clone(), tr.m.clone()
+    big = [d * 3.0e4 for d in derm]  # activations beyond fp16's range -> inf in the forward, nan gradients
+    tr.step(big, clinic)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.store.flat_p, p_before) and torch.equal(tr.m, m_before)
+    assert float(tr._scaler["scale"]) == 512.0 and tr.steps_taken() == 1 and int(tr._scaler["found_inf"]) == 0
+    tr.step(derm, clinic)
+    tr.step(derm, clinic)
+    torch.cuda.synchronize()
+    assert tr.steps_taken() == 3 and float(tr._scaler["scale"]) == 1024.0  # two clean steps: growth
+    assert not torch.equal(eng.store.flat_p, p_before) and bool(torch.isfinite(eng.store.flat_p).all())
+    sd = tr.scaler_state_dict()
+    assert sd["scale"] == 1024.0 and sd["growth_interval"] == 2
+
+    # ---- compat path under torch's GradScaler (the reference's literal loop) ----
+    mc = _build(0, torch.float16, init)
+    mc.train()
+    opt = torch.optim.AdamW(mc.parameters(), lr=1e-4, weight_decay=5e-2, eps=1e-5)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+    crit = torch.nn.CrossEntropyLoss()
+    outs = mc(derm, clinic, 0)
+    loss = crit(*outs[0]) + crit(*outs[1]) + 0.5 * crit(*outs[2][0]) + 0.5 * crit(*outs[2][1])
+    opt.zero_grad(set_to_none=True)
+    scaler.scale(loss).backward()
+    scaler.step(opt)
+    scaler.update()
+    torch.cuda.synchronize()
+    assert abs(float(loss.detach()) - out[torch.float16][0]) < 2e-3
+    assert scaler.get_scale() == 1024.0

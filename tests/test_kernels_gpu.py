@@ -10,6 +10,8 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 DTYPES = [torch.float32, torch.bfloat16]
+DTYPES3 = [torch.float32, torch.bfloat16, torch.float16]  # + the reference's AMP storage type (round 2)
+IDS3 = ["f32", "bf16", "f16"]
 
 
 def _ops():
@@ -34,7 +36,7 @@ def rnd(x, dt):
 
 
 def tol(dt, scale):
-    return (2e-5 if dt == torch.float32 else 1.2e-2) * scale
+    return {torch.float32: 2e-5, torch.bfloat16: 1.2e-2, torch.float16: 2e-3}[dt] * scale
 
 
 CONV_CASES = [
@@ -58,7 +60,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dt", DTYPES3, ids=IDS3)
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd_dgrad_wgrad(case, dt):
     ops = _ops()
@@ -123,7 +125,7 @@ def test_conv_fwd_dgrad_wgrad(case, dt):
     assert (got_dw.double() - ref_dw).abs().max().item() < tol(dt, sc) * 2
 
 
-@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dt", DTYPES3, ids=IDS3)
 @pytest.mark.parametrize("case", [(2, 64, 128, 9, 11, 1, 1, 0), (3, 128, 64, 10, 8, 3, 1, 1), (2, 64, 192, 13, 11, 3, 2, 1),
                                   (12, 256, 128, 57, 50, 1, 1, 0), (8, 128, 64, 66, 62, 3, 2, 1),
                                   # 3x3 stride 1 with many row tiles, 64- and 128-column tiles, M tails
@@ -169,7 +171,7 @@ def test_dgrad_with_fused_bn_backward_phase1(case, dt):
     assert torch.allclose(a, b, rtol=1e-4, atol=1e-3 * float(b.abs().max()))
 
 
-@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dt", DTYPES3, ids=IDS3)
 def test_linear_as_conv(dt):
     ops = _ops()
     code = ops.dtype_code(dt)
@@ -185,7 +187,7 @@ def test_linear_as_conv(dt):
     assert (y.float().cpu().double() - ref).abs().max().item() < tol(dt, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dt", DTYPES3, ids=IDS3)
 @pytest.mark.parametrize("shape", [(2 * 9 * 9, 64), (300, 256), (7, 2048), (1000, 128)])
 def test_bn_train_forward_backward(shape, dt):
     ops = _ops()
@@ -322,7 +324,7 @@ def test_stem_im2col_matches_conv(dt):
     assert (got_dw.double() - ref_dw).abs().max().item() < tol(dt, ref_dw.abs().max().item()) * 2
 
 
-@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dt", DTYPES3, ids=IDS3)
 def test_pools(dt):
     ops = _ops()
     code = ops.dtype_code(dt)
@@ -423,7 +425,7 @@ def test_adamw_matches_torch():
     assert int(found) == 1 and torch.equal(before, pd)
 
 
-@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dt", DTYPES3, ids=IDS3)
 def test_bn_two_views_in_one_launch_equal_two_launches(dt):
     """`views=2` (two row ranges back to back, per-view statistics / parameters) must give bit for bit what two
     `views=1` calls give, running statistics updated view 0 first."""
@@ -490,7 +492,7 @@ def test_bn_two_views_in_one_launch_equal_two_launches(dt):
     assert not torch.equal(out["one_launch"][0][0], out["one_launch"][0][1])  # the views really differ
 
 
-@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dt", DTYPES3, ids=IDS3)
 @pytest.mark.parametrize("case", [(16, 256, 128, 8, 8, 1, 1, 0), (8, 64, 64, 16, 16, 3, 1, 1), (16, 128, 128, 8, 8, 3, 2, 1)])
 def test_fused_dgrad_two_views_equal_two_launches(case, dt):
     """sm3_conv_dgrad_bnfuse over a batch that holds two views (per-view BN mean/invstd, per-view partial rows)
@@ -542,7 +544,7 @@ def test_fused_dgrad_two_views_equal_two_launches(case, dt):
 # ------------------------------------------------------------------------------------------
 # round 2: BatchNorm passes folded into their consumers
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dt", DTYPES3, ids=IDS3)
 @pytest.mark.parametrize("views", [1, 2])
 def test_join_with_downsample_bn_in_one_pass(dt, views):
     """sm3_bn_add_bn_act == sm3_bn_act on the downsample output followed by sm3_bn_act(+residual) on bn3's (to the
@@ -601,7 +603,7 @@ def test_join_with_downsample_bn_in_one_pass(dt, views):
         torch.cuda.synchronize()
         out[mode] = (dx, dg, db)
     for i in range(2):
-        if dt == torch.bfloat16:
+        if dt != torch.float32:
             assert torch.equal(out["single"][0][i], out["dual"][0][i])
         else:  # f32: the two kernels contract k0*(dz-k1) - (x-mu)*q into FMAs differently (1 ulp)
             assert torch.allclose(out["single"][0][i], out["dual"][0][i], rtol=2e-6, atol=2e-6)
@@ -616,7 +618,7 @@ def test_join_with_downsample_bn_in_one_pass(dt, views):
     assert torch.equal(dx0, out["dual"][0][0]) and torch.equal(dzc, out["dual"][0][1])
 
 
-@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dt", DTYPES3, ids=IDS3)
 @pytest.mark.parametrize("geom", [(2, 13, 11, 1), (4, 16, 16, 2), (6, 9, 14, 2)])
 def test_stem_bn_relu_maxpool_fused_equals_separate_kernels(dt, geom):
     """sm3_bn_relu_maxpool_fwd == sm3_bn_act + sm3_maxpool3x3s2_fwd (values and argmax bit for bit);
@@ -673,13 +675,13 @@ def test_stem_bn_relu_maxpool_fused_equals_separate_kernels(dt, geom):
     assert torch.allclose(s_new, s_ref, rtol=1e-4, atol=1e-3 * float(s_ref.abs().max()))
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("geom", [(3, 30, 26, 1), (4, 64, 64, 2), (2, 45, 270, 1)])
-def test_direct_stem_forward_and_fused_weight_gradient(geom):
+def test_direct_stem_forward_and_fused_weight_gradient(geom, dt):
     """csrc/stem.hip (bf16): sm3_stem_conv_fwd against F.conv2d(7x7/2/3) in fp64 on bf16-rounded operands, its BatchNorm
     partial sums against the stored output; sm3_stem_wgrad_bn against conv2d_weight of the BatchNorm input gradient
     computed in fp64 from the same (dz, xo, sums).  Odd sizes, two views, and an image wider than one 128-pixel tile."""
     ops = _ops()
-    dt = torch.bfloat16
     code = ops.dtype_code(dt)
     N, H, W, views = geom
     D = dev()
@@ -740,7 +742,7 @@ def test_direct_stem_forward_and_fused_weight_gradient(geom):
     assert torch.allclose(dgam.cpu().double(), gs[:, 64:].sum(0), rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dt", DTYPES3, ids=IDS3)
 @pytest.mark.parametrize("geom", [(4, 10, 12), (3, 9, 7)])
 def test_fused_dgrad_with_compact_stride2_addend(dt, geom):
     """sm3_conv_dgrad_bnfuse with the addend given only at the even output pixels (compact tensor) == the same launch
