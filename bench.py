@@ -374,7 +374,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "SM3 pretrain images/sec (paired 224x224)",
+            "metric": f"SM3 pretrain images/sec (paired {S}x{S})",
             "value": round(pairs_per_s, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",

@@ -221,10 +221,10 @@ B32_GN_RTOL = 1e-2
 B32_L2_RTOL = 3.5e-2
 
 
-def test_config5_image_size_448_b32_bf16():
-    """BASELINE.json configs[4]'s image size (448x448; its fp16 + loss scaling is this build's bf16, which needs no
-    scaling) at B = 32: both views in one batch (14x14 maps x 32 images = 49 row tiles per view), bf16 against the
-    exact-f32 mode, finite gradients."""
+def test_config5_image_size_448_b32_16bit_modes():
+    """BASELINE.json configs[4] -- 448x448, fp16 + loss scaling -- at B = 32: both views in one batch (14x14 maps x 32
+    images = 49 row tiles per view); the fp16 mode (dynamic loss scaling on the device, as the config is written) and the
+    bf16 mode against the exact-f32 mode, finite gradients, the fp16 step taken (no overflow at init_scale 65536)."""
     from sm3hip.trainer import SM3Trainer
     B, S = 32, 448
     derm, clinic = _latent_batch(B, S, 11)
@@ -232,7 +232,7 @@ def test_config5_image_size_448_b32_bf16():
     from src.models.simclr import SimCLRSkinV32
     init = {k: v.clone() for k, v in SimCLRSkinV32("resnet50", None, 128, 0.1).state_dict().items()}
     out = {}
-    for dt in (torch.bfloat16, torch.float32):
+    for dt in (torch.float16, torch.bfloat16, torch.float32):
         model = _build(0, dt, init)
         tr = SM3Trainer(model, lr=1e-6)
         eng = tr._engine()
@@ -240,13 +240,19 @@ def test_config5_image_size_448_b32_bf16():
         loss = float(tr.step(derm, clinic))
         torch.cuda.synchronize()
         assert bool(torch.isfinite(eng.store.flat_g).all())
-        out[dt] = (loss, float(eng.store.flat_g.double().norm()))
+        gn = float(eng.store.flat_g.double().norm())
+        if dt == torch.float16:
+            assert tr.steps_taken() == 1 and float(tr._scaler["scale"]) == 65536.0
+            gn /= 65536.0
+        out[dt] = (loss, gn)
         del tr, eng, model
         torch.cuda.empty_cache()
     # random init at B = 32: the loss is only comparable to ~1 in bf16 (see T2 above: torch's own bf16 autocast of this
-    # network is 0.5 off at this batch size); the gradient norm is the tighter signal
+    # network is 0.5 off at this batch size); the gradient norm is the tighter signal; fp16 sits closer on both
     assert abs(out[torch.bfloat16][0] - out[torch.float32][0]) < 1.0, out
     assert abs(out[torch.bfloat16][1] - out[torch.float32][1]) < 0.1 * out[torch.float32][1], out
+    assert abs(out[torch.float16][0] - out[torch.float32][0]) < 0.5, out
+    assert abs(out[torch.float16][1] - out[torch.float32][1]) < 0.05 * out[torch.float32][1], out
 
 
 def test_checkpoint_resume_in_the_reference_wire_format(tmp_path):
