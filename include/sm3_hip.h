@@ -286,6 +286,25 @@ int sm3_loss_scale_update(float* loss_scale, int32_t* found_inf, int32_t* growth
 /* found_inf[0] |= any(!isfinite(g)) */
 int sm3_check_finite(const float* g, int64_t n, int32_t* found_inf, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Input pipeline on the GPU: the SimCLR augmentation chain of tools/backbone_train.py:448-466 (torchvision 0.13
+ * transforms on PIL images in DataLoader workers there) over a batch of decoded RGB images resident in HBM.
+ * Random parameters are drawn by the host (sm3hip/augment.py, torchvision's sampling rules) and passed per sample.
+ * ------------------------------------------------------------------------------------------ */
+/* RandomResizedCrop + RandomHorizontalFlip + ToTensor: crop box[b] = (top, left, height, width) of src [B,Hs,Ws,3] uint8,
+ * antialiased bilinear resample (PIL's triangle filter, support max(scale,1)) to [H,W], mirrored when flip[b] != 0;
+ * out [B,3,H,W] fp32 in [0,1]. */
+int sm3_aug_resized_crop(const uint8_t* src, int B, int Hs, int Ws, const int32_t* box, const uint8_t* flip, float* out,
+                         int H, int W, void* stream);
+/* One position of ColorJitter's randomly ordered chain, in place on img [B,3,H,W]: op[b] = 0 none, 1 brightness, 2 contrast,
+ * 3 saturation, 4 hue, with factor[b] (torchvision functional_tensor: _blend / rgb_to_grayscale / _rgb2hsv / _hsv2rgb).
+ * gray_mean: [B] scratch (the per-image grayscale mean the contrast blend needs, recomputed by every call). */
+int sm3_aug_color_op(float* img, int B, int H, int W, const int32_t* op, const float* factor, float* gray_mean, void* stream);
+/* RandomGrayscale (gray[b] != 0: 3-channel grayscale) -> GaussianBlur 3x3 with reflect padding (sigma[b] > 0, else none) ->
+ * Normalize: out = (x - mean3[c]) / std3[c].  mean3 / std3 are HOST arrays of 3 floats. */
+int sm3_aug_finish(const float* img, int B, int H, int W, const uint8_t* gray, const float* sigma, const float* mean3,
+                   const float* std3, float* out, void* stream);
+
 /* ---- multi-label heads of the inference model (reference inference.py:53-96; eval mode) -------------------
  * The Linear layers of that model run as sm3_conv_gather_gemm (1x1, bias-free) + sm3_bn_act(scale=1, shift=bias).
  * qkv: [B*S, 3*D] rows b*S+s, columns [q|k|v] (nn.MultiheadAttention's in_proj layout); out: [B*S, D]:

@@ -90,6 +90,9 @@ SIGNATURES = {
     "sm3_loss_scale_update": [_P, _P, _P, _P, _F, _F, _I, _P],
     "sm3_ntxent_fused_scaled": [_I, _P, _I, _I, _F, _F, _P, _P, _P, _P, _P],
     "sm3_check_finite": [_P, _L, _P, _P],
+    "sm3_aug_resized_crop": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P],
+    "sm3_aug_color_op": [_P, _I, _I, _I, _P, _P, _P, _P],
+    "sm3_aug_finish": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "sm3_token_attention": [_I, _P, _P, _I, _I, _I, _I, _P],
     "sm3_add_layernorm": [_I, _P, _P, _P, _P, _F, _P, _L, _I, _P],
     "sm3_token_heads": [_I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P],

@@ -37,6 +37,8 @@ def get_parser():
     p.add_argument("--data-name", type=str, required=True)
     p.add_argument("--data-path", type=str, required=True)
     p.add_argument("--img-sz", nargs=2, type=int, default=[224, 224])
+    p.add_argument("--mean", nargs=3, type=float, default=[0.485, 0.456, 0.406])  # src/utils/misc.py:get_parser
+    p.add_argument("--std", nargs=3, type=float, default=[0.229, 0.224, 0.225])
     p.add_argument("-a", "--arch", default="resnet50", type=str)
     p.add_argument("--arch-weights", default=None, type=str)
     p.add_argument("--arch-version", default="v32", type=str,
@@ -57,6 +59,9 @@ def get_parser():
     p.add_argument("--print-freq", type=int, default=50)
     p.add_argument("--amp", action="store_true")
     p.add_argument("--amp-dtype", default="bf16", choices=["bf16", "fp16"])
+    p.add_argument("--gpu-augment", action="store_true",
+                   help="synthetic uint8 source images + the reference's augmentation chain on the GPU instead of "
+                        "ready-made normalised tensors")
     p.add_argument("--resume-path", type=str, default=None)
     p.add_argument("--log-path", type=str, default="./logs")
     p.add_argument("--engine", default="fused", choices=["fused", "compat"])
@@ -129,12 +134,25 @@ def main(local_rank, args):
                 scaler.load_state_dict(ckpt["scaler"])
 
     gen = torch.Generator(device=dev).manual_seed(args.seed + local_rank)
+    augment = None
+    if args.gpu_augment:
+        # the reference's transform chain (backbone_train.py:448-466) on the GPU: decoded uint8 source images in HBM ->
+        # two augmented, normalised views per modality (sm3hip/augment.py, csrc/augment.hip)
+        from sm3hip.augment import SimCLRAugment
+        augment = SimCLRAugment(tuple(args.img_sz), args.mean, args.std)
+        aug_gen = torch.Generator().manual_seed(args.seed + 1000 + local_rank)
     os.makedirs(args.log_path, exist_ok=True)
     for epoch in range(start_epoch, args.epochs):
         model.train()
         t0, seen, running = time.time(), 0, None
         for it in range(args.steps_per_epoch):
-            derm, clinic = synthetic_batch(bs, args.img_sz, dev, gen, args.synthetic_kind)
+            if augment is not None:
+                src_hw = (2 * args.img_sz[0] + 14, 3 * args.img_sz[1] + 46)  # ~ derm7pt's 462 x 718 at 224
+                d_src = torch.randint(0, 256, (bs,) + src_hw + (3,), device=dev, generator=gen, dtype=torch.uint8)
+                c_src = torch.randint(0, 256, (bs,) + src_hw + (3,), device=dev, generator=gen, dtype=torch.uint8)
+                derm, clinic = augment(d_src, aug_gen), augment(c_src, aug_gen)
+            else:
+                derm, clinic = synthetic_batch(bs, args.img_sz, dev, gen, args.synthetic_kind)
             if args.engine == "fused":
                 loss = trainer.step(derm, clinic)
             else:
