@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--workload", default="pretrain", choices=["pretrain", "linear_probe", "inference"],
                     help="pretrain = BASELINE.json's metric (default); linear_probe = SURVEY.md 8f-1 (tools/backbone_eval.py "
                          "--finetune fc step at run.sh's batch 128: frozen eval-mode encoders + 8 trained heads)")
+    ap.add_argument("--global-negatives", action="store_true",
+                    help="opt-in north_star mode: NT-Xent against the all-gathered projections of every rank (not the "
+                         "reference's local negatives; changes the loss)")
     ap.add_argument("--single-lane", action="store_true",
                     help="run the derm and clinic branches on ONE stream (diagnostic: per-kernel durations without the "
                          "other lane's kernels sharing the chip -- what roofline.achieved is measured on)")
@@ -285,7 +288,8 @@ def main():
     model = SimCLRSkinV32("resnet50", None, 128, 0.1)
     model.sm3_dtype = tdt
     model.to(dev)
-    trainer = SM3Trainer(model, lr=1e-6, weight_decay=5e-2, eps=1e-5, style=0)  # run.sh:6 lr
+    trainer = SM3Trainer(model, lr=1e-6, weight_decay=5e-2, eps=1e-5, style=0,  # run.sh:6 lr
+                         global_negatives=args.global_negatives)
 
     g = torch.Generator(device=dev).manual_seed(3407 + rank)
     B, S = args.batch, args.img
@@ -381,6 +385,7 @@ def main():
             "config": {"workload": f"SM3 pretrain step, SimCLRSkinV32(resnet50 x2), synthetic {S}x{S} derm+clinical "
                                    f"pairs, batch {B}/GPU, style 0, AdamW, random-init weights",
                        "global_batch": B * world, "parallelism": f"dp{world}", "encoder_images_per_s": round(4 * pairs_per_s, 1),
+                       "negatives": "global (all-gather)" if args.global_negatives else "local (reference)",
                        "loss": round(loss_val, 5)},
             "roofline": roofline,
         }

@@ -264,6 +264,20 @@ int sm3_ntxent_fused(int dtype, const float* z, int R, int D, float temperature,
 int sm3_ntxent_fused_scaled(int dtype, const float* z, int R, int D, float temperature, float weight,
                             const float* dz_scale, float* workspace, float* loss, void* dz, void* stream);
 
+/* Global negatives under data parallelism (BASELINE.json north_star: all-gather of the projection embeddings; NOT the
+ * reference's behaviour -- its negatives are the local batch, SURVEY.md section 0 -- hence an opt-in mode of the trainer):
+ *   zn = normalise(z) (sm3_normalize_rows), all-gathered over RCCL to zg [Rg = world*Rl][D];
+ *   S = zn zg^T (sm3_conv_gather_gemm, exact-f32);  sm3_ntxent_rect: loss += weight * mean_i(-S_ip/T + log sum_{j != self}
+ *   exp(S_ij/T)) over the Rl local rows (self = column self_offset + i, positive = self_offset + (i + Rl/2) % Rl) and
+ *   S <- d(loss)/dS in place (x dz_scale[0] if given);  d(zn) = dS zg (anchor role, sm3_conv_gather_gemm) + the local
+ *   rows of all_reduce(dS^T zn) (candidate role, sm3_conv_wgrad);  sm3_normalize_rows_bwd: dz = inv_norm * (v - zn (zn.v)),
+ *   v = dzn_a + dzn_b (dzn_b nullable). */
+int sm3_normalize_rows(const float* z, int R, int D, float* zn, float* inv_norm, void* stream);
+int sm3_ntxent_rect(float* S, int Rl, int Rg, int self_offset, float temperature, float weight, const float* dz_scale,
+                    float* loss, void* stream);
+int sm3_normalize_rows_bwd(int dtype, const float* dzn_a, const float* dzn_b, const float* zn, const float* inv_norm,
+                           int R, int D, void* dz, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * AdamW over a flat fp32 buffer.  replaces torch.optim.AdamW(eps=1e-5, wd) + GradScaler unscale
  * (tools/backbone_train.py:124-127, 525-527).  g is multiplied by grad_scale first.

@@ -229,6 +229,21 @@ def sm3_loss(outputs, style):
     return cross_entropy_zero_label(derm_outs[0]) + cross_entropy_zero_label(clinic_outs[0]) + cross_loss
 
 
+def ntxent_global_rows(z_local, z_all, offset, temperature):
+    """NT-Xent of this rank's rows against the candidate rows of EVERY rank (opt-in "global negatives" mode of the build;
+    not reference behaviour): mean_i[ -S_ip/T + log sum_{j != self} exp(S_ij/T) ] with S the cosines
+    of the local rows (anchors) against z_all, self = offset + i, positive = offset + (i + B) % 2B."""
+    R = z_local.shape[0]
+    zl = z_local / z_local.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    za = z_all / z_all.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    s = zl @ za.t() / temperature
+    idx = torch.arange(R)
+    pos = s[idx, offset + (idx + R // 2) % R]
+    mask = torch.zeros_like(s, dtype=torch.bool)
+    mask[idx, offset + idx] = True
+    return (torch.logsumexp(s.masked_fill(mask, float("-inf")), dim=1) - pos).mean()
+
+
 def extract(P, B, derm, clinic):
     """SimCLRSkinV3.extract, src/models/simclr.py:393-396 (whatever mode the caller set; the
     callers use eval mode)."""

@@ -229,6 +229,64 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict_
     }
 }
 
+// ---- global negatives (data parallel): local anchors x the all-gathered candidate set -------------------------------
+// S [Rl][Rg]: cosines of this rank's Rl = 2B normalised projections (rows) against the Rg = world * Rl gathered ones
+// (columns; rank r's block is columns r*Rl .., its own rows sit at columns off + i).  Row i's positive is the other view
+// of the same pair, column off + (i + B) % Rl; its own column is excluded.  One workgroup per row:
+//   loss += weight/Rl * (-S_ip/T + log sum_{j != self} exp(S_ij/T));   S_ij <- dloss/dS_ij (in place; 0 at self)
+__global__ __launch_bounds__(256) void ntxent_rect_kernel(float* __restrict__ S, int Rl, int Rg, int off, float inv_t,
+                                                          float weight, const float* __restrict__ dz_scale,
+                                                          float* __restrict__ loss) {
+    __shared__ float red[8];
+    const int i = blockIdx.x, self = off + i, pos = off + (i + (Rl >> 1)) % Rl;
+    float* row = S + (int64_t)i * Rg;
+    float mx = -INFINITY;
+    for (int j = threadIdx.x; j < Rg; j += 256)
+        if (j != self) mx = fmaxf(mx, row[j] * inv_t);
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float se = 0.f;
+    for (int j = threadIdx.x; j < Rg; j += 256)
+        if (j != self) se += __expf(row[j] * inv_t - mx);
+    se = wave_sum(se);
+    if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = se;
+    __syncthreads();
+    se = (red[4] + red[5]) + (red[6] + red[7]);
+    const float lse = mx + __logf(se);
+    const float k = weight / (float)Rl;
+    if (threadIdx.x == 0) atomicAdd(loss, k * (lse - row[pos] * inv_t));
+    const float g = k * inv_t * (dz_scale ? dz_scale[0] : 1.f);
+    for (int j = threadIdx.x; j < Rg; j += 256) {
+        float d = 0.f;
+        if (j != self) d = g * (__expf(row[j] * inv_t - lse) - (j == pos ? 1.f : 0.f));
+        row[j] = d;
+    }
+}
+
+// gradient through zn = z / max(||z||, 1e-12): dz_i = inv_norm_i * (v_i - zn_i (zn_i . v_i)), v = d(loss)/d(zn) = a + b
+template <typename T>
+__global__ __launch_bounds__(256) void normalize_rows_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                 const float* __restrict__ zn,
+                                                                 const float* __restrict__ inv_norm, int R, int D,
+                                                                 T* __restrict__ dz) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= R) return;
+    float dot = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const int64_t o = (int64_t)row * D + d;
+        dot += (a[o] + (b ? b[o] : 0.f)) * zn[o];
+    }
+    dot = wave_sum(dot);
+    const float inv = inv_norm[row];
+    for (int d = lane; d < D; d += 64) {
+        const int64_t o = (int64_t)row * D + d;
+        store_out<T>(dz + o, inv * ((a[o] + (b ? b[o] : 0.f)) - zn[o] * dot));
+    }
+}
+
 }  // namespace
 
 extern "C" int sm3_ntxent_logits(const float* z, int R, int D, float temperature, float* zn, float* inv_norm,
@@ -300,4 +358,33 @@ extern "C" int sm3_ntxent_fused_scaled(int dtype, const float* z, int R, int D, 
                                        const float* dz_scale, float* workspace, float* loss, void* dz, void* stream) {
     if (!dz_scale) return SM3_EINVAL;
     return ntxent_fused_impl(dtype, z, R, D, temperature, weight, dz_scale, workspace, loss, dz, stream);
+}
+
+extern "C" int sm3_normalize_rows(const float* z, int R, int D, float* zn, float* inv_norm, void* stream) {
+    if (!z || !zn || !inv_norm || R <= 0 || D <= 0) return SM3_EINVAL;
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, z, R, D, zn, inv_norm);
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_ntxent_rect(float* S, int Rl, int Rg, int self_offset, float temperature, float weight,
+                               const float* dz_scale, float* loss, void* stream) {
+    if (!S || !loss || Rl < 2 || (Rl & 1) || Rg < Rl || self_offset < 0 || self_offset + Rl > Rg || temperature <= 0)
+        return SM3_EINVAL;
+    hipLaunchKernelGGL(ntxent_rect_kernel, dim3(Rl), dim3(256), 0, (hipStream_t)stream, S, Rl, Rg, self_offset,
+                       1.f / temperature, weight, dz_scale, loss);
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_normalize_rows_bwd(int dtype, const float* dzn_a, const float* dzn_b, const float* zn,
+                                      const float* inv_norm, int R, int D, void* dz, void* stream) {
+    if (!dzn_a || !zn || !inv_norm || !dz || R <= 0 || D <= 0) return SM3_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+#define SM3_NB(T) \
+    hipLaunchKernelGGL(normalize_rows_bwd_kernel<T>, dim3((R + 3) / 4), dim3(256), 0, st, dzn_a, dzn_b, zn, inv_norm, R, D, (T*)dz)
+    SM3_DISPATCH_DTYPE(dtype, SM3_NB);
+#undef SM3_NB
+    SM3_CHECK_LAUNCH();
+    return 0;
 }

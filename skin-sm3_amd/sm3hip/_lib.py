@@ -85,6 +85,9 @@ SIGNATURES = {
     "sm3_ntxent_logits_bwd": [_I, _P, _P, _P, _I, _I, _F, _P, _P],
     "sm3_ce_label0": [_P, _I, _I, _F, _P, _P, _P],
     "sm3_ntxent_fused": [_I, _P, _I, _I, _F, _F, _P, _P, _P, _P],
+    "sm3_normalize_rows": [_P, _I, _I, _P, _P, _P],
+    "sm3_ntxent_rect": [_P, _I, _I, _I, _F, _F, _P, _P, _P],
+    "sm3_normalize_rows_bwd": [_I, _P, _P, _P, _P, _I, _I, _P, _P],
     "sm3_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P, _P],
     "sm3_adamw_dynamic": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P],
     "sm3_loss_scale_update": [_P, _P, _P, _P, _F, _F, _I, _P],

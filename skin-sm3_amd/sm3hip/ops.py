@@ -724,6 +724,36 @@ def ntxent_fused(dtype, z, temperature, weight, workspace, loss, dz, dz_scale=No
                   "sm3_ntxent_fused_scaled")
 
 
+def normalize_rows(z, zn, inv_norm):
+    for t in (z, zn, inv_norm):
+        _chk(t, torch.float32)
+    R, D = z.shape
+    if zn.numel() != R * D or inv_norm.numel() != R:
+        raise ValueError("normalize_rows: size mismatch")
+    check(_lib.load().sm3_normalize_rows(_ptr(z), R, D, _ptr(zn), _ptr(inv_norm), _stream()), "sm3_normalize_rows")
+
+
+def ntxent_rect(S, self_offset, temperature, weight, loss, dz_scale=None):
+    """Local anchors x gathered candidates: loss += weight * NT-Xent rows, S <- dloss/dS in place (sm3_ntxent_rect)."""
+    _chk(S, torch.float32, "S"); _chk(loss, torch.float32, "loss"); _chk(dz_scale, torch.float32, "dz_scale")
+    Rl, Rg = S.shape
+    if Rl % 2 or self_offset < 0 or self_offset + Rl > Rg:
+        raise ValueError("ntxent_rect: bad geometry")
+    with _prof("ntxent_rect", 0.0, 8.0 * Rl * Rg):
+        check(_lib.load().sm3_ntxent_rect(_ptr(S), Rl, Rg, self_offset, temperature, weight, _ptr(dz_scale), _ptr(loss),
+                                          _stream()), "sm3_ntxent_rect")
+
+
+def normalize_rows_bwd(dtype, dzn_a, dzn_b, zn, inv_norm, dz):
+    _chk(dzn_a, torch.float32); _chk(dzn_b, torch.float32); _chk(zn, torch.float32); _chk(inv_norm, torch.float32)
+    _chk(dz, TORCH_DTYPE[dtype])
+    R, D = zn.shape
+    if dzn_a.numel() != R * D or (dzn_b is not None and dzn_b.numel() != R * D) or dz.numel() != R * D or inv_norm.numel() != R:
+        raise ValueError("normalize_rows_bwd: size mismatch")
+    check(_lib.load().sm3_normalize_rows_bwd(dtype, _ptr(dzn_a), _ptr(dzn_b), _ptr(zn), _ptr(inv_norm), R, D, _ptr(dz),
+                                             _stream()), "sm3_normalize_rows_bwd")
+
+
 # ------------------------------------------------------------------------------------------
 # optimizer
 # ------------------------------------------------------------------------------------------

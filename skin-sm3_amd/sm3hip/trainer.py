@@ -17,9 +17,12 @@ from .bridge import sm3_engine_for
 class SM3Trainer:
     def __init__(self, model, lr, weight_decay=5e-2, eps=1e-5, betas=(0.9, 0.999), style=0, data_parallel=None,
                  sync_bn=None, loss_scale=None, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5,
-                 growth_interval=2000):
+                 growth_interval=2000, global_negatives=False):
         """loss_scale: None = on exactly when the model's arithmetic is fp16 (the reference's AMP recipe: autocast +
-        GradScaler with its defaults, tools/backbone_train.py:98,125-127,480); True / False force it."""
+        GradScaler with its defaults, tools/backbone_train.py:98,125-127,480); True / False force it.
+        global_negatives: every NT-Xent term contrasts this rank's 2B projections against the projections of ALL ranks,
+        all-gathered over RCCL (BASELINE.json north_star).  NOT the reference's behaviour -- its negatives are the local
+        batch and more negatives mean a larger logsumexp -- hence opt-in, default off."""
         self.model = model
         self.kind = model._KIND
         self.lr, self.wd, self.eps, self.betas, self.style = lr, weight_decay, eps, betas, style
@@ -32,6 +35,7 @@ class SM3Trainer:
         self._handles = []
         self._pending = []
         self.loss = None
+        self.global_negatives = bool(global_negatives)
         self.loss_scale = loss_scale
         self.scaler_cfg = (float(init_scale), float(growth_factor), float(backoff_factor), int(growth_interval))
         self._scaler = None  # device state: scale, found_inf, growth tracker, optimizer steps taken
@@ -72,6 +76,38 @@ class SM3Trainer:
         a = st.offsets[names[lo]]
         b = st.offsets[names[hi]] + (st._view(st.flat_g, names[hi]).numel() + 15) // 16 * 16
         self._handles.append(dist.all_reduce(st.flat_g[a:b], async_op=True, group=self._groups["grads"]))
+
+    # ---- global negatives: all-gather of the projection embeddings (north_star; opt-in) ---------------------------
+    def _ntxent_global(self, eng, name, z, T, weight, loss, dz_out, dz_scale):
+        """One NT-Xent term with this rank's rows as anchors and the rows of every rank as candidates.  Exchanges: an
+        all-gather of the normalised projections [2B, D] and an all-reduce of the candidate-role gradient [world*2B, D],
+        both fp32 over the "main" communicator.  The similarity and its two gradient products run on the exact-f32 MFMA
+        gather-GEMM / weight-gradient kernels (a few MFLOP)."""
+        from ._lib import SM3_F32
+        dev = z.device
+        Rl, D = z.shape
+        W = self.world if self.dp else 1
+        rank = dist.get_rank() if self.dp else 0
+        Rg = W * Rl
+        zn = torch.empty_like(z)
+        inv = torch.empty(Rl, dtype=torch.float32, device=dev)
+        ops.normalize_rows(z, zn, inv)
+        if W > 1:
+            zg = torch.empty(Rg, D, dtype=torch.float32, device=dev)
+            dist.all_gather(list(zg.view(W, Rl, D).unbind(0)), zn, group=self._groups["main"])
+        else:
+            zg = zn
+        S = torch.empty(Rl, Rg, dtype=torch.float32, device=dev)
+        ops.conv_gemm(ops.fwd_desc(SM3_F32, Rl, 1, 1, D, Rg, 1, 1, 0), zn, zg, S, None, None)       # S = zn zg^T
+        ops.ntxent_rect(S, rank * Rl, T, weight, loss, dz_scale=dz_scale)                           # S <- dloss/dS
+        dzn_anchor = torch.empty(Rl, D, dtype=torch.float32, device=dev)
+        zgt = zg.t().contiguous()                                                                    # [D, Rg]
+        ops.conv_gemm(ops.fwd_desc(SM3_F32, Rl, 1, 1, Rg, D, 1, 1, 0), S, zgt, dzn_anchor, None, None)  # dS zg
+        dzg = torch.zeros(Rg, D, dtype=torch.float32, device=dev)
+        ops.conv_wgrad(ops.fwd_desc(SM3_F32, Rl, 1, 1, D, Rg, 1, 1, 0), zn, S, dzg)                  # dS^T zn
+        if W > 1:
+            dist.all_reduce(dzg, group=self._groups["main"])
+        ops.normalize_rows_bwd(eng.dtype, dzn_anchor, dzg[rank * Rl:(rank + 1) * Rl], zn, inv, dz_out)
 
     # ---- dynamic loss scaling (fp16): torch.cuda.amp.GradScaler with its state on the device ----------------
     def _scaler_state(self, dev, dtype):
@@ -127,8 +163,11 @@ class SM3Trainer:
             R, D = z.shape
             ws = eng._work("ntxent_ws", R * D + 2 * R)
             dz[name] = torch.empty(R, D, dtype=eng.tdt, device=dev)
-            ops.ntxent_fused(eng.dtype, z, T, weights[name], ws, loss, dz[name],
-                             dz_scale=sc["scale"] if sc is not None else None)
+            scale = sc["scale"] if sc is not None else None
+            if self.global_negatives:
+                self._ntxent_global(eng, name, z, T, weights[name], loss, dz[name], scale)
+            else:
+                ops.ntxent_fused(eng.dtype, z, T, weights[name], ws, loss, dz[name], dz_scale=scale)
         self._handles = []
         eng.grad_ready = (lambda f, l: self._bucket_ready(eng, f, l)) if self.dp else None
         eng.backward(saved, dz)

@@ -59,6 +59,8 @@ def get_parser():
     p.add_argument("--print-freq", type=int, default=50)
     p.add_argument("--amp", action="store_true")
     p.add_argument("--amp-dtype", default="bf16", choices=["bf16", "fp16"])
+    p.add_argument("--global-negatives", action="store_true",
+                   help="extension (not reference behaviour): NT-Xent against the all-gathered projections of all ranks")
     p.add_argument("--gpu-augment", action="store_true",
                    help="synthetic uint8 source images + the reference's augmentation chain on the GPU instead of "
                         "ready-made normalised tensors")
@@ -114,7 +116,8 @@ def main(local_rank, args):
 
     if args.engine == "fused":
         from sm3hip.trainer import SM3Trainer
-        trainer = SM3Trainer(model, lr=args.base_lr, weight_decay=args.wd, eps=1e-5, style=style)
+        trainer = SM3Trainer(model, lr=args.base_lr, weight_decay=args.wd, eps=1e-5, style=style,
+                             global_negatives=args.global_negatives)
     else:
         wrapped = nn.parallel.DistributedDataParallel(model, device_ids=[local_rank]) if world > 1 else model
         optimizer = torch.optim.AdamW(wrapped.parameters(), lr=args.base_lr, weight_decay=args.wd, eps=1e-5)

@@ -457,3 +457,41 @@ def test_fp16_mode_with_dynamic_loss_scaling():
     torch.cuda.synchronize()
     assert abs(float(loss.detach()) - out[torch.float16][0]) < 2e-3
     assert scaler.get_scale() == 1024.0
+
+
+def test_global_negatives_mode_single_rank_equals_local_and_rect_kernel():
+    """Opt-in north_star mode (all-gather of projection embeddings).  With one rank the gathered set IS the local set, so
+    the rectangular path (normalise -> exact-f32 GEMM -> sm3_ntxent_rect -> two gradient GEMMs -> normalise backward) must
+    reproduce the fused local NT-Xent step; and sm3_ntxent_rect alone against torch on a 3x wider candidate set."""
+    from sm3hip import ops
+    from sm3hip.trainer import SM3Trainer
+    torch.manual_seed(3)
+    from src.models.simclr import SimCLRSkinV32
+    init = {k: v.clone() for k, v in SimCLRSkinV32("resnet50", None, 128, 0.1).state_dict().items()}
+    derm, clinic = _latent_batch(16, 64, 5)
+    out = {}
+    for gn in (False, True):
+        m = _build(0, torch.float32, init)
+        tr = SM3Trainer(m, lr=1e-4, global_negatives=gn)
+        loss = float(tr.step(derm, clinic))
+        torch.cuda.synchronize()
+        out[gn] = (loss, tr._engine().store.flat_g.double().clone())
+    assert abs(out[True][0] - out[False][0]) < 1e-5, (out[True][0], out[False][0])
+    rel = float((out[True][1] - out[False][1]).norm() / out[False][1].norm())
+    assert rel < 1e-3, rel
+    # the kernel alone: 24 local rows (B = 12) at offset 48 of 96 candidates
+    g = torch.Generator().manual_seed(9)
+    Rl, Rg, off, T, w = 24, 96, 48, 0.1, 0.5
+    zg = torch.nn.functional.normalize(torch.randn(Rg, 128, generator=g), dim=1).double()
+    S = (zg[off:off + Rl] @ zg.t()).requires_grad_(True)
+    idx = torch.arange(Rl)
+    mask = torch.zeros(Rl, Rg, dtype=torch.bool)
+    mask[idx, off + idx] = True
+    ref = w * (torch.logsumexp((S / T).masked_fill(mask, float("-inf")), 1) - S[idx, off + (idx + Rl // 2) % Rl] / T).mean()
+    ref.backward()
+    Sd = S.detach().float().to(DEV).contiguous()
+    loss = torch.zeros(1, device=DEV)
+    ops.ntxent_rect(Sd, off, T, w, loss)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(ref)) < 1e-5
+    assert float((Sd.cpu().double() - S.grad).abs().max()) < 1e-6

@@ -31,7 +31,24 @@ class _AllReduceSum(torch.autograd.Function):
         return g
 
 
-def _rank_main(rank, world, port, q, Bl=4):
+class _AllGatherRows(torch.autograd.Function):
+    """all_gather whose backward returns to every rank the gradient ALL ranks' losses hold for its rows."""
+    @staticmethod
+    def forward(ctx, x):
+        outs = [torch.empty_like(x) for _ in range(dist.get_world_size())]
+        dist.all_gather(outs, x.contiguous())
+        ctx.n = x.shape[0]
+        return torch.cat(outs, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.clone()
+        dist.all_reduce(g)
+        r = dist.get_rank()
+        return g[r * ctx.n:(r + 1) * ctx.n]
+
+
+def _rank_main(rank, world, port, q, Bl=4, global_neg=False):
     try:
         for p in (ROOT, os.path.join(ROOT, "skin-sm3_amd"), os.path.join(ROOT, "tests")):
             if p not in sys.path:
@@ -49,8 +66,13 @@ def _rank_main(rank, world, port, q, Bl=4):
         P, Bf = O.split_state(state, torch.float64)
         derm = [torch.from_numpy(a[sl]).double() for a in derm_np]
         clinic = [torch.from_numpy(a[sl]).double() for a in clinic_np]
-        outs = O.sm3_v32_forward(P, Bf, derm, clinic, 0, T, True, stat_reduce=_AllReduceSum.apply)
-        loss_ref = O.sm3_loss(outs, 0)
+        if global_neg:  # every term: local anchors against the gathered projections of both ranks
+            zs = O.sm3_v32_projections(P, Bf, derm, clinic, 0, True, stat_reduce=_AllReduceSum.apply)
+            terms = [O.ntxent_global_rows(z, _AllGatherRows.apply(z), rank * 2 * Bl, T) for z in zs]
+            loss_ref = terms[0] + terms[1] + 0.5 * terms[2] + 0.5 * terms[3]
+        else:
+            outs = O.sm3_v32_forward(P, Bf, derm, clinic, 0, T, True, stat_reduce=_AllReduceSum.apply)
+            loss_ref = O.sm3_loss(outs, 0)
         loss_ref.backward()
         gref = torch.cat([p.grad.reshape(-1) for p in P.values()])
         dist.all_reduce(gref)
@@ -61,7 +83,7 @@ def _rank_main(rank, world, port, q, Bl=4):
         model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
         model.sm3_dtype = torch.float32
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model).to(dev)
-        tr = SM3Trainer(model, lr=lr)
+        tr = SM3Trainer(model, lr=lr, global_negatives=global_neg)
         assert tr.dp and tr.sync_bn and tr.world == world
         loss = tr.step([torch.from_numpy(a[sl]).to(dev) for a in derm_np], [torch.from_numpy(a[sl]).to(dev) for a in clinic_np])
         torch.cuda.synchronize()
@@ -113,3 +135,27 @@ def test_two_rank_dp_step_matches_sharded_oracle(Bl):
         assert o["nbt"] == 2
     assert res[0]["loss"] != res[1]["loss"]                       # different shards
     assert abs(res[0]["param_sum"] - res[1]["param_sum"]) < 1e-6 * abs(res[0]["param_sum"]) + 1e-6   # replicas stay in sync
+
+
+def test_two_rank_global_negatives_match_the_oracle():
+    """Opt-in north_star mode: the projections of both ranks are all-gathered and every NT-Xent term contrasts the local
+    2B rows with all 4B; the candidate-role gradient comes back through an all-reduce.  Against the CPU oracle with an
+    autograd-aware all_gather (fp64), sharded like DDP."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q, 16, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, ok, payload = q.get(timeout=900)
+        assert ok, f"rank {r} failed:\n{payload}"
+        res[r] = payload
+    for p in procs:
+        p.join(timeout=60)
+    for r in (0, 1):
+        o = res[r]
+        assert abs(o["loss"] - o["loss_ref"]) < 1e-3, o
+        assert o["grad_rel"] < 6e-2, o
+    assert abs(res[0]["param_sum"] - res[1]["param_sum"]) < 1e-6 * abs(res[0]["param_sum"]) + 1e-6
