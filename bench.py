@@ -77,6 +77,11 @@ def parse():
     ap.add_argument("--global-negatives", action="store_true",
                     help="opt-in north_star mode: NT-Xent against the all-gathered projections of every rank (not the "
                          "reference's local negatives; changes the loss)")
+    ap.add_argument("--metadata-dim", type=int, default=0,
+                    help="opt-in north_star extension: synthetic N(0,1) metadata of this width through the metadata-MLP branch "
+                         "(two more NT-Xent terms); 0 = the reference's model")
+    ap.add_argument("--target-momentum", type=float, default=None,
+                    help="opt-in north_star extension: momentum-updated target encoders (one more forward pass per step)")
     ap.add_argument("--single-lane", action="store_true",
                     help="run the derm and clinic branches on ONE stream (diagnostic: per-kernel durations without the "
                          "other lane's kernels sharing the chip -- what roofline.achieved is measured on)")
@@ -285,16 +290,20 @@ def main():
 
     tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     torch.manual_seed(3407)  # identical random-init weights on every rank (Kaiming fan_out, resnet.py:227-232)
-    model = SimCLRSkinV32("resnet50", None, 128, 0.1)
+    model = SimCLRSkinV32("resnet50", None, 128, 0.1, metadata_dim=args.metadata_dim or None)
     model.sm3_dtype = tdt
     model.to(dev)
     trainer = SM3Trainer(model, lr=1e-6, weight_decay=5e-2, eps=1e-5, style=0,  # run.sh:6 lr
-                         global_negatives=args.global_negatives)
+                         global_negatives=args.global_negatives, target_momentum=args.target_momentum)
 
     g = torch.Generator(device=dev).manual_seed(3407 + rank)
     B, S = args.batch, args.img
     derm = [torch.randn(B, 3, S, S, device=dev, generator=g) for _ in range(2)]
     clinic = [torch.randn(B, 3, S, S, device=dev, generator=g) for _ in range(2)]
+    if args.metadata_dim:
+        meta = torch.randn(B, args.metadata_dim, device=dev, generator=g)
+        _plain_step = trainer.step
+        trainer.step = lambda d, c: _plain_step(d, c, metadata=meta)
 
     def sync():
         if world > 1:
@@ -386,6 +395,7 @@ def main():
                                    f"pairs, batch {B}/GPU, style 0, AdamW, random-init weights",
                        "global_batch": B * world, "parallelism": f"dp{world}", "encoder_images_per_s": round(4 * pairs_per_s, 1),
                        "negatives": "global (all-gather)" if args.global_negatives else "local (reference)",
+                       "extensions": {"metadata_dim": args.metadata_dim, "target_momentum": args.target_momentum},
                        "loss": round(loss_val, 5)},
             "roofline": roofline,
         }

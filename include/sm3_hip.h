@@ -297,6 +297,9 @@ int sm3_adamw_dynamic(float* p, const float* g, float* m, float* v, int64_t n, f
                       const int32_t* steps_taken, const int32_t* found_inf, void* stream);
 int sm3_loss_scale_update(float* loss_scale, int32_t* found_inf, int32_t* growth_tracker, int32_t* steps_taken,
                           float growth_factor, float backoff_factor, int growth_interval, void* stream);
+/* Momentum ("target") encoder of BASELINE.json's north_star -- an extension: the reference has no target network
+ * (SURVEY.md section 0).  target = momentum * target + (1 - momentum) * online over the flat fp32 parameter buffer. */
+int sm3_ema_update(float* target, const float* online, int64_t n, float momentum, void* stream);
 /* found_inf[0] |= any(!isfinite(g)) */
 int sm3_check_finite(const float* g, int64_t n, int32_t* found_inf, void* stream);
 

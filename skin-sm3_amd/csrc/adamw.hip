@@ -126,6 +126,31 @@ extern "C" int sm3_loss_scale_update(float* loss_scale, int32_t* found_inf, int3
     return 0;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void ema_update_kernel(float* __restrict__ t, const float* __restrict__ p, int64_t n, float m) {
+    const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = t0; i < n4; i += stride) {
+        float4 a = reinterpret_cast<float4*>(t)[i];
+        const float4 b = reinterpret_cast<const float4*>(p)[i];
+        a.x = m * a.x + (1.f - m) * b.x; a.y = m * a.y + (1.f - m) * b.y;
+        a.z = m * a.z + (1.f - m) * b.z; a.w = m * a.w + (1.f - m) * b.w;
+        reinterpret_cast<float4*>(t)[i] = a;
+    }
+    for (int64_t i = (n4 << 2) + t0; i < n; i += stride) t[i] = m * t[i] + (1.f - m) * p[i];
+}
+}  // namespace
+
+extern "C" int sm3_ema_update(float* target, const float* online, int64_t n, float momentum, void* stream) {
+    if (!target || !online || n <= 0 || momentum < 0.f || momentum > 1.f) return SM3_EINVAL;
+    if ((((uintptr_t)target | (uintptr_t)online) & 15) != 0) return SM3_EALIGN;
+    int64_t blocks = ((n >> 2) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(ema_update_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, target, online, n, momentum);
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int sm3_check_finite(const float* g, int64_t n, int32_t* found_inf, void* stream) {
     if (!g || !found_inf || n <= 0) return SM3_EINVAL;
     int64_t blocks = (n + 255) / 256;

@@ -241,6 +241,7 @@ class SM3Engine:
         self.fuse_bn_bwd = True  # BN-backward phase 1 inside the data-gradient epilogue (sm3_conv_dgrad_bnfuse)
         self.branches = OrderedDict()
         self.cross = None
+        self.meta = None
         if kind in ("v32", "v3"):
             proj_dim = module.proj_dim
             for key in ("derm", "clinic"):
@@ -253,6 +254,8 @@ class SM3Engine:
             else:
                 self.cross = (ProjectorPlan("cross_proj.0.", 2048, proj_dim),
                               ProjectorPlan("cross_proj.1.", 2048, proj_dim))
+            if getattr(module, "meta_proj", None) is not None:  # metadata-MLP extension (src/models/simclr.py)
+                self.meta = ProjectorPlan("meta_proj.", module.meta_proj[0].in_features, proj_dim)
         elif kind == "simclr":
             self.branches["main"] = (EncoderPlan("encoder.", module.encoder.block_counts),
                                      ProjectorPlan("projector.", module.encoder_out_dim, module.proj_dim))
@@ -289,6 +292,8 @@ class SM3Engine:
         seen = set()
         plans = [p for pair in self.branches.values() for p in pair if p is not None]
         plans += list(self.cross or ())
+        if self.meta is not None:
+            plans.append(self.meta)
         for plan in plans:
             for cu in plan.conv_units():
                 if id(cu) not in seen:
@@ -312,25 +317,28 @@ class SM3Engine:
                 raise RuntimeError(f"buffer {name} is on {b.device}, expected {device}: call module.to(device) first")
 
     def refresh_weights(self):
-        """fp32 master -> `dtype` filter banks (forward and data-gradient order); once per step, one launch."""
+        """fp32 master -> `dtype` filter banks (forward and data-gradient order); once per step, one launch.  The device
+        table of (master, bank) pointers is cached per master buffer (the online weights, and the momentum target's when
+        the trainer swaps store.flat_p for a target forward)."""
         key = (self.store.flat_p.data_ptr(), len(self.store.names))
-        if getattr(self, "_wprep_key", None) != key:
-            items, self._direct_stems = [], []
+        cache = self.__dict__.setdefault("_wprep_cache", {})
+        if key not in cache:
+            items, stems = [], []
             for cu in self._all_conv_units():
                 wname = cu.name + ".weight"
                 if wname not in self.store.offsets:
                     continue  # projector dropped by the caller (mlc_train.py:344-346 sets them to None)
                 m = self.store.flat2d(self.store.flat_p, wname)
                 if cu.stem and self.direct_stem:
-                    self._direct_stems.append((m, cu.w_fwd))
+                    stems.append((m, cu.w_fwd))
                 elif cu.stem:
                     items.append((m, cu.w_fwd, None, cu.Co, 1, 147, STEM_KPAD))
                 else:
                     items.append((m, cu.w_fwd, cu.w_dgrad, cu.Co, cu.taps, cu.Ci, cu.taps * cu.Ci))
-            self._wprep_table = ops.weight_prep_table(items, self.store.flat_p.device)
-            self._wprep_key = key
-        ops.weight_prep_batch(self.dtype, self._wprep_table)
-        for m, w in self._direct_stems:
+            cache[key] = (ops.weight_prep_table(items, self.store.flat_p.device), stems)
+        table, stems = cache[key]
+        ops.weight_prep_batch(self.dtype, table)
+        for m, w in stems:
             ops.stem_weight_prep(self.dtype, m, w)
 
     def _work(self, key, numel, dtype=torch.float32):
@@ -434,6 +442,7 @@ class SM3Engine:
         gamma = self._p(bu.name + ".weight") if bu.affine else None
         beta = self._p(bu.name + ".bias") if bu.affine else None
         rm, rv = self.buffers[bu.name + ".running_mean"], self.buffers[bu.name + ".running_var"]
+        track = not self.__dict__.get("_no_stat_update", False)  # momentum-target pass: batch statistics, buffers untouched
         mean = invstd = None
         if train:
             prow = ops.stem_partial_rows(N, H, W) if direct else ops.conv_partial_rows(d)
@@ -459,9 +468,9 @@ class SM3Engine:
                 # running_mean/var/num_batches_tracked are updated view 0 first, then view 1, as in the reference's
                 # sequential encoder(x1); encoder(x2): the view-1 lane waits for view 0's update of THIS BatchNorm
                 torch.cuda.current_stream().wait_event(self._bn_ev[bu.name])
-            ops.bn_finalize(sums, count, C, gamma, beta, BN_EPS, BN_MOMENTUM, rm, rv,
-                            self.buffers[bu.name + ".num_batches_tracked"], scale, shift, mean, invstd, groups=groups,
-                            views=V)
+            ops.bn_finalize(sums, count, C, gamma, beta, BN_EPS, BN_MOMENTUM, rm if track else None,
+                            rv if track else None, self.buffers[bu.name + ".num_batches_tracked"] if track else None,
+                            scale, shift, mean, invstd, groups=groups, views=V)
             if ordered and self._view == 0:
                 ev = self._bn_ev.get(bu.name)
                 if ev is None:
@@ -847,7 +856,7 @@ class SM3Engine:
     def cross_pairs(style):
         return {0: [(0, 0), (1, 1)], 1: [(0, 1), (1, 0)], 2: [(0, 0), (0, 1), (1, 0), (1, 1)]}[style]
 
-    def forward(self, views, style=0, train=True, want_grad=True):
+    def forward(self, views, style=0, train=True, want_grad=True, metadata=None):
         """views: dict branch -> [x_view0, x_view1] (NCHW fp32).  SimCLRSkinV32.forward / SimCLR.forward.
         Returns (zs, feats, saved): zs[name] is the fp32 [2B,proj] projector output whose NT-Xent logits the
         caller emits; feats[branch] = (fp32, dtype) pooled features [2B,2048]; saved feeds backward()."""
@@ -913,6 +922,25 @@ class SM3Engine:
                     cross_saved.append((a, b, pa[0], pb[0]))
         if want_grad:
             saved["cross"] = cross_saved
+        if metadata is not None:
+            if self.meta is None:
+                raise ValueError("the model was built without metadata_dim")
+            pad = self.meta.l0.Ci
+            if metadata.dim() != 2 or metadata.shape[0] != B or metadata.shape[1] > pad:
+                raise ValueError(f"metadata must be [B, <= {pad}]")
+            x32 = torch.zeros(B, pad, dtype=torch.float32, device=dev)
+            x32[:, : metadata.shape[1]].copy_(metadata)
+            if self.tdt == torch.float32:
+                xt = x32
+            else:
+                xt = torch.empty(B, pad, dtype=self.tdt, device=dev)
+                ops.cast_from_f32(self.dtype, x32, xt)
+            zm = torch.empty(B, self.module.proj_dim, dtype=torch.float32, device=dev)
+            pm = sv()
+            self.projector_forward(self.meta, xt, B, train, zm, pm)
+            zs["meta"] = zm  # [B, proj]: not a loss term by itself -- the trainer pairs it with the cross projections
+            if want_grad:
+                saved["meta"] = pm[0]
         return zs, feats, saved
 
     def _notify(self, plan_prefix_first, plan_prefix_last):
@@ -953,6 +981,10 @@ class SM3Engine:
                 self._notify(proj.prefix, proj.prefix)
         if self.cross is not None:
             self._notify(self.cross[0].prefix, self.cross[-1].prefix)
+        if self.meta is not None:
+            if "meta" in dz and saved.get("meta") is not None:
+                self.projector_backward(saved["meta"], dz["meta"])
+            self._notify(self.meta.prefix, self.meta.prefix)
         split = bool(streams) and self.view_lanes
         for key, (plan, proj) in self.branches.items():
             if len(saved[key]["enc"]) == 1:  # both views went through as one batch

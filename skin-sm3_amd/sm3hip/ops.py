@@ -791,6 +791,13 @@ def loss_scale_update(loss_scale, found_inf, growth_tracker, steps_taken, growth
           "sm3_loss_scale_update")
 
 
+def ema_update(target, online, momentum):
+    _chk(target, torch.float32); _chk(online, torch.float32)
+    if target.numel() != online.numel():
+        raise ValueError("ema_update: size mismatch")
+    check(_lib.load().sm3_ema_update(_ptr(target), _ptr(online), target.numel(), float(momentum), _stream()), "sm3_ema_update")
+
+
 def check_finite(g, found_inf):
     _chk(g, torch.float32); _chk(found_inf, torch.int32)
     check(_lib.load().sm3_check_finite(_ptr(g), g.numel(), _ptr(found_inf), _stream()), "sm3_check_finite")

@@ -17,12 +17,17 @@ from .bridge import sm3_engine_for
 class SM3Trainer:
     def __init__(self, model, lr, weight_decay=5e-2, eps=1e-5, betas=(0.9, 0.999), style=0, data_parallel=None,
                  sync_bn=None, loss_scale=None, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5,
-                 growth_interval=2000, global_negatives=False):
+                 growth_interval=2000, global_negatives=False, target_momentum=None):
         """loss_scale: None = on exactly when the model's arithmetic is fp16 (the reference's AMP recipe: autocast +
         GradScaler with its defaults, tools/backbone_train.py:98,125-127,480); True / False force it.
         global_negatives: every NT-Xent term contrasts this rank's 2B projections against the projections of ALL ranks,
         all-gathered over RCCL (BASELINE.json north_star).  NOT the reference's behaviour -- its negatives are the local
-        batch and more negatives mean a larger logsumexp -- hence opt-in, default off."""
+        batch and more negatives mean a larger logsumexp -- hence opt-in, default off.
+        target_momentum: None (reference behaviour: both views through the online network) or m in [0, 1): north_star's
+        "momentum-updated target encoders", an extension with no counterpart in the reference.  A target copy of ALL
+        parameters follows the online ones by EMA after every step (sm3_ema_update); each loss term then pairs the
+        online projection of one view with the target projection (no gradient) of the other, symmetrised:
+        L = 1/2 [NTXent(cat(q_v0, k_v1)) + NTXent(cat(k_v0, q_v1))], q online, k target (MoCo-v3 / BYOL style)."""
         self.model = model
         self.kind = model._KIND
         self.lr, self.wd, self.eps, self.betas, self.style = lr, weight_decay, eps, betas, style
@@ -36,6 +41,8 @@ class SM3Trainer:
         self._pending = []
         self.loss = None
         self.global_negatives = bool(global_negatives)
+        self.target_momentum = target_momentum
+        self.flat_target = None
         self.loss_scale = loss_scale
         self.scaler_cfg = (float(init_scale), float(growth_factor), float(backoff_factor), int(growth_interval))
         self._scaler = None  # device state: scale, found_inf, growth tracker, optimizer steps taken
@@ -138,12 +145,14 @@ class SM3Trainer:
             self._scaler["scale"].fill_(float(sd["scale"]))
             self._scaler["tracker"].fill_(int(sd.get("_growth_tracker", 0)))
 
-    def step(self, derm_imgs, clinic_imgs):
-        """One optimizer step on this rank's batch; returns the (device, fp32, 1-element) loss tensor."""
+    def step(self, derm_imgs, clinic_imgs, metadata=None):
+        """One optimizer step on this rank's batch; returns the (device, fp32, 1-element) loss tensor.
+        metadata (extension; model built with metadata_dim): [B, d] fp32 -- two more NT-Xent terms of weight 1/2 contrast
+        meta_proj(metadata) with the cross-modal projections of the first derm / clinic views."""
         with ops.stream_scope():  # launches outside the lanes go to the stream that is current now
-            return self._step(derm_imgs, clinic_imgs)
+            return self._step(derm_imgs, clinic_imgs, metadata)
 
-    def _step(self, derm_imgs, clinic_imgs):
+    def _step(self, derm_imgs, clinic_imgs, metadata=None):
         eng = self._engine()
         dev = derm_imgs[0].device
         eng.prepare(dev)
@@ -153,8 +162,24 @@ class SM3Trainer:
             self.v = torch.zeros(st.total, dtype=torch.float32, device=dev)
         st.flat_g.zero_()
         self.model.train()
-        zs, _feats, saved = eng.forward({"derm": list(derm_imgs), "clinic": list(clinic_imgs)}, self.style, True, True)
+        views = {"derm": list(derm_imgs), "clinic": list(clinic_imgs)}
+        zt = None
+        if self.target_momentum is not None:
+            # keys: the momentum target's projections of the same batch (no gradient, BatchNorm buffers untouched)
+            if self.flat_target is None or self.flat_target.numel() != st.total:
+                self.flat_target = st.flat_p.clone()
+            online, st.flat_p = st.flat_p, self.flat_target
+            eng.__dict__["_no_stat_update"] = True
+            try:
+                zt, _f, _s = eng.forward(views, self.style, True, False)
+            finally:
+                st.flat_p = online
+                eng.__dict__["_no_stat_update"] = False
+        if metadata is not None and (self.style != 0 or self.target_momentum is not None):
+            raise NotImplementedError("the metadata branch is defined for style 0 without a momentum target")
+        zs, _feats, saved = eng.forward(views, self.style, True, True, metadata=metadata)
         loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        z_meta = zs.pop("meta", None)
         weights = self._weights(list(zs))
         dz = {}
         T = float(self.model.temperature)
@@ -164,10 +189,41 @@ class SM3Trainer:
             ws = eng._work("ntxent_ws", R * D + 2 * R)
             dz[name] = torch.empty(R, D, dtype=eng.tdt, device=dev)
             scale = sc["scale"] if sc is not None else None
-            if self.global_negatives:
+            if zt is not None:
+                # symmetrised query/key terms; only the query half of each gradient is kept
+                h = R // 2
+                k = zt[name]
+                for q_first in (True, False):
+                    zz = torch.cat([z[:h], k[h:]] if q_first else [k[:h], z[h:]], 0)
+                    dd = torch.empty(R, D, dtype=eng.tdt, device=dev)
+                    if self.global_negatives:
+                        self._ntxent_global(eng, name, zz, T, 0.5 * weights[name], loss, dd, scale)
+                    else:
+                        ops.ntxent_fused(eng.dtype, zz, T, 0.5 * weights[name], ws, loss, dd, dz_scale=scale)
+                    if q_first:
+                        dz[name][:h].copy_(dd[:h])
+                    else:
+                        dz[name][h:].copy_(dd[h:])
+            elif self.global_negatives:
                 self._ntxent_global(eng, name, z, T, weights[name], loss, dz[name], scale)
             else:
                 ops.ntxent_fused(eng.dtype, z, T, weights[name], ws, loss, dz[name], dz_scale=scale)
+        if z_meta is not None:
+            # metadata terms: [cross_proj[m](first view of modality m) ; meta_proj(metadata)], positives = same sample
+            Bm = z_meta.shape[0]
+            zc = zs["cross0"]
+            dmeta = torch.zeros(Bm, z_meta.shape[1], dtype=eng.tdt, device=dev)
+            for half in (0, 1):
+                zz = torch.cat([zc[half * Bm:(half + 1) * Bm], z_meta], 0)
+                dd = torch.empty(2 * Bm, zz.shape[1], dtype=eng.tdt, device=dev)
+                ws = eng._work("ntxent_ws", zz.numel() + 4 * Bm)
+                if self.global_negatives:
+                    self._ntxent_global(eng, "meta", zz, T, 0.5, loss, dd, sc["scale"] if sc is not None else None)
+                else:
+                    ops.ntxent_fused(eng.dtype, zz, T, 0.5, ws, loss, dd, dz_scale=sc["scale"] if sc is not None else None)
+                dz["cross0"][half * Bm:(half + 1) * Bm] += dd[:Bm]
+                dmeta += dd[Bm:]
+            dz["meta"] = dmeta
         self._handles = []
         eng.grad_ready = (lambda f, l: self._bucket_ready(eng, f, l)) if self.dp else None
         eng.backward(saved, dz)
@@ -187,6 +243,8 @@ class SM3Trainer:
             ops.loss_scale_update(sc["scale"], sc["found_inf"], sc["tracker"], sc["steps"], self.scaler_cfg[1],
                                   self.scaler_cfg[2], self.scaler_cfg[3])
             self.step_count += 1  # calls made; the number of optimizer steps TAKEN lives on the device (steps_taken())
+        if self.target_momentum is not None:
+            ops.ema_update(self.flat_target, st.flat_p, self.target_momentum)
         self.loss = loss
         return loss
 

@@ -93,12 +93,26 @@ class SimCLRSkinV3(nn.Module):
                 bridge.branch_features(self, self._KIND, "clinic", clinic_imgs)]
 
 
+METADATA_PAD = 64  # the metadata vector is zero-padded to one 128-byte K chunk of the MFMA GEMM
+
+
 class SimCLRSkinV32(SimCLRSkinV3):
-    """Independent cross projectors per modality (reference simclr.py:399-482; run.sh:4 uses this one)."""
+    """Independent cross projectors per modality (reference simclr.py:399-482; run.sh:4 uses this one).
+
+    metadata_dim (extension, default None = the reference's model, identical state_dict): BASELINE.json's north_star
+    names a "metadata-MLP branch" over a 20-dim metadata vector; the reference has none (its metadata columns only become
+    label dicts).  With metadata_dim = d <= 64 the model owns `meta_proj`, a BN-MLP projector
+    (make_projector over the zero-padded vector), whose output is contrasted with the cross-modal projections of the
+    first views by two more NT-Xent terms in sm3hip.trainer.SM3Trainer.step(..., metadata=)."""
     _KIND = "v32"
 
-    def __init__(self, arch, weights=None, proj_dim=128, temperature=0.5, use_checkpoint=False) -> None:
+    def __init__(self, arch, weights=None, proj_dim=128, temperature=0.5, use_checkpoint=False, metadata_dim=None) -> None:
         super().__init__(arch, weights, proj_dim, temperature)
         self.cross_proj = nn.ModuleList([make_projector(self.derm_feat_dim, proj_dim),
                                          make_projector(self.clinic_feat_dim, proj_dim)])
         self.use_checkpoint = use_checkpoint
+        self.metadata_dim = metadata_dim
+        if metadata_dim is not None:
+            if not 0 < metadata_dim <= METADATA_PAD:
+                raise ValueError(f"metadata_dim must be in 1..{METADATA_PAD}")
+            self.meta_proj = make_projector(METADATA_PAD, proj_dim)

@@ -495,3 +495,95 @@ def test_global_negatives_mode_single_rank_equals_local_and_rect_kernel():
     torch.cuda.synchronize()
     assert abs(float(loss) - float(ref)) < 1e-5
     assert float((Sd.cpu().double() - S.grad).abs().max()) < 1e-6
+
+
+def test_momentum_target_extension():
+    """north_star's momentum-updated target encoders (an extension: the reference has none).  With momentum 0 and the
+    target initialised to the online weights the keys equal the queries, so the symmetrised query/key loss equals the
+    plain loss; the EMA buffer follows the online weights by sm3_ema_update; gradients flow to the query rows only."""
+    from sm3hip.trainer import SM3Trainer
+    from sm3hip import ops
+    torch.manual_seed(4)
+    from src.models.simclr import SimCLRSkinV32
+    init = {k: v.clone() for k, v in SimCLRSkinV32("resnet50", None, 128, 0.1).state_dict().items()}
+    derm, clinic = _latent_batch(16, 64, 6)
+    m0 = _build(0, torch.float32, init)
+    base = SM3Trainer(m0, lr=1e-4)
+    l0 = float(base.step(derm, clinic))
+    m1 = _build(0, torch.float32, init)
+    tr = SM3Trainer(m1, lr=1e-4, target_momentum=0.9)
+    l1 = float(tr.step(derm, clinic))
+    torch.cuda.synchronize()
+    assert abs(l0 - l1) < 1e-4, (l0, l1)  # first step: target == online
+    eng = tr._engine()
+    # the target moved 10 % of the way to the updated online weights
+    p_on = eng.store.flat_p
+    p_init = base._engine().store.flat_p  # same init, same first update -> equals p_on; rebuild the initial point instead
+    init_flat = SM3Trainer(_build(0, torch.float32, init), lr=0.0)._engine()
+    init_flat.prepare(torch.device(DEV))
+    want = 0.9 * init_flat.store.flat_p + 0.1 * p_on
+    assert torch.allclose(tr.flat_target, want, rtol=1e-6, atol=1e-8)
+    # BatchNorm buffers were updated once per view by the ONLINE pass only
+    assert int(m1.state_dict()["derm_backbone.encoder.bn1.num_batches_tracked"]) == 2
+    # second step: keys now differ from queries; loss finite, gradient only half as strong through the query rows
+    l2 = float(tr.step(derm, clinic))
+    torch.cuda.synchronize()
+    assert np.isfinite(l2) and bool(torch.isfinite(eng.store.flat_g).all())
+    # ema kernel alone
+    a, b = torch.randn(1003, device=DEV), torch.randn(1003, device=DEV)
+    a = torch.cat([a, torch.zeros(1, device=DEV)])[:1003].contiguous()
+    t = torch.zeros(1008, device=DEV)[:1003]
+    t.copy_(a)
+    ops.ema_update(t, b, 0.75)
+    torch.cuda.synchronize()
+    assert torch.allclose(t, 0.75 * a + 0.25 * b, rtol=1e-6, atol=1e-7)
+
+
+def test_metadata_mlp_extension_against_the_oracle():
+    """north_star's metadata-MLP branch (an extension: no counterpart in the reference).  SimCLRSkinV32(metadata_dim=20)
+    owns meta_proj; SM3Trainer.step(..., metadata=) adds 1/2 NT-Xent(cat(cross_proj[0](derm_f0), meta_proj(meta))) +
+    1/2 NT-Xent(cat(cross_proj[1](clinic_f0), meta_proj(meta))).  Loss and gradients against the same definition written
+    with the CPU oracle's pieces in fp64; the default model's state_dict is untouched by the option."""
+    from oracle import procedural, sm3_oracle as O
+    from sm3hip.trainer import SM3Trainer
+    from src.models.simclr import SimCLRSkinV32, METADATA_PAD
+    B, size, seed, T = 16, 64, 41, 0.1
+    model = SimCLRSkinV32("resnet50", None, 128, T, metadata_dim=20)
+    keys = open(os.path.join(os.path.dirname(__file__), "golden", "state_dict_keys.txt")).read().split()
+    sd0 = model.state_dict()
+    assert [k for k in sd0 if not k.startswith("meta_proj.")] == keys and len(sd0) == len(keys) + 16
+    spec = [(k, tuple(v.shape)) for k, v in sd0.items()]
+    state = procedural.make_state_dict(spec, seed=seed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    model.sm3_dtype = torch.float32
+    model.to(DEV)
+    derm_np, clinic_np = procedural.make_pair_batch(B, size, seed)
+    g = torch.Generator().manual_seed(seed)
+    meta = torch.randn(B, 20, generator=g)
+    tr = SM3Trainer(model, lr=1e-4)
+    loss = float(tr.step([torch.from_numpy(a).to(DEV) for a in derm_np], [torch.from_numpy(a).to(DEV) for a in clinic_np],
+                         metadata=meta.to(DEV)))
+    torch.cuda.synchronize()
+    eng = tr._engine()
+    grads = dict(zip(eng.store.names, eng.store.grad_views()))
+    # oracle (fp64)
+    P, Bf = O.split_state(state, torch.float64)
+    derm = [torch.from_numpy(a).double() for a in derm_np]
+    clinic = [torch.from_numpy(a).double() for a in clinic_np]
+    zs = O.sm3_v32_projections(P, Bf, derm, clinic, 0, True)
+    x = torch.zeros(B, METADATA_PAD, dtype=torch.float64)
+    x[:, :20] = meta.double()
+    zm = O.projector(x, P, Bf, "meta_proj.", True)
+    nt = lambda z: O.ntxent_loss_closed_form(z, T)
+    ref = (nt(zs[0]) + nt(zs[1]) + 0.5 * nt(zs[2]) + 0.5 * nt(zs[3])
+           + 0.5 * nt(torch.cat([zs[2][:B], zm], 0)) + 0.5 * nt(torch.cat([zs[2][B:], zm], 0)))
+    ref.backward()
+    assert abs(loss - float(ref)) < 1e-3, (loss, float(ref))
+    for k in ("meta_proj.0.weight", "meta_proj.3.weight", "meta_proj.6.weight", "meta_proj.1.weight", "meta_proj.4.bias",
+              "cross_proj.0.6.weight", "cross_proj.1.0.weight", "derm_backbone.encoder.layer4.2.conv3.weight"):
+        a, b = grads[k].double().cpu(), P[k].grad
+        if k == "meta_proj.0.weight":  # the padded input columns receive no gradient
+            assert float(a[:, 20:].abs().max()) == 0.0
+        rel = float((a - b).norm() / b.norm())
+        assert rel < 6e-2, (k, rel)
+    assert int(model.state_dict()["meta_proj.1.num_batches_tracked"]) == 1
