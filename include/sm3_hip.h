@@ -336,6 +336,46 @@ int sm3_add_layernorm(int dtype, const void* a, const void* b, const float* gamm
 int sm3_token_heads(int dtype, const void* x, const float* W, const float* bias, const int* token_of, int l2_norm,
                     float* out, int B, int S, int D, int T, void* stream);
 
+/* ---- TRAINING of those heads (reference tools/mlc_train.py:58-90,241-283; tools/mlc_eval.py), all fp32 ------------------
+ * The Linear layers (label projectors, attention in/out projections, feed-forward) are sm3_conv_gather_gemm / sm3_conv_wgrad
+ * in SM3_F32; these entry points are everything else of one train-mode nn.TransformerEncoderLayer (post-norm, ReLU) over the
+ * S <= 8 label tokens, the prototype heads, the pseudo-label cross-entropy and the spherical k-means behind the pseudo-labels.
+ * Dropout keeps no mask: element e of stream `seed` is kept iff hash(seed, e) >= p; backward recomputes it. */
+/* Token rows: label_major = 0: row(b, s) = b*S + s (the inference path's layout); 1: row(b, s) = s*B + b, the reference's
+ * [S, B, D] stacking (mlc_train.py:79).
+ * out[rows, D] = softmax(QK^T/sqrt(hd)) (dropout p on the probabilities) V, qkv [rows, 3D]; and its backward */
+int sm3_mlc_attention_fwd(const float* qkv, float* out, int B, int S, int D, int nhead, float p, uint32_t seed,
+                          int label_major, void* stream);
+int sm3_mlc_attention_bwd(const float* qkv, const float* dout, float* dqkv, int B, int S, int D, int nhead, float p,
+                          uint32_t seed, int label_major, void* stream);
+/* out = LayerNorm(a + dropout_p(b)) * gamma + beta; stats[rows][2] = (mean, rstd).  Backward: da = d(sum), db = mask/(1-p) *
+ * d(sum), dgamma / dbeta accumulated (atomics). */
+int sm3_mlc_add_ln_fwd(const float* a, const float* b, const float* gamma, const float* beta, float eps, float p,
+                       uint32_t seed, float* out, float* stats, int64_t rows, int D, void* stream);
+int sm3_mlc_add_ln_bwd(const float* dout, const float* a, const float* b, const float* stats, const float* gamma, float p,
+                       uint32_t seed, float* da, float* db, float* dgamma, float* dbeta, int64_t rows, int D, void* stream);
+/* h = relu(y + bias) [rows, N], hd = dropout_p(h); backward dh = dhd * mask/(1-p) * (h > 0), dbias += column sums */
+int sm3_mlc_bias_relu_drop_fwd(const float* y, const float* bias, float p, uint32_t seed, float* h, float* hd, int64_t rows,
+                               int N, void* stream);
+int sm3_mlc_relu_drop_bwd(const float* dhd, const float* h, float p, uint32_t seed, float* dh, float* dbias, int64_t rows,
+                          int N, void* stream);
+/* db[c] += sum_r dy[r][c]: the bias gradient of a Linear */
+int sm3_mlc_colsum(const float* dy, float* db, int64_t rows, int N, void* stream);
+/* loss[0] += mean_h mean_b CE(logits[b, off[h]:off[h+1]] / T, targets[h][b]); dlogits written (mlc_train.py:252-261) */
+int sm3_mlc_ce(const float* logits, const int64_t* targets, const int* head_offsets, int H, int B, int Tn, float temperature,
+               float* loss, float* dlogits, void* stream);
+/* prototype heads in fp32 with either row layout (bias nullable: mlc_train.py's prototypes have none), and the backward:
+ * dx written, dW [Tn,D] and dbias [Tn] (nullable) accumulated */
+int sm3_mlc_heads_fwd(const float* x, const float* W, const float* bias, const int* token_of, int l2_norm, float* out, int B,
+                      int S, int D, int Tn, int label_major, void* stream);
+int sm3_mlc_heads_bwd(const float* dlogits, const float* x, const float* W, const int* token_of, int l2_norm, float* dx,
+                      float* dW, float* dbias, int B, int S, int D, int Tn, int label_major, void* stream);
+/* spherical k-means (mlc_train.py:146-177): E step assign[n] = argmax_k <emb[n], centroids[k]> (+ sums / counts of the M
+ * step when given); M step centroid = normalise(sum / count) for non-empty clusters, every centroid L2-normalised */
+int sm3_mlc_kmeans_assign(const float* emb, const float* centroids, int64_t* assign, float* sums, int* counts, int N, int D,
+                          int K, void* stream);
+int sm3_mlc_kmeans_update(float* centroids, const float* sums, const int* counts, int K, int D, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

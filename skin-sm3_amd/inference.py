@@ -4,8 +4,9 @@
 The two ResNet-50 encoders (all of the FLOPs) run on the sm3hip engine in eval mode, and so do the heads
 (`sm3hip/heads.py`): the 8 x Linear(4096,512) label projectors as one MFMA GEMM, the 8-token
 TransformerEncoderLayer (attention, residual LayerNorms, feed-forward) and the 8 prototype heads on
-`csrc/heads.hip`.  The nn.Modules below only own the parameters in the reference's layout; in training mode
-(`tools/mlc_train.py`, not built natively yet) they run as stock PyTorch.  Checkpoints in the reference's wire format
+`csrc/heads.hip`.  The nn.Modules below only own the parameters in the reference's layout; in training mode (the
+fine-tuning of tools/mlc_eval.py) the heads run on the train-mode kernels of `sm3hip/mlc.py` / `csrc/heads_train.hip`
+(exact-f32 MFMA GEMMs, attention / LayerNorm / dropout / prototype kernels with autograd).  Checkpoints in the reference's wire format
 (`best_linear.pth` / `best_finetune.pth`, keys with "encoder." stripped, inference.py:123-127) load unchanged.
 """
 import torch
@@ -71,11 +72,10 @@ class Model(nn.Module):
             import sm3hip
             dt = self.extractor.derm_backbone.__dict__.get("sm3_dtype") or sm3hip.default_dtype()
             return self._hip_heads(feats.float(), dt)
-        tokens = torch.stack(self.projectors(feats), dim=0)                           # [8, B, 512]
-        sa = self.mlc_sa(tokens)
-        if self.l2_norm:
-            sa = nn.functional.normalize(sa, dim=-1, p=2)
-        return [self.prototypes[i](sa[i % len(sa)]) for i in range(len(self.prototypes))]
+        if not feats.is_cuda:
+            raise RuntimeError("the SM3 HIP path has no CPU fallback: move the model and its inputs to the GPU")
+        from sm3hip import mlc                                                        # train mode: heads with autograd
+        return mlc.heads_forward(self, feats.float())[1]
 
 
 def build_model(arch="resnet50", mlc_proj_dim=512, num_labels=8, l2_norm=False, num_heads=1, sa_dim_ff=128,

@@ -43,7 +43,7 @@ class WPrepItem(C.Structure):
                 ("Co", C.c_int32), ("taps", C.c_int32), ("Ci", C.c_int32), ("ld_fwd", C.c_int32)]
 
 
-_P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+_P, _I, _L, _F, _D, _U = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_uint32
 _DESC = C.POINTER(ConvDesc)
 
 # name -> argtypes ; every function returns int.  Must list every symbol include/sm3_hip.h declares
@@ -100,6 +100,18 @@ SIGNATURES = {
     "sm3_token_attention": [_I, _P, _P, _I, _I, _I, _I, _P],
     "sm3_add_layernorm": [_I, _P, _P, _P, _P, _F, _P, _L, _I, _P],
     "sm3_token_heads": [_I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
+    "sm3_mlc_attention_fwd": [_P, _P, _I, _I, _I, _I, _F, _U, _I, _P],
+    "sm3_mlc_attention_bwd": [_P, _P, _P, _I, _I, _I, _I, _F, _U, _I, _P],
+    "sm3_mlc_heads_fwd": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
+    "sm3_mlc_add_ln_fwd": [_P, _P, _P, _P, _F, _F, _U, _P, _P, _L, _I, _P],
+    "sm3_mlc_add_ln_bwd": [_P, _P, _P, _P, _P, _F, _U, _P, _P, _P, _P, _L, _I, _P],
+    "sm3_mlc_bias_relu_drop_fwd": [_P, _P, _F, _U, _P, _P, _L, _I, _P],
+    "sm3_mlc_relu_drop_bwd": [_P, _P, _F, _U, _P, _P, _L, _I, _P],
+    "sm3_mlc_colsum": [_P, _P, _L, _I, _P],
+    "sm3_mlc_ce": [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P],
+    "sm3_mlc_heads_bwd": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "sm3_mlc_kmeans_assign": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "sm3_mlc_kmeans_update": [_P, _P, _P, _I, _I, _P],
 }
 
 _lib = None

@@ -6,8 +6,8 @@
 Every Linear is sm3_conv_gather_gemm (the MFMA gather-GEMM as a 1x1 convolution, M = rows) followed by sm3_bn_act
 with scale = 1 and shift = bias; the 8 label projectors are ONE GEMM with their weights stacked to [4096, 4096].
 Tokens are kept sample-major ([B, 8, 512] = rows b*8+t), so every later GEMM sees one [8B, 512] matrix and the
-attention kernel one contiguous block per sample.  No autograd: training these heads (tools/mlc_train.py) is not
-built yet and raises."""
+attention kernel one contiguous block per sample.  No autograd here: training these heads (tools/mlc_train.py,
+tools/mlc_eval.py fine-tuning) goes through sm3hip/mlc.py."""
 import torch
 
 from . import ops

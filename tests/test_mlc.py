@@ -1,0 +1,153 @@
+"""f-2 second half: training of the multi-label heads (tools/mlc_train.py) on the HIP kernels (sm3hip/mlc.py,
+csrc/heads_train.hip) against stock PyTorch autograd of the reference's own module structure, and the spherical k-means
+against a restatement of mlc_train.py:146-177."""
+import math
+
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+NUM_CLASSES = [5, 3, 2, 3, 3, 3, 3, 2]
+
+
+class _RefHeads(nn.Module):
+    """The head part of the reference's Model (mlc_train.py:58-90), stock PyTorch."""
+
+    def __init__(self, in_dim, D, nhead, ff, dropout, l2_norm, bias):
+        super().__init__()
+        from src.models.projector import MultiLabelProjector4
+        self.projectors = MultiLabelProjector4(in_dim, D, 8)
+        self.mlc_sa = nn.TransformerEncoderLayer(d_model=D, nhead=nhead, dim_feedforward=ff, dropout=dropout)
+        self.prototypes = nn.ModuleList([nn.Linear(D, n, bias=bias) for n in NUM_CLASSES])
+        self.l2_norm = l2_norm
+
+    def forward(self, feats):
+        sa = self.mlc_sa(torch.stack(self.projectors(feats), dim=0))
+        if self.l2_norm:
+            sa = nn.functional.normalize(sa, dim=-1, p=2)
+        return sa, [self.prototypes[i](sa[i % len(sa)]) for i in range(len(self.prototypes))]
+
+
+@pytest.mark.parametrize("cfg", [dict(D=512, nhead=1, ff=128, l2=False, bias=False),   # run.sh:39-47 (mlc_train)
+                                 dict(D=256, nhead=4, ff=256, l2=True, bias=True)],    # mlc_eval-style heads, parser defaults
+                         ids=["v4_512_h1", "256_h4_l2_bias"])
+def test_heads_training_matches_torch_autograd(cfg):
+    from sm3hip import mlc
+    torch.manual_seed(3)
+    B, in_dim, T = 24, 256, 0.7
+    ref = _RefHeads(in_dim, cfg["D"], cfg["nhead"], cfg["ff"], 0.0, cfg["l2"], cfg["bias"]).double()
+    ref.train()
+    feats = torch.randn(B, in_dim, dtype=torch.float64, requires_grad=True)
+    targets = torch.stack([torch.randint(0, n, (B,)) for n in NUM_CLASSES])
+    crit = nn.CrossEntropyLoss()
+    sa_ref, preds_ref = ref(feats)
+    loss_ref = sum(crit(p / T, t) for p, t in zip(preds_ref, targets)) / 8     # mlc_train.py:252-261
+    loss_ref.backward()
+
+    hip = _RefHeads(in_dim, cfg["D"], cfg["nhead"], cfg["ff"], 0.0, cfg["l2"], cfg["bias"])
+    hip.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    hip.to(DEV).train()
+    f = feats.detach().float().to(DEV).requires_grad_(True)
+    sa, preds = mlc.heads_forward(hip, f, seed=1)
+    loss = sum(crit(p / T, t.to(DEV)) for p, t in zip(preds, targets)) / 8
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(loss_ref)) < 1e-5
+    assert float((sa.cpu().double() - sa_ref.detach()).abs().max()) < 1e-4
+    for (k, p_ref), (_, p) in zip(ref.named_parameters(), hip.named_parameters()):
+        err = float((p.grad.cpu().double() - p_ref.grad).norm() / (p_ref.grad.norm() + 1e-12))
+        assert err < 2e-4, (k, err)
+    err = float((f.grad.cpu().double() - feats.grad).norm() / feats.grad.norm())
+    assert err < 2e-4, err
+    # the fused pseudo-label cross-entropy kernel gives the same loss and d(logits)
+    lk, dl = mlc.pseudo_label_loss([p.detach() for p in preds], targets.to(DEV), T)
+    assert abs(float(lk) - float(loss_ref)) < 1e-5
+    cat = torch.cat(preds, 1).detach().requires_grad_(True)
+    l2 = sum(crit(p / T, t.to(DEV)) for p, t in zip(cat.split(NUM_CLASSES, 1), targets)) / 8
+    l2.backward()
+    assert float((dl - cat.grad).abs().max()) < 1e-7
+
+
+def test_dropout_is_deterministic_unbiased_and_used_in_backward():
+    from sm3hip import mlc
+    torch.manual_seed(0)
+    B, in_dim = 64, 128
+    hip = _RefHeads(in_dim, 256, 2, 128, 0.1, False, False).to(DEV).train()
+    f = torch.randn(B, in_dim, device=DEV)
+    sa1, p1 = mlc.heads_forward(hip, f, seed=5)
+    sa2, p2 = mlc.heads_forward(hip, f, seed=5)
+    sa3, p3 = mlc.heads_forward(hip, f, seed=6)
+    assert torch.equal(sa1, sa2) and not torch.equal(sa1, sa3)        # the mask is a pure function of (seed, element)
+    hip.eval()
+    sa_e, _ = mlc.heads_forward(hip, f, seed=5)                        # eval: dropout off (mlc_train.py:init_memory)
+    hip.train()
+    mean = torch.stack([mlc.heads_forward(hip, f, seed=100 + i)[0] for i in range(48)]).mean(0)
+    assert float((mean - sa_e).abs().mean()) < 0.2 * float(sa_e.abs().mean())  # unbiased in expectation (LayerNorm is non-linear: loose)
+    # finite-difference check of one weight through the dropped network (same seed = same mask)
+    w = hip.mlc_sa.linear2.weight
+    tgt = torch.stack([torch.randint(0, n, (B,), device=DEV) for n in NUM_CLASSES])
+    crit = nn.CrossEntropyLoss()
+
+    def loss_of():
+        _, pr = mlc.heads_forward(hip, f, seed=9)
+        return sum(crit(p, t) for p, t in zip(pr, tgt)) / 8
+    loss = loss_of()
+    hip.zero_grad()
+    loss.backward()
+    g = w.grad[3, 5].item()
+    with torch.no_grad():
+        w[3, 5] += 1e-2
+        lp = float(loss_of())
+        w[3, 5] -= 2e-2
+        lm = float(loss_of())
+        w[3, 5] += 1e-2
+    assert abs((lp - lm) / 2e-2 - g) < 5e-3 + 0.05 * abs(g), ((lp - lm) / 2e-2, g)
+
+
+def test_spherical_kmeans_matches_the_reference_algorithm():
+    from sm3hip import mlc
+    g = torch.Generator().manual_seed(4)
+    N, D, K = 413, 512, 5                                    # derm7pt's training split is 413 cases
+    centers = nn.functional.normalize(torch.randn(K, D, generator=g), dim=1)
+    emb = nn.functional.normalize(centers[torch.randint(0, K, (N,), generator=g)] + 0.3 * torch.randn(N, D, generator=g), dim=1)
+    gk = torch.Generator().manual_seed(7)
+    cent, assign = mlc.spherical_kmeans(emb.to(DEV), K, iters=10, generator=gk)
+    # restatement of mlc_train.py:146-177 with the same initial centroids
+    idx = torch.randperm(N, generator=torch.Generator().manual_seed(7))[:K]
+    c = emb[idx].double()
+    e = emb.double()
+    for it in range(11):
+        a = (e @ c.t()).max(1).indices
+        if it == 10:
+            break
+        for k in range(K):
+            if (a == k).any():
+                c[k] = e[a == k].sum(0) / (a == k).sum()
+        c = nn.functional.normalize(c, dim=1)
+    assert torch.equal(assign.cpu(), a)
+    assert float((cent.cpu().double() - c).abs().max()) < 1e-5
+    assert len(set(assign.cpu().tolist())) == K
+
+
+def test_mlc_train_tool_runs_and_learns(tmp_path):
+    """tools/mlc_train.py end to end on synthetic data: frozen HIP extractor (eval mode), memory bank, per-epoch spherical
+    k-means, pseudo-label training of the heads; the loss must fall, the checkpoint must hold the reference's keys."""
+    import importlib.util
+    import os
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "skin-sm3_amd", "tools")
+    spec = importlib.util.spec_from_file_location("sm3_mlc_train", os.path.join(tools, "mlc_train.py"))
+    mt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mt)
+    args = mt.get_parser().parse_args(["--data-name", "synthetic", "--epochs", "3", "-b", "32", "--num-samples", "96",
+                                       "--img-sz", "64", "64", "--log-path", str(tmp_path), "--temperature", "1",
+                                       "--mlc-proj-dim", "128", "--sa-dim-ff", "64", "--sa-dropout", "0.1", "-lr", "1e-3"])
+    args.world_size = 1
+    hist = mt.main(0, args)
+    assert len(hist) == 3 and all(math.isfinite(v) for v in hist) and hist[-1] < hist[0]
+    ck = torch.load(os.path.join(str(tmp_path), "checkpoint.pth.tar"), map_location="cpu", weights_only=False)
+    assert {"epoch", "state_dict", "optimizer"} <= set(ck)
+    keys = list(ck["state_dict"].keys())
+    assert any(k.startswith("extractor.derm_backbone.encoder.") for k in keys)
+    assert "mlc_sa.self_attn.in_proj_weight" in keys and "prototypes.7.weight" in keys and "projectors.projectors.0.0.weight" in keys
