@@ -151,3 +151,30 @@ def test_mlc_train_tool_runs_and_learns(tmp_path):
     keys = list(ck["state_dict"].keys())
     assert any(k.startswith("extractor.derm_backbone.encoder.") for k in keys)
     assert "mlc_sa.self_attn.in_proj_weight" in keys and "prototypes.7.weight" in keys and "projectors.projectors.0.0.weight" in keys
+
+
+@pytest.mark.parametrize("mode", ["projector", "all"])
+def test_mlc_eval_tool_finetunes_from_an_mlc_train_checkpoint(tmp_path, mode):
+    """tools/mlc_eval.py: loads the mlc_train checkpoint format (bias-free prototypes dropped, strict=False), fine-tunes
+    with real labels in the `projector` and `all` freeze modes (the latter sends gradients into the HIP encoders'
+    layer1-4 through the autograd bridge), saves best_finetune.pth with the reference's keys."""
+    import importlib.util
+    import os
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "skin-sm3_amd", "tools")
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location("sm3_" + name, os.path.join(tools, name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    mt, me = load("mlc_train"), load("mlc_eval")
+    targs = mt.get_parser().parse_args(["--epochs", "1", "-b", "16", "--num-samples", "32", "--img-sz", "64", "64",
+                                        "--log-path", str(tmp_path / "train"), "--mlc-proj-dim", "128", "--sa-dim-ff", "64"])
+    targs.world_size = 1
+    mt.main(0, targs)
+    hist = me.main(["--epochs", "2", "-b", "16", "--steps-per-epoch", "3", "--val-steps", "2", "--img-sz", "64", "64",
+                    "--log-path", str(tmp_path / "eval"), "--mlc-proj-dim", "128", "--sa-dim-ff", "64", "--finetune", mode,
+                    "--pretrain-path", str(tmp_path / "train" / "ckp_0.pth")])
+    assert len(hist) == 2 and all(math.isfinite(t["loss"]) and 0.0 <= v["AUC_AVG"] <= 1.0 for t, v in hist)
+    ck = torch.load(str(tmp_path / "eval" / "best_finetune.pth"), map_location="cpu", weights_only=False)
+    assert "prototypes.0.bias" in ck["state_dict"] and "extractor.clinic_backbone.encoder.layer4.2.bn3.weight" in ck["state_dict"]
