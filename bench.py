@@ -71,7 +71,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=3)
-    ap.add_argument("--workload", default="pretrain", choices=["pretrain", "linear_probe", "inference"],
+    ap.add_argument("--workload", default="pretrain", choices=["pretrain", "linear_probe", "inference", "mlc_train"],
                     help="pretrain = BASELINE.json's metric (default); linear_probe = SURVEY.md 8f-1 (tools/backbone_eval.py "
                          "--finetune fc step at run.sh's batch 128: frozen eval-mode encoders + 8 trained heads)")
     ap.add_argument("--global-negatives", action="store_true",
@@ -233,6 +233,84 @@ def inference_bench(args):
                      "kernel": "conv_igemm_kernel<bf16_t,128,128,2,2,*> with the conv+evalBN+ReLU epilogue"}}), flush=True)
 
 
+def mlc_train_bench(args):
+    """Secondary line (BASELINE.json configs[3]): the multi-label DeepCluster step of tools/mlc_train.py:236-262 --
+    frozen HIP encoders in eval mode (fused conv+BN epilogue), label projectors / 8-token transformer layer / prototype
+    heads training on csrc/heads_train.hip, pseudo-label cross-entropy / 8, AdamW; plus the per-epoch spherical k-means
+    (cluster_memory) timed apart over a 2048-sample memory bank."""
+    import importlib.util
+    from sm3hip import ops, profiler
+    spec = importlib.util.spec_from_file_location("sm3_mlc_train", os.path.join(ROOT, "skin-sm3_amd", "tools", "mlc_train.py"))
+    mt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mt)
+    from src.models.projector import MultiLabelProjector4
+    from src.models.simclr import SimCLRSkinV32
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3407)
+    B, S = (128 if args.batch == 256 else args.batch), args.img
+    margs = mt.get_parser().parse_args(["-b", str(B), "--mlc-proj-dim", "512", "--sa-dim-ff", "128"])  # run.sh:39-47
+    ex = SimCLRSkinV32(arch="resnet50", proj_dim=128)
+    ex.derm_backbone.projector = ex.clinic_backbone.projector = ex.cross_proj = None
+    ex.sm3_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
+    for p in ex.parameters():
+        p.requires_grad = False
+    m = mt.Model(ex, MultiLabelProjector4(4096, 512, 8), 512, False, 1, 128, 0.1).to(dev)
+    m.eval()
+    m.projectors.train(); m.mlc_sa.train(); m.prototypes.train()
+    opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3, weight_decay=5e-2)
+    crit = torch.nn.CrossEntropyLoss(ignore_index=-100)
+    g = torch.Generator(device=dev).manual_seed(3407)
+    derm = torch.randn(B, 3, S, S, device=dev, generator=g)
+    clinic = torch.randn(B, 3, S, S, device=dev, generator=g)
+    assign = [torch.randint(0, pr.weight.size(0), (B,), device=dev, generator=g) for pr in m.prototypes]
+
+    def step():
+        _, preds = m(derm, clinic)
+        loss = sum(crit(p / margs.temperature, a) for p, a in zip(preds, assign)) / 8
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    prof = profiler.Profiler(only={"conv_gemm_128x128"})
+    torch.cuda.synchronize()
+    ops.set_profiler(prof)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.set_profiler(None)
+    # the per-epoch clustering: 8 spherical k-means (10 iterations each) over a 2048 x 512 memory bank
+    nmem = 2048
+    idx = torch.arange(nmem, device=dev)
+    emb = torch.nn.functional.normalize(torch.randn(nmem, 512, device=dev, generator=g), dim=1)
+    margs.world_size, margs.rank = 1, 0
+    gk = torch.Generator().manual_seed(3407)
+    torch.cuda.synchronize()
+    tk = time.perf_counter()
+    for pr in m.prototypes:
+        mt.cluster_memory(margs, pr, pr.weight.size(0), idx, emb, generator=gk)
+    torch.cuda.synchronize()
+    kmeans_ms = 1e3 * (time.perf_counter() - tk)
+    dom = prof.summary().get("conv_gemm_128x128", {"flops": 0.0, "ms": 0.0, "launches": 0})
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+    peak = MFMA_PEAK_TFLOPS[args.dtype]
+    print(json.dumps({
+        "metric": "SM3 multi-label DeepCluster pairs/sec (224x224, frozen ResNet-50 x2 + transformer heads training)",
+        "value": round(B * args.steps / elapsed, 2), "unit": "pairs/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"tools/mlc_train.py step (run.sh:39-47: v4 projectors 512, sa_dim_ff 128, 1 head), "
+                               f"batch {B}, {S}x{S}", "global_batch": B, "parallelism": "dp1", "loss": round(float(loss.detach()), 5),
+                   "kmeans_ms_per_epoch": round(kmeans_ms, 2), "kmeans_bank": nmem},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                     "frac": round(achieved / peak, 4), "traffic": None,
+                     "kernel": "conv_igemm_kernel<bf16_t,128,128,2,2,*> with the conv+evalBN+ReLU epilogue"}}), flush=True)
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N fresh worker processes of this same file, one rank
     per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1), and return
@@ -262,6 +340,8 @@ def main():
         return linear_probe_bench(args)
     if args.workload == "inference":
         return inference_bench(args)
+    if args.workload == "mlc_train":
+        return mlc_train_bench(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))

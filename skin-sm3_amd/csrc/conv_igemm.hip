@@ -156,9 +156,31 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
     };
     set_tap(0);
     dma_stage(0, 0, wtap_off);
-    dma_drain();
-    __syncthreads();  // publishes the stage
-    if constexpr (STAGES == 2) {
+    if constexpr (STAGES > 2) {
+        // Deep pipeline for launches of at most one workgroup per CU (projector Linears: M = 256..512 rows, 32 K-steps):
+        // with one stage in flight a K-step costs a full DMA round trip (~1.1 us); here STAGES - 1 stages are in
+        // flight, each step waits (counted vmcnt) only for its own stage and passes one barrier.
+        constexpr int PER = AI + BI;  // DMA instructions per stage per wave
+        for (int s = 1; s < STAGES - 1 && s < nsteps; ++s) {
+            advance();
+            dma_stage(s, (uint32_t)kc * 128u, wtap_off + (uint32_t)kc * 128u);
+        }
+        for (int s = 0; s < nsteps; ++s) {
+            const int younger = min(STAGES - 2, nsteps - 1 - s);  // stages issued after stage s
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+            else dma_drain();
+            __syncthreads();  // stage s is complete for everyone; everyone has finished computing stage s - 1
+            if (s + STAGES - 1 < nsteps) {
+                advance();
+                dma_stage((s + STAGES - 1) % STAGES, (uint32_t)kc * 128u, wtap_off + (uint32_t)kc * 128u);
+            }
+            compute(s % STAGES);
+        }
+        __syncthreads();  // the epilogue re-uses the stage memory
+    } else if constexpr (STAGES == 2) {
+        dma_drain();
+        __syncthreads();  // publishes the stage
         for (int s = 0; s < nsteps; ++s) {
             if (s + 1 < nsteps) {
                 advance();
@@ -169,6 +191,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
             __syncthreads();  // everyone's has; and everyone is done reading stage s
         }
     } else {
+        dma_drain();
+        __syncthreads();  // publishes the stage
         for (int s = 0; s < nsteps; ++s) {
             compute(0);
             __syncthreads();  // everyone is done reading the stage
@@ -470,12 +494,19 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
     const char* v = getenv("SM3_CONV_SINGLE_STAGE_MAX");
     const int single_max = v ? atoi(v) : 8;
     const bool single = p.ntaps * p.kchunks <= single_max;
+    // at most one workgroup per CU and a K-loop worth pipelining: 3 stages in flight (128 KB of LDS, see the kernel)
+    const long nblocks = (long)((p.M + BM - 1) / BM) * ((p.Co + BN - 1) / BN);
+    const char* dv = getenv("SM3_CONV_DEEP");
+    const bool deep = !(dv && atoi(dv) == 0) && nblocks <= 256 && p.ntaps * p.kchunks >= 6;
     if constexpr (sizeof(T) == 2) {
         const char* lv = getenv("SM3_CONV_LEAN");
         const bool dense = p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.HWout == p.HoWo;
-        if (!(lv && atoi(lv) == 0) && dense && !p.addend && !p.fz_x)  // train-mode forward, and conv+evalBN(+ReLU)
+        if (!(lv && atoi(lv) == 0) && dense && !p.addend && !p.fz_x) {  // train-mode forward, and conv+evalBN(+ReLU)
+            if (deep) return launch_conv_st<T, BM, BN, WM, WN, 4, true>(p, st);
             return single ? launch_conv_st<T, BM, BN, WM, WN, 1, true>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, true>(p, st);
+        }
     }
+    if (deep) return launch_conv_st<T, BM, BN, WM, WN, 4, false>(p, st);
     if (single) return launch_conv_st<T, BM, BN, WM, WN, 1, false>(p, st);
     return launch_conv_st<T, BM, BN, WM, WN, 2, false>(p, st);
 }
@@ -559,7 +590,9 @@ static int conv_gather_gemm_impl(const sm3_conv_desc* d, const void* x, const vo
     p.ep_shift = ep_shift;
     p.ep_relu = ep_relu;
     hipStream_t st = (hipStream_t)stream;
-    const bool narrow = d->Co <= 64;
+    // 64-column tiles for Co <= 64, and for the small-M Linears whose 128-column grid would leave most CUs idle
+    const long tiles128 = (long)((p.M + kBM - 1) / kBM) * ((d->Co + 127) / 128);
+    const bool narrow = d->Co <= 64 || (tiles128 <= 96 && p.ntaps * p.kchunks >= 6);
     if (d->dtype == SM3_BF16)
         return narrow ? launch_conv<bf16_t, kBM, 64, 2, 2>(p, st) : launch_conv<bf16_t, kBM, 128, 2, 2>(p, st);
     if (d->dtype == SM3_F16)

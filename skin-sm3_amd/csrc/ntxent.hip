@@ -325,6 +325,207 @@ extern "C" int sm3_ce_label0(const float* logits, int R, int Cc, float weight, f
     return 0;
 }
 
+namespace {
+
+// ---- tiled fused path (D % 4 == 0, D <= 128): 8 anchor rows per workgroup against 64-candidate tiles -------------------
+// The row-per-workgroup kernels above spend a wave reduction per similarity (~95 us per launch at R = 512, D = 128, on
+// the step's forward/backward turnaround where neither execution lane has other work).  Here a workgroup keeps 8 anchor
+// rows and walks the candidates in tiles of 64 rows staged in LDS (row pitch D + 4 floats: the 16-byte reads of 16
+// different rows fall on different banks); thread (il = t / 32, jj = t % 32) owns S[i0 + il][j0 + jj], S[..][j0 + jj + 32]
+// (float4 dot products).  LSE: online max / sum per thread, folded over the 32 lanes of a row.  BWD: the tile's
+// coefficients go to LDS and v[il][:] += coef[il][tile] * Zn[tile][:] re-uses the staged tile (thread (il, ch) owns the
+// 16-byte chunks ch, ch + 32 of the row).  The next tile's global loads are issued before the current tile's arithmetic.
+constexpr int NTX_TI = 8, NTX_TJ = 64, NTX_CP = NTX_TJ + 4;
+
+template <bool BWD, typename T, int NV>
+__global__ __launch_bounds__(256) void ntxent_tile_kernel(const float* __restrict__ zn, const float* __restrict__ inv_norm,
+                                                          float* __restrict__ lse, int R, int D, float inv_t, float weight,
+                                                          const float* __restrict__ dz_scale, float* __restrict__ loss,
+                                                          T* __restrict__ dz) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int D4 = D >> 2, DP = D + 4;
+    float* zi = sm;                      // [TI][DP]
+    float* zj = zi + NTX_TI * DP;        // [TJ][DP]
+    float* coef = zj + NTX_TJ * DP;      // [TI][CP]   (BWD)
+    float* lse_t = coef + NTX_TI * NTX_CP;  // [TJ]    (BWD)
+    float* red = lse_t + NTX_TJ;         // [TI]
+    const int t = threadIdx.x, il = t >> 5, jj = t & 31;
+    const int i0 = blockIdx.x * NTX_TI, i = i0 + il, half = R >> 1;
+    const bool row_ok = i < R;
+    const int p = row_ok ? (i + half) % R : -1;
+    const int ntiles = (R + NTX_TJ - 1) / NTX_TJ;
+
+    float4 pre[NV];
+    float pre_lse = 0.f;
+    auto fetch = [&](int j0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int idx = t + k * 256, r = idx / D4, c = idx - r * D4;
+            pre[k] = (r < NTX_TJ && j0 + r < R) ? *reinterpret_cast<const float4*>(zn + (int64_t)(j0 + r) * D + c * 4)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (BWD && t < NTX_TJ) pre_lse = (j0 + t < R) ? lse[j0 + t] : 0.f;
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int idx = t + k * 256, r = idx / D4, c = idx - r * D4;
+            if (r < NTX_TJ) *reinterpret_cast<float4*>(zj + r * DP + c * 4) = pre[k];
+        }
+        if (BWD && t < NTX_TJ) lse_t[t] = pre_lse;
+    };
+    fetch(0);
+    for (int idx = t; idx < NTX_TI * D4; idx += 256) {
+        const int r = idx / D4, c = idx - r * D4;
+        *reinterpret_cast<float4*>(zi + r * DP + c * 4) =
+            (i0 + r < R) ? *reinterpret_cast<const float4*>(zn + (int64_t)(i0 + r) * D + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    commit();
+    __syncthreads();
+
+    // dz_scale: the dynamic loss scale of the fp16 mode (device scalar; GradScaler.scale(loss), backbone_train.py:125)
+    const float k = BWD ? weight * (dz_scale ? dz_scale[0] : 1.f) * inv_t / (float)R : 0.f;
+    const float lse_i = (BWD && row_ok) ? lse[i] : 0.f;
+    float run_m = -INFINITY, run_s = 0.f, s_pos = 0.f;
+    constexpr int NCH = (NV * 256 / NTX_TJ + 31) / 32;  // 16-byte chunks of a row per thread (BWD accumulators)
+    float4 acc[NCH];
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) acc[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int j0 = tile * NTX_TJ;
+        if (tile + 1 < ntiles) fetch(j0 + NTX_TJ);
+        float a0 = 0.f, a1 = 0.f;
+        const float* zr = zi + il * DP;
+        const float* zb0 = zj + jj * DP;
+        const float* zb1 = zj + (jj + 32) * DP;
+        for (int d = 0; d < D; d += 4) {
+            const float4 x = *reinterpret_cast<const float4*>(zr + d);
+            const float4 b0 = *reinterpret_cast<const float4*>(zb0 + d);
+            const float4 b1 = *reinterpret_cast<const float4*>(zb1 + d);
+            a0 += x.x * b0.x + x.y * b0.y + x.z * b0.z + x.w * b0.w;
+            a1 += x.x * b1.x + x.y * b1.y + x.z * b1.z + x.w * b1.w;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = j0 + jj + 32 * h;
+            const float s = (h ? a1 : a0) * inv_t;
+            const bool valid = row_ok && j < R && j != i;
+            if constexpr (BWD) {
+                float c = 0.f;
+                if (valid) {
+                    const float pos = (j == p) ? 1.f : 0.f;  // p_j == i  <=>  j == p_i  (R even)
+                    c = k * ((__expf(s - lse_i) - pos) + (__expf(s - lse_t[jj + 32 * h]) - pos));
+                }
+                coef[il * NTX_CP + jj + 32 * h] = c;
+            } else if (valid) {
+                if (j == p) s_pos = s;
+                if (s > run_m) {
+                    run_s = run_s * __expf(run_m - s) + 1.f;
+                    run_m = s;
+                } else {
+                    run_s += __expf(s - run_m);
+                }
+            }
+        }
+        if constexpr (BWD) {
+            __syncthreads();  // the tile's coefficients are in LDS
+            const float* cr = coef + il * NTX_CP;
+            for (int j = 0; j < NTX_TJ; j += 4) {
+                const float4 c4 = *reinterpret_cast<const float4*>(cr + j);
+#pragma unroll
+                for (int m = 0; m < NCH; ++m) {
+                    const int ch = jj + 32 * m;
+                    if (ch < D4) {
+                        const float* col = zj + j * DP + ch * 4;
+                        const float4 r0 = *reinterpret_cast<const float4*>(col);
+                        const float4 r1 = *reinterpret_cast<const float4*>(col + DP);
+                        const float4 r2 = *reinterpret_cast<const float4*>(col + 2 * DP);
+                        const float4 r3 = *reinterpret_cast<const float4*>(col + 3 * DP);
+                        acc[m].x += c4.x * r0.x + c4.y * r1.x + c4.z * r2.x + c4.w * r3.x;
+                        acc[m].y += c4.x * r0.y + c4.y * r1.y + c4.z * r2.y + c4.w * r3.y;
+                        acc[m].z += c4.x * r0.z + c4.y * r1.z + c4.z * r2.z + c4.w * r3.z;
+                        acc[m].w += c4.x * r0.w + c4.y * r1.w + c4.z * r2.w + c4.w * r3.w;
+                    }
+                }
+            }
+        }
+        __syncthreads();  // everyone is done with this tile (and its coefficients)
+        if (tile + 1 < ntiles) {
+            commit();
+            __syncthreads();
+        }
+    }
+
+    if constexpr (BWD) {
+        float dot = 0.f;
+#pragma unroll
+        for (int m = 0; m < NCH; ++m) {
+            const int ch = jj + 32 * m;
+            if (ch < D4) {
+                const float4 x = *reinterpret_cast<const float4*>(zi + il * DP + ch * 4);
+                dot += acc[m].x * x.x + acc[m].y * x.y + acc[m].z * x.z + acc[m].w * x.w;
+            }
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);  // over the 32 lanes of the row
+        if (row_ok) {
+            const float inv = inv_norm[i];
+#pragma unroll
+            for (int m = 0; m < NCH; ++m) {
+                const int ch = jj + 32 * m;
+                if (ch < D4) {
+                    const float4 x = *reinterpret_cast<const float4*>(zi + il * DP + ch * 4);
+                    T* o = dz + (int64_t)i * D + ch * 4;
+                    store_out<T>(o + 0, inv * (acc[m].x - x.x * dot));
+                    store_out<T>(o + 1, inv * (acc[m].y - x.y * dot));
+                    store_out<T>(o + 2, inv * (acc[m].z - x.z * dot));
+                    store_out<T>(o + 3, inv * (acc[m].w - x.w * dot));
+                }
+            }
+        }
+    } else {
+        float mx = run_m;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float s = (run_m == -INFINITY) ? 0.f : run_s * __expf(run_m - mx);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o, 64);
+            s_pos += __shfl_xor(s_pos, o, 64);
+        }
+        if (jj == 0) {
+            float term = 0.f;
+            if (row_ok) {
+                const float l = mx + __logf(s);
+                lse[i] = l;
+                term = weight * (l - s_pos) / (float)R;
+            }
+            red[il] = term;
+        }
+        __syncthreads();
+        if (t == 0 && loss) {
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < NTX_TI; ++r) a += red[r];
+            atomicAdd(loss, a);
+        }
+    }
+}
+
+template <typename T, int NV>
+static void launch_ntxent_tiles(const float* zn, const float* inv_norm, float* lse, int R, int D, float inv_t, float weight,
+                                const float* dz_scale, float* loss, T* dz, hipStream_t st) {
+    const size_t lds = (size_t)((NTX_TI + NTX_TJ) * (D + 4) + NTX_TI * NTX_CP + NTX_TJ + NTX_TI) * 4;
+    const dim3 grid((R + NTX_TI - 1) / NTX_TI);
+    hipLaunchKernelGGL((ntxent_tile_kernel<false, T, NV>), grid, dim3(256), lds, st, zn, inv_norm, lse, R, D, inv_t, weight,
+                       nullptr, loss, (T*)nullptr);
+    hipLaunchKernelGGL((ntxent_tile_kernel<true, T, NV>), grid, dim3(256), lds, st, zn, inv_norm, lse, R, D, inv_t, weight,
+                       dz_scale, (float*)nullptr, dz);
+}
+
+}  // namespace
+
 static int ntxent_fused_impl(int dtype, const float* z, int R, int D, float temperature, float weight,
                              const float* dz_scale, float* workspace, float* loss, void* dz, void* stream) {
     if (!z || !workspace || !dz || R < 2 || (R & 1) || D <= 0 || temperature <= 0) return SM3_EINVAL;
@@ -338,6 +539,13 @@ static int ntxent_fused_impl(int dtype, const float* z, int R, int D, float temp
     const float inv_t = 1.f / temperature;
     hipLaunchKernelGGL(normalize_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, st, z, R, D, zn, inv_norm);
     SM3_CHECK_LAUNCH();
+    if (D % 4 == 0 && D <= 128 && ((uintptr_t)workspace & 15) == 0) {  // tiled kernels (8 anchors x 64-candidate tiles, 40 KB of LDS)
+#define SM3_NTX_TILE(T) launch_ntxent_tiles<T, 8>(zn, inv_norm, lse, R, D, inv_t, weight, dz_scale, loss, (T*)dz, st)
+        SM3_DISPATCH_DTYPE(dtype, SM3_NTX_TILE);
+#undef SM3_NTX_TILE
+        SM3_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(fused_lse_kernel, dim3(R), dim3(256), lds, st, zn, R, D, inv_t, weight, lse, loss);
     SM3_CHECK_LAUNCH();
 #define SM3_NTX(T)                                                                                                       \

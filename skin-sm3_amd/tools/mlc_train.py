@@ -213,10 +213,10 @@ def main(local_rank, args):
             for i in range(len(local_memory_embeddings)):
                 local_memory_embeddings[i][start_idx:start_idx + nb] = proj_feats[i].detach()
             start_idx += nb
-            total += float(loss) * nb
+            total += float(loss.detach()) * nb
             seen += nb
             if local_rank == 0 and it % args.print_freq == 0:
-                print(f"Train epoch: [{epoch}][{it}/{n_batches}] Loss {float(loss):.4f}", flush=True)
+                print(f"Train epoch: [{epoch}][{it}/{n_batches}] Loss {float(loss.detach()):.4f}", flush=True)
         history.append(total / max(seen, 1))
         if local_rank == 0:
             print(f"epoch {epoch}: loss {history[-1]:.4f}, {time.time() - t0:.1f} s", flush=True)

@@ -188,6 +188,49 @@ def test_linear_as_conv(dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES3, ids=IDS3)
+@pytest.mark.parametrize("case", ["linear_256x2048x2048", "linear_512x2048x128", "conv3x3_2x14x14x256", "ragged_200x1024x192"])
+def test_deep_pipeline_equals_two_stage(case, dt, monkeypatch):
+    """Launches of at most one workgroup per CU with >= 6 K-steps run the 4-stage K-loop (3 DMA stages in flight) on
+    64-column tiles; same MFMA order, so output AND BatchNorm partial sums are bit-identical to the 2-stage kernel
+    (SM3_CONV_DEEP=0), and both match fp64 on the rounded operands."""
+    ops = _ops()
+    code = ops.dtype_code(dt)
+    g = torch.Generator().manual_seed(11)
+    if case.startswith("conv3x3"):
+        N, H, Ci, Co, k, pad = 2, 14, 256, 256, 3, 1
+    else:
+        M, Ci, Co = {"linear_256x2048x2048": (256, 2048, 2048), "linear_512x2048x128": (512, 2048, 128),
+                     "ragged_200x1024x192": (200, 1024, 192)}[case]
+        N, H, k, pad = M, 1, 1, 0
+    x = rnd(torch.randn(N, Ci, H, H, generator=g), dt)
+    w = rnd(torch.randn(Co, Ci, k, k, generator=g) / math.sqrt(Ci * k * k), dt)
+    ref = F.conv2d(x.double(), w.double(), padding=pad)
+    d = ops.fwd_desc(code, N, H, H, Ci, Co, k, 1, pad)
+    xd = nhwc(x, dt)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dt).to(dev())
+    prow = ops.conv_partial_rows(d)
+    outs = {}
+    for deep in ("1", "0"):
+        monkeypatch.setenv("SM3_CONV_DEEP", deep)
+        y = torch.empty(N * H * H, Co, dtype=dt, device=dev())
+        part = torch.full((prow, 2, Co), float("nan"), device=dev())
+        ops.conv_gemm(d, xd, wd, y, None, part)
+        y2 = torch.empty_like(y)
+        addend = torch.zeros_like(y)
+        ops.conv_gemm(d, xd, wd, y2, addend, None)     # general epilogue
+        torch.cuda.synchronize()
+        outs[deep] = (y.clone(), part.clone(), y2.clone())
+    for a, b in zip(outs["1"], outs["0"]):
+        assert torch.equal(a, b)
+    y = outs["1"][0].float().cpu().double().reshape(N, H, H, Co).permute(0, 3, 1, 2)
+    assert (y - ref).abs().max().item() < tol(dt, ref.abs().max().item())
+    if dt != torch.float32:  # lean vs general epilogue: same rounding of the same accumulators
+        assert torch.equal(outs["1"][0], outs["1"][2])
+    stored = outs["1"][0].float().cpu().double()
+    assert torch.allclose(outs["1"][1].cpu().double().sum(0)[0], stored.sum(0), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("dt", DTYPES3, ids=IDS3)
 @pytest.mark.parametrize("shape", [(2 * 9 * 9, 64), (300, 256), (7, 2048), (1000, 128)])
 def test_bn_train_forward_backward(shape, dt):
     ops = _ops()
@@ -397,6 +440,33 @@ def test_ntxent_logits_and_backward(R):
     torch.cuda.synchronize()
     assert abs(float(loss2) - float(ref_loss)) < 2e-5
     assert (dz2.cpu().double() - z64.grad).abs().max().item() < 1e-4 * sc + 1e-7
+
+
+@pytest.mark.parametrize("R,Dm", [(8, 128), (64, 128), (130, 128), (512, 128), (1024, 128), (62, 64), (66, 36), (64, 160), (10, 130)],
+                         ids=lambda v: str(v))
+def test_ntxent_fused_tiled_and_row_kernels(R, Dm):
+    """sm3_ntxent_fused: the tiled kernels (D % 4 == 0, D <= 128: 8 anchors x 64-candidate tiles, ragged last tiles and
+    anchor groups) and the row-per-workgroup fallback (D = 160, 130) against the fp64 oracle; with a loss scale too."""
+    ops = _ops()
+    from oracle import sm3_oracle as O
+    D = dev()
+    g = torch.Generator().manual_seed(R * 7 + Dm)
+    z = torch.randn(R, Dm, generator=g)
+    z64 = z.double().requires_grad_(True)
+    ref_logits, _ = O.ntxent_logits(z64, 0.1)
+    ref_loss = 0.5 * O.cross_entropy_zero_label(ref_logits)
+    ref_loss.backward()
+    sc = z64.grad.abs().max().item()
+    ws = torch.empty(R * Dm + 2 * R, device=D)
+    for scale in (None, 1024.0):
+        loss = torch.zeros(1, device=D)
+        dz = torch.full((R, Dm), float("nan"), device=D)
+        ops.ntxent_fused(0, z.to(D), 0.1, 0.5, ws, loss, dz,
+                         dz_scale=None if scale is None else torch.tensor([scale], device=D))
+        torch.cuda.synchronize()
+        assert abs(float(loss) - float(ref_loss)) < 2e-5 * max(1.0, abs(float(ref_loss)))
+        k = scale or 1.0
+        assert (dz.cpu().double() / k - z64.grad).abs().max().item() < 1e-4 * sc + 1e-7
 
 
 def test_adamw_matches_torch():
