@@ -27,7 +27,8 @@ struct WgradParams {
     int sy, sx, ntaps;
     int dyt[SM3_MAX_TAPS], dxt[SM3_MAX_TAPS], wtap[SM3_MAX_TAPS];
     int w_row_stride;
-    int HoWo, Wo;
+    int HoWo, Wo, Ho;
+    int adv_n, adv_oy, adv_ox;  // one K-step (KP pixels) = adv_n images + adv_oy rows + adv_ox pixels
     FastDiv div_HoWo, div_Wo;
     int tilesCo, tilesCi;   // tiles per pixel slice: gx = tilesCo * ntaps * tilesCi
     int k_per_split;        // pixels per slice (multiple of KP)
@@ -53,7 +54,7 @@ __device__ __forceinline__ uint32_t swz_bytes(int row) {
 
 // DENSE: 1x1 / stride 1 / no offset forward conv (X row of output pixel m is simply row m): every DMA offset is
 // a per-lane constant plus a scalar that advances by one K-step -- no VALU at all in the loop.
-template <typename T, int BMW, int BNW, int KP, bool DENSE>  // KP = pixels per K-step
+template <typename T, int BMW, int BNW, int KP, bool DENSE, int NST>  // KP = pixels per K-step, NST = LDS stages
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int SZ = sizeof(T);
     constexpr bool kBf16 = (SZ == 2);
@@ -123,6 +124,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         b_off[i] = col_ok ? (uint32_t)(kbeg + r) * (uint32_t)(p.Ci * SZ) + b_cho[i] : kOOB;  // DENSE form
     }
     const uint32_t smem_lds = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+    int g_m[BI], g_n[BI], g_oy[BI], g_ox[BI];  // non-DENSE: output pixel of this lane's X rows in the next step to stage
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        g_m[i] = kbeg + b_row[i];  // negative for lanes whose channel chunk lies beyond Ci
+        const int m = g_m[i] < 0 ? 0 : g_m[i];
+        g_n[i] = fdiv(m, p.div_HoWo);
+        const int rem = m - g_n[i] * p.HoWo;
+        g_oy[i] = fdiv(rem, p.div_Wo);
+        g_ox[i] = rem - g_oy[i] * p.Wo;
+    }
 
     auto dma_stage = [&](int stage, int step) {
         const uint32_t sA = smem_lds + (uint32_t)(stage * STAGE) + (uint32_t)wave * 1024u;
@@ -135,20 +146,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
             for (int i = 0; i < BI; ++i) dma16(rx, sB + i * 4096, b_off[i], soff_b);
         } else {
+            // X rows follow the tap-shifted pixel of each output pixel.  (n, oy, ox) of the BI rows this lane stages
+            // are carried from step to step (one K-step = adv_n images + adv_oy rows + adv_ox pixels, single carries)
+            // instead of two divisions per row per step: that index arithmetic, not the MFMAs, was setting the
+            // K-step time of the 3x3 layers.  dma_stage is called with step = 0, 1, 2, ... in order.
 #pragma unroll
             for (int i = 0; i < BI; ++i) {
-                const int m = kbeg + step * KP + b_row[i];
                 uint32_t off = kOOB;
-                if (m >= 0 && m < kend) {
-                    const int n = fdiv(m, p.div_HoWo);
-                    const int rem = m - n * p.HoWo;
-                    const int oy = fdiv(rem, p.div_Wo);
-                    const int ox = rem - oy * p.Wo;
-                    const int iy = oy * p.sy + ddy, ix = ox * p.sx + ddx;
+                if (g_m[i] >= 0 && g_m[i] < kend) {
+                    const int iy = g_oy[i] * p.sy + ddy, ix = g_ox[i] * p.sx + ddx;
                     if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
-                        off = (uint32_t)((n * p.Hi + iy) * p.Wi + ix) * (uint32_t)(p.Ci * SZ) + b_cho[i];
+                        off = (uint32_t)((g_n[i] * p.Hi + iy) * p.Wi + ix) * (uint32_t)(p.Ci * SZ) + b_cho[i];
                 }
                 dma16(rx, sB + i * 4096, off, 0u);
+                g_m[i] += KP;
+                g_n[i] += p.adv_n;
+                g_oy[i] += p.adv_oy;
+                g_ox[i] += p.adv_ox;
+                if (g_ox[i] >= p.Wo) {
+                    g_ox[i] -= p.Wo;
+                    ++g_oy[i];
+                }
+                if (g_oy[i] >= p.Ho) {
+                    g_oy[i] -= p.Ho;
+                    ++g_n[i];
+                }
             }
         }
     };
@@ -183,14 +205,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         for (int j = 0; j < TN; ++j) rb_off[j] = A_BYTES + (uint32_t)h * RB + (uint32_t)(wn * WTN + j * 32 + r) * 4u;
     }
 
+    // Ring of NST stages, NST - 1 of them in flight: a K-step's MFMAs (0.1-0.25 us) are far shorter than the round
+    // trip of its DMA, so with one stage in flight (NST = 2) the loop runs at the DMA latency; each step waits (counted
+    // vmcnt) only for its own stage and passes one barrier.
     const int nsteps = (kend - kbeg + KP - 1) / KP;
-    dma_stage(0, 0);
-    dma_drain();
-    __syncthreads();
+    constexpr int PER = AI + BI;  // DMA instructions per stage per wave
+    static_assert(NST >= 2 && NST <= 4 && 2 * PER <= 63, "vmcnt immediates below cover NST <= 4");
+    for (int s = 0; s < NST - 1 && s < nsteps; ++s) dma_stage(s, s);
 
     for (int s = 0; s < nsteps; ++s) {
-        if (s + 1 < nsteps) dma_stage((s + 1) & 1, s + 1);
-        const char* sS = smem + (s & 1) * STAGE;
+        const int younger = min(NST - 2, nsteps - 1 - s);  // stages issued after stage s
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+        else dma_drain();
+        __syncthreads();  // stage s has landed for everyone; everyone is done computing stage s - 1
+        if (s + NST - 1 < nsteps) dma_stage((s + NST - 1) % NST, s + NST - 1);
+        const char* sS = smem + (s % NST) * STAGE;
         if constexpr (kBf16) {
 #pragma unroll
             for (int ks = 0; ks < KP / 16; ++ks) {
@@ -234,8 +264,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }
         }
-        dma_drain();
-        __syncthreads();
     }
 
     const int frow = lane & 31, fh = lane >> 5;
@@ -258,18 +286,53 @@ static int env_int(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-template <typename T, int BMW, int BNW, int KP, bool DENSE>
+// CUs per XCD and workgroups of `kern` a CU holds at once (LDS / VGPR / wave limits), looked up once per kernel.
+static int cus_per_xcd() {
+    static int v = 0;
+    if (!v) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+            cus = 256;
+        v = cus / 8;
+    }
+    return v;
+}
+
+template <typename T, int BMW, int BNW, int KP, bool DENSE, int NST>
 int launch_wgrad_kp(WgradParams p, hipStream_t st) {
     constexpr int SZ = sizeof(T);
-    constexpr int LDS = 2 * KP * (BMW * SZ + BNW * SZ);
+    constexpr int LDS = NST * KP * (BMW * SZ + BNW * SZ);
     p.tilesCo = (p.Co + BMW - 1) / BMW;
     p.tilesCi = (p.Ci + BNW - 1) / BNW;
+    p.adv_n = KP / p.HoWo;
+    p.adv_oy = (KP % p.HoWo) / p.Wo;
+    p.adv_ox = (KP % p.HoWo) % p.Wo;
     const long gx = (long)p.tilesCo * p.ntaps * p.tilesCi;
-    // split the pixel axis so that ~target workgroups are in flight, >= 8 K-steps each.  Every workgroup ends
-    // with BMW*BNW f32 atomics, so the atomic traffic of a launch is ~target * 64 KB whatever the layer: at the
-    // chip's ~1.3 TB/s atomic rate 1024 workgroups cost 51 us per launch (12 ms per step); 512 halves that.
-    const long target = env_int("SM3_WGRAD_TARGET_CTAS", 512);
-    long splits = (target + gx - 1) / gx;
+    auto kern = conv_wgrad_kernel<T, BMW, BNW, KP, DENSE, NST>;
+    static int per_cu = 0;  // resident workgroups per CU
+    if (!per_cu) {
+        if (LDS > 65536) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess) return (int)e;
+        }
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, LDS) != hipSuccess || n < 1) n = 1;
+        per_cu = n;
+    }
+    // Split the pixel axis so that the launch is ONE full wave of workgroups: every XCD holds whole pixel slices (all
+    // gx tiles of a slice side by side, re-reading the slice's dY / X rows from that XCD's L2 while they walk it in step)
+    // and as many slices as fit its CUs.  One workgroup too many per XCD and the launch takes a second, nearly empty
+    // round: 3x3 256->256 at 72 workgroups for 64 slots ran at 515 TFLOP/s, at 108 for 128 slots at 749.  Each
+    // workgroup keeps >= 8 K-steps, and ends with BMW*BNW f32 atomics (~1.3 TB/s chip-wide), which is what keeps the
+    // 64 KB-per-workgroup variant (fewer, longer workgroups) ahead for the 1x1 layers.  SM3_WGRAD_TARGET_CTAS overrides.
+    const long slots_xcd = (long)cus_per_xcd() * per_cu;
+    const long target = env_int("SM3_WGRAD_TARGET_CTAS", 0);
+    long splits;
+    if (target > 0) splits = (target + gx - 1) / gx;
+    else if (gx <= slots_xcd) splits = 8 * (slots_xcd / gx);
+    else splits = 8 * slots_xcd / gx;  // < 8 slices: tiles go round-robin over the XCDs (see the kernel)
     const long max_splits = (p.M + KP * 8 - 1) / (KP * 8);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -277,14 +340,6 @@ int launch_wgrad_kp(WgradParams p, hipStream_t st) {
     kps = (kps + KP - 1) / KP * KP;
     splits = (p.M + kps - 1) / kps;
     p.k_per_split = (int)kps;
-    auto kern = conv_wgrad_kernel<T, BMW, BNW, KP, DENSE>;
-    static bool attr_set = false;
-    if (!attr_set && LDS > 65536) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
     p.gx = (int)gx;
     p.splits = (int)splits;
     const long nblocks = gx * (splits >= 8 ? (splits + 7) / 8 * 8 : splits);
@@ -296,12 +351,14 @@ int launch_wgrad_kp(WgradParams p, hipStream_t st) {
 
 template <typename T, int BMW, int BNW>
 int launch_wgrad(WgradParams p, hipStream_t st) {
-    // K-step: 64 pixels in bf16, 32 in f32 (same 16-32 KB of tile bytes per stage)
-    constexpr int KP = sizeof(T) == 2 ? 64 : 32;
+    // K-step: 32 pixels in bf16, 16 in f32 (8-16 KB of tile bytes per stage).  1x1 stride-1 layers: ring of 4 stages
+    // (3 in flight), two 64 KB workgroups per CU.  Tap-shifted layers (3x3, stride 2): 2 stages, 32 KB, four to five
+    // workgroups per CU -- more, shorter workgroups fill the single wave better (measured per shape, profiles/r02b).
+    constexpr int KP = sizeof(T) == 2 ? 32 : 16;
     const bool dense = p.ntaps == 1 && p.sy == 1 && p.sx == 1 && p.dyt[0] == 0 && p.dxt[0] == 0 &&
                        p.HoWo == p.Hi * p.Wi;
-    if (dense) return launch_wgrad_kp<T, BMW, BNW, KP, true>(p, st);
-    return launch_wgrad_kp<T, BMW, BNW, KP, false>(p, st);
+    if (dense) return launch_wgrad_kp<T, BMW, BNW, KP, true, 4>(p, st);
+    return launch_wgrad_kp<T, BMW, BNW, KP, false, 2>(p, st);
 }
 
 }  // namespace
@@ -323,7 +380,7 @@ extern "C" int sm3_conv_wgrad(const sm3_conv_desc* d, const void* x, const void*
     p.sy = d->sy; p.sx = d->sx; p.ntaps = d->ntaps;
     for (int t = 0; t < SM3_MAX_TAPS; ++t) { p.dyt[t] = d->dy[t]; p.dxt[t] = d->dx[t]; p.wtap[t] = d->wtap[t]; }
     p.w_row_stride = d->w_row_stride;
-    p.HoWo = d->Ho * d->Wo; p.Wo = d->Wo;
+    p.HoWo = d->Ho * d->Wo; p.Wo = d->Wo; p.Ho = d->Ho;
     p.div_HoWo = make_fastdiv((uint32_t)p.HoWo);
     p.div_Wo = make_fastdiv((uint32_t)p.Wo);
     const long xb = (long)d->N * d->Hi * d->Wi * d->Ci * sz, yb = M * d->Co * sz;
