@@ -100,6 +100,13 @@ int sm3_conv_dgrad_bnfuse(const sm3_conv_desc* d, const void* dy_in, const void*
  * tools/backbone_eval.py --finetune fc, inference.py) never writes or re-reads a pre-BN tensor. */
 int sm3_conv_bn_act_eval(const sm3_conv_desc* d, const void* x, const void* w, const float* scale,
                          const float* shift, const void* residual, int relu, void* y, void* stream);
+/* Same launch with scale/shift derived in the epilogue from the BatchNorm's own tensors,
+ *   scale = gamma / sqrt(running_var + eps),  shift = beta - running_mean * scale      (gamma/beta NULL: 1 / 0),
+ * bit-identical to sm3_bn_eval_scale_shift followed by sm3_conv_bn_act_eval, without the 53 small launches per encoder
+ * pass that computing the vectors first costs (nn.BatchNorm2d.forward in eval mode, src/models/resnet.py:156-169). */
+int sm3_conv_bn_eval(const sm3_conv_desc* d, const void* x, const void* w, const float* gamma, const float* beta,
+                     const float* running_mean, const float* running_var, float eps, const void* residual, int relu,
+                     void* y, void* stream);
 
 /* Weight gradient of the forward conv described by d (autograd of the same call sites):
  *   dw[co*w_row_stride + wtap[t]*Ci + ci] += sum_{n,oy,ox} dy[(n,oy,ox), co] * x[n, oy*sy+dy[t], ox*sx+dx[t], ci]
@@ -192,6 +199,7 @@ int sm3_stem_im2col(int dtype, const float* x_nchw, void* cols, int N, int H, in
  *   output pixels of one output row -- tiles are image-major, so a view's rows are contiguous. */
 int sm3_stem_partial_rows(int N, int H, int W);
 int sm3_stem_weight_prep(int dtype, const float* w_master, void* w_stem, void* stream);
+int sm3_stem_weight_prep_if(int dtype, const float* w_master, void* w_stem, const int* only_if, void* stream);
 int sm3_stem_conv_fwd(int dtype, const float* x_nchw, const void* w_stem, void* y, float* stat_partials, int N, int H,
                       int W, void* stream);
 /* Stem weight gradient with phase 2 of bn1's backward fused into its operand load:
@@ -237,6 +245,15 @@ typedef struct sm3_wprep_item {
     int32_t Co, taps, Ci, ld_fwd;
 } sm3_wprep_item;
 int sm3_weight_prep_batch(int dtype, const sm3_wprep_item* items_device, int n, void* stream);
+/* Frozen weights keep their banks (frozen-encoder loops: tools/backbone_eval.py --finetune fc, tools/mlc_train.py,
+ * inference.py) without the host ever reading device memory or trusting a framework's dirty bits:
+ *   sm3_weights_changed: position-weighted 64-bit hash of the n fp32 words at `flat`; *changed = (hash != state[1]);
+ *                        state[1] = hash.  state: 2 x uint64 on the device, zero-initialised by the caller once.
+ *   sm3_weight_prep_batch_if / sm3_stem_weight_prep_if: the launches above, whose workgroups return at once when
+ *                        *only_if == 0 (only_if NULL = unconditional).  Two launches + early-exit kernels: ~0.03 ms
+ *                        instead of the 0.2 ms re-layout of 47 M weights. */
+int sm3_weights_changed(const float* flat, int64_t n, uint64_t* state, int* changed, void* stream);
+int sm3_weight_prep_batch_if(int dtype, const sm3_wprep_item* items_device, int n, const int* only_if, void* stream);
 /* elementwise cast fp32 -> dtype */
 int sm3_cast_from_f32(int dtype, const float* src, void* dst, int64_t n, void* stream);
 int sm3_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, void* stream);

@@ -37,7 +37,26 @@ struct ConvParams {
     const float* ep_scale;
     const float* ep_shift;
     int ep_relu;
+    // ... or the BatchNorm's own tensors, scale/shift derived per channel in the epilogue (ep_rv != null)
+    const float* ep_gamma;
+    const float* ep_beta;
+    const float* ep_rm;
+    const float* ep_rv;
+    float ep_eps;
 };
+
+// eval-mode BatchNorm as y = x * scale + shift, the arithmetic of bn_eval_kernel (bn.hip)
+__device__ __forceinline__ void ep_affine(const ConvParams& p, int c, float& scale, float& shift) {
+    if (p.ep_rv) {
+        const float invstd = 1.f / sqrtf(p.ep_rv[c] + p.ep_eps);
+        const float g = p.ep_gamma ? p.ep_gamma[c] : 1.f, b = p.ep_beta ? p.ep_beta[c] : 0.f;
+        scale = g * invstd;
+        shift = b - p.ep_rm[c] * g * invstd;
+    } else {
+        scale = p.ep_scale[c];
+        shift = p.ep_shift[c];
+    }
+}
 
 template <typename T>
 __device__ __forceinline__ void mma_frag(const uint4& a, const uint4& b, f32x16& c);

@@ -222,9 +222,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
             char* colp = sC + (wn * WTN + j * 32 + frow) * 2 + (wm * WTM + 4 * fh) * LEAN_PITCH;
             // inference: eval-mode BatchNorm (+ReLU) of this lane's column, applied in the accumulator layout
             const int gcol = n0 + wn * WTN + j * 32 + frow;
-            const bool epl = p.ep_scale != nullptr;
-            const float esc = (epl && gcol < p.Co) ? p.ep_scale[gcol] : 1.f;
-            const float esh = (epl && gcol < p.Co) ? p.ep_shift[gcol] : 0.f;
+            const bool epl = p.ep_scale != nullptr || p.ep_rv != nullptr;
+            float esc = 1.f, esh = 0.f;
+            if (epl && gcol < p.Co) ep_affine(p, gcol, esc, esh);
             const float elo = (epl && p.ep_relu) ? 0.f : -INFINITY;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
     }
 
     // f_mu/f_is double as the inference epilogue's per-channel scale/shift (the two modes are exclusive)
-    const bool ep = p.ep_scale != nullptr;
+    const bool ep = p.ep_scale != nullptr || p.ep_rv != nullptr;
     // two views in one launch: a tile belongs to exactly one of them (view rows are a multiple of BM)
     const int fz_view = (p.fz_view_tiles > 0 && bm >= p.fz_view_tiles) ? 1 : 0;
     const int fz_prow = fz_view ? p.fz_row_off1 + bm - p.fz_view_tiles : p.fz_row_off + bm;
@@ -327,8 +327,16 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
     for (int e = 0; e < EPC; ++e) {
         f_s1[e] = 0.f;
         f_s2[e] = 0.f;
-        f_mu[e] = (ncol < p.Co) ? (fz ? p.fz_mean[fz_view * p.Co + ncol + e] : (ep ? p.ep_shift[ncol + e] : 0.f)) : 0.f;
-        f_is[e] = (ncol < p.Co) ? (fz ? p.fz_invstd[fz_view * p.Co + ncol + e] : (ep ? p.ep_scale[ncol + e] : 0.f)) : 0.f;
+        f_mu[e] = 0.f;
+        f_is[e] = 0.f;
+        if (ncol < p.Co) {
+            if (fz) {
+                f_mu[e] = p.fz_mean[fz_view * p.Co + ncol + e];
+                f_is[e] = p.fz_invstd[fz_view * p.Co + ncol + e];
+            } else if (ep) {
+                ep_affine(p, ncol + e, f_is[e], f_mu[e]);
+            }
+        }
     }
 
 #pragma unroll
@@ -553,9 +561,15 @@ extern "C" int sm3_conv_partial_rows(const sm3_conv_desc* d) {
     return (int)((M + kBM - 1) / kBM);
 }
 
+struct EvalBn {  // eval-mode BatchNorm folded into the epilogue: precomputed vectors, or the BatchNorm's tensors
+    const float *scale, *shift, *gamma, *beta, *rm, *rv;
+    float eps;
+    int relu;
+};
+
 static int conv_gather_gemm_impl(const sm3_conv_desc* d, const void* x, const void* w, void* y, const void* addend,
                                  float* stat_partials, const sm3_bn_bwd_fuse* fuse, void* stream,
-                                 const float* ep_scale = nullptr, const float* ep_shift = nullptr, int ep_relu = 0) {
+                                 const EvalBn* ebn = nullptr) {
     if (!d || !x || !w || !y) return SM3_EINVAL;
     if (fuse && (!fuse->x || !fuse->mean || !fuse->invstd || !fuse->partials || fuse->partial_row_offset < 0))
         return SM3_EINVAL;
@@ -586,9 +600,14 @@ static int conv_gather_gemm_impl(const sm3_conv_desc* d, const void* x, const vo
         p.fz_view_tiles = p.M / 2 / kBM;
         p.fz_row_off1 = fuse->partial_row_offset_view1;
     }
-    p.ep_scale = ep_scale;
-    p.ep_shift = ep_shift;
-    p.ep_relu = ep_relu;
+    p.ep_scale = ebn ? ebn->scale : nullptr;
+    p.ep_shift = ebn ? ebn->shift : nullptr;
+    p.ep_gamma = ebn ? ebn->gamma : nullptr;
+    p.ep_beta = ebn ? ebn->beta : nullptr;
+    p.ep_rm = ebn ? ebn->rm : nullptr;
+    p.ep_rv = ebn ? ebn->rv : nullptr;
+    p.ep_eps = ebn ? ebn->eps : 0.f;
+    p.ep_relu = ebn ? ebn->relu : 0;
     hipStream_t st = (hipStream_t)stream;
     // 64-column tiles for Co <= 64, and for the small-M Linears whose 128-column grid would leave most CUs idle
     const long tiles128 = (long)((p.M + kBM - 1) / kBM) * ((d->Co + 127) / 128);
@@ -614,5 +633,14 @@ extern "C" int sm3_conv_dgrad_bnfuse(const sm3_conv_desc* d, const void* dy_in, 
 extern "C" int sm3_conv_bn_act_eval(const sm3_conv_desc* d, const void* x, const void* w, const float* scale,
                                     const float* shift, const void* residual, int relu, void* y, void* stream) {
     if (!scale || !shift) return SM3_EINVAL;
-    return conv_gather_gemm_impl(d, x, w, y, residual, nullptr, nullptr, stream, scale, shift, relu);
+    const EvalBn e{scale, shift, nullptr, nullptr, nullptr, nullptr, 0.f, relu};
+    return conv_gather_gemm_impl(d, x, w, y, residual, nullptr, nullptr, stream, &e);
+}
+
+extern "C" int sm3_conv_bn_eval(const sm3_conv_desc* d, const void* x, const void* w, const float* gamma,
+                                const float* beta, const float* running_mean, const float* running_var, float eps,
+                                const void* residual, int relu, void* y, void* stream) {
+    if (!running_mean || !running_var || !(eps >= 0.f)) return SM3_EINVAL;
+    const EvalBn e{nullptr, nullptr, gamma, beta, running_mean, running_var, eps, relu};
+    return conv_gather_gemm_impl(d, x, w, y, residual, nullptr, nullptr, stream, &e);
 }

@@ -419,8 +419,10 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, int Co, int taps
 // fp32 reads (along ci) and the T writes (along co) are coalesced -- the element-wise form read w with a stride of
 // taps*Ci floats per lane and ran at 0.8 TB/s (0.8 ms per step for 47 M weights).
 template <typename T>
-__global__ __launch_bounds__(256) void weight_prep_batch_kernel(const sm3_wprep_item* __restrict__ items) {
+__global__ __launch_bounds__(256) void weight_prep_batch_kernel(const sm3_wprep_item* __restrict__ items,
+                                                                const int* __restrict__ only_if) {
     __shared__ float tile[32][33];
+    if (only_if && *only_if == 0) return;  // masters unchanged since the banks were written (sm3_weights_changed)
     const sm3_wprep_item it = items[blockIdx.y];
     const float* __restrict__ w = it.w;
     T* __restrict__ wf = reinterpret_cast<T*>(it.w_fwd);
@@ -638,13 +640,55 @@ extern "C" int sm3_weight_prep(int dtype, const float* w, int Co, int taps, int 
     return 0;
 }
 
-extern "C" int sm3_weight_prep_batch(int dtype, const sm3_wprep_item* items_device, int n, void* stream) {
+extern "C" int sm3_weight_prep_batch_if(int dtype, const sm3_wprep_item* items_device, int n, const int* only_if,
+                                        void* stream) {
     if (!items_device || n <= 0 || n > 65535) return SM3_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(weight_prep_batch_kernel<float>, dim3(96, n), dim3(256), 0, st, items_device),
-               hipLaunchKernelGGL(weight_prep_batch_kernel<bf16_t>, dim3(96, n), dim3(256), 0, st, items_device),
-               hipLaunchKernelGGL(weight_prep_batch_kernel<f16_t>, dim3(96, n), dim3(256), 0, st, items_device));
+               hipLaunchKernelGGL(weight_prep_batch_kernel<float>, dim3(96, n), dim3(256), 0, st, items_device, only_if),
+               hipLaunchKernelGGL(weight_prep_batch_kernel<bf16_t>, dim3(96, n), dim3(256), 0, st, items_device, only_if),
+               hipLaunchKernelGGL(weight_prep_batch_kernel<f16_t>, dim3(96, n), dim3(256), 0, st, items_device, only_if));
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_weight_prep_batch(int dtype, const sm3_wprep_item* items_device, int n, void* stream) {
+    return sm3_weight_prep_batch_if(dtype, items_device, n, nullptr, stream);
+}
+
+namespace {
+
+// h = sum_i (bits_i + c) * (2i + 1)  mod 2^64: any single changed word changes h (odd multiplier), and the masters'
+// typical change (every word, by an optimizer step) cancelling exactly is a 2^-64 event.
+__global__ __launch_bounds__(256) void weights_hash_kernel(const uint32_t* __restrict__ w, int64_t n,
+                                                           unsigned long long* __restrict__ acc) {
+    unsigned long long h = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        h += ((unsigned long long)w[i] + 0x9E3779B97F4A7C15ull) * (unsigned long long)(2 * i + 1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
+    __shared__ unsigned long long part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+}
+
+__global__ void weights_changed_kernel(unsigned long long* __restrict__ state, int* __restrict__ changed) {
+    *changed = state[0] != state[1];
+    state[1] = state[0];
+    state[0] = 0;  // accumulator of the next call
+}
+
+}  // namespace
+
+extern "C" int sm3_weights_changed(const float* flat, int64_t n, uint64_t* state, int* changed, void* stream) {
+    if (!flat || !state || !changed || n <= 0) return SM3_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(weights_hash_kernel, dim3(1024), dim3(256), 0, st, reinterpret_cast<const uint32_t*>(flat), n,
+                       reinterpret_cast<unsigned long long*>(state));
+    SM3_CHECK_LAUNCH();
+    hipLaunchKernelGGL(weights_changed_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<unsigned long long*>(state), changed);
     SM3_CHECK_LAUNCH();
     return 0;
 }

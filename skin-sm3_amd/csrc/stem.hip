@@ -316,9 +316,9 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradParams p
 
 // master [64][kh][kw][c] fp32 -> bf16 [64][176], k = (kh*3 + c)*8 + kw, zero where kw == 7 or k >= 168
 template <typename T>
-__global__ void stem_weight_prep_kernel(const float* __restrict__ w, T* __restrict__ out) {
+__global__ void stem_weight_prep_kernel(const float* __restrict__ w, T* __restrict__ out, const int* __restrict__ only_if) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 64 * KPAD) return;
+    if (i >= 64 * KPAD || (only_if && *only_if == 0)) return;
     const int co = i / KPAD, k = i - co * KPAD;
     const int g = k >> 3, kw = k & 7;
     float v = 0.f;
@@ -348,18 +348,22 @@ extern "C" int sm3_stem_partial_rows(int N, int H, int W) {
     return tiles > 0x7fffffffL ? SM3_EINVAL : (int)tiles;
 }
 
-extern "C" int sm3_stem_weight_prep(int dtype, const float* w_master, void* w_stem, void* stream) {
+extern "C" int sm3_stem_weight_prep_if(int dtype, const float* w_master, void* w_stem, const int* only_if, void* stream) {
     if (!w_master || !w_stem) return SM3_EINVAL;
     if (dtype == SM3_BF16)
         hipLaunchKernelGGL(stem_weight_prep_kernel<bf16_t>, dim3((64 * KPAD + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                           w_master, (bf16_t*)w_stem);
+                           w_master, (bf16_t*)w_stem, only_if);
     else if (dtype == SM3_F16)
         hipLaunchKernelGGL(stem_weight_prep_kernel<f16_t>, dim3((64 * KPAD + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                           w_master, (f16_t*)w_stem);
+                           w_master, (f16_t*)w_stem, only_if);
     else
         return SM3_EDTYPE;
     SM3_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int sm3_stem_weight_prep(int dtype, const float* w_master, void* w_stem, void* stream) {
+    return sm3_stem_weight_prep_if(dtype, w_master, w_stem, nullptr, stream);
 }
 
 extern "C" int sm3_stem_conv_fwd(int dtype, const float* x_nchw, const void* w_stem, void* y, float* stat_partials, int N,

@@ -54,6 +54,7 @@ SIGNATURES = {
     "sm3_conv_gather_gemm": [_DESC, _P, _P, _P, _P, _P, _P],
     "sm3_conv_dgrad_bnfuse": [_DESC, _P, _P, _P, _P, _P, _P],
     "sm3_conv_bn_act_eval": [_DESC, _P, _P, _P, _P, _P, _I, _P, _P],
+    "sm3_conv_bn_eval": [_DESC, _P, _P, _P, _P, _P, _P, _F, _P, _I, _P, _P],
     "sm3_conv_wgrad": [_DESC, _P, _P, _P, _P],
     "sm3_bn_stats_reduce": [_P, _I, _I, _P, _P, _I, _P],
     "sm3_bn_reduce_groups": [_I],
@@ -71,11 +72,14 @@ SIGNATURES = {
     "sm3_stem_im2col": [_I, _P, _P, _I, _I, _I, _I, _P],
     "sm3_stem_partial_rows": [_I, _I, _I],
     "sm3_stem_weight_prep": [_I, _P, _P, _P],
+    "sm3_stem_weight_prep_if": [_I, _P, _P, _P, _P],
     "sm3_stem_conv_fwd": [_I, _P, _P, _P, _P, _I, _I, _I, _P],
     "sm3_stem_wgrad_bn": [_I, _P, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "sm3_maxpool3x3s2_fwd": [_I, _P, _P, _P, _I, _I, _I, _I, _P],
     "sm3_maxpool3x3s2_bwd": [_I, _P, _P, _P, _I, _I, _I, _I, _P],
     "sm3_weight_prep_batch": [_I, _P, _I, _P],
+    "sm3_weight_prep_batch_if": [_I, _P, _I, _P, _P],
+    "sm3_weights_changed": [_P, _L, _P, _P, _P],
     "sm3_avgpool_fwd": [_I, _P, _P, _P, _I, _I, _I, _P],
     "sm3_avgpool_bwd": [_I, _P, _P, _I, _I, _I, _P],
     "sm3_weight_prep": [_I, _P, _I, _I, _I, _P, _I, _P, _P],

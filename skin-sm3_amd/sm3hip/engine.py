@@ -320,7 +320,7 @@ class SM3Engine:
         """fp32 master -> `dtype` filter banks (forward and data-gradient order); once per step, one launch.  The device
         table of (master, bank) pointers is cached per master buffer (the online weights, and the momentum target's when
         the trainer swaps store.flat_p for a target forward)."""
-        key = (self.store.flat_p.data_ptr(), len(self.store.names))
+        key = (self.store.flat_p.data_ptr(), len(self.store.names), self.dtype)
         cache = self.__dict__.setdefault("_wprep_cache", {})
         if key not in cache:
             items, stems = [], []
@@ -335,11 +335,26 @@ class SM3Engine:
                     items.append((m, cu.w_fwd, None, cu.Co, 1, 147, STEM_KPAD))
                 else:
                     items.append((m, cu.w_fwd, cu.w_dgrad, cu.Co, cu.taps, cu.Ci, cu.taps * cu.Ci))
-            cache[key] = (ops.weight_prep_table(items, self.store.flat_p.device), stems)
-        table, stems = cache[key]
-        ops.weight_prep_batch(self.dtype, table)
+            dev = self.store.flat_p.device
+            cache[key] = (ops.weight_prep_table(items, dev), stems,
+                          torch.zeros(2, dtype=torch.int64, device=dev), torch.ones(1, dtype=torch.int32, device=dev))
+        table, stems, hstate, changed = cache[key]
+        # Frozen masters (linear probe, multi-label heads, inference: the same encoders forward after forward) keep their
+        # banks.  Whether they changed is decided ON THE DEVICE from a hash of the flat buffer -- torch's version counters
+        # miss `p.data` writes and raw-pointer kernels, a stale bank would be a silent error.  A caller that knows it just
+        # rewrote the masters (the fused optimizer step) sets weights_dirty and skips the hash.
+        only_if = None
+        if not self.__dict__.get("weights_dirty", True) and self.__dict__.get("_wprep_key") == key:
+            ops.weights_changed(self.store.flat_p, hstate, changed)
+            if self.__dict__.get("_hash_tracks_banks", False):
+                only_if = changed
+            self._hash_tracks_banks = True  # from here on the hash state is that of the masters the banks were made from
+        else:
+            self._hash_tracks_banks = False  # unconditional re-layout: the remembered hash no longer describes the banks
+        self._wprep_key, self.weights_dirty = key, False
+        ops.weight_prep_batch(self.dtype, table, only_if)
         for m, w in stems:
-            ops.stem_weight_prep(self.dtype, m, w)
+            ops.stem_weight_prep(self.dtype, m, w, only_if)
 
     def _work(self, key, numel, dtype=torch.float32):
         """Stream-ordered scratch; one set per execution lane (branch stream) so concurrent branches never share."""
@@ -416,13 +431,17 @@ class SM3Engine:
 
     # ---- conv + BN (+residual) (+ReLU) ---------------------------------------------------
     def conv_bn(self, cu, bu, x, N, H, W, relu, residual=None, train=True, save=None, out_f32=False, y_out=None,
-                apply=True, scale_shift=None, res_affine=None):
+                apply=True, scale_shift=None, res_affine=None, pending=None):
         """One conv + BatchNorm (+residual) (+ReLU) unit on N images.  With self._V == 2 the batch is two views back
         to back (N = 2B): one convolution launch, BatchNorm statistics / running-statistics updates per view.
         apply=False: stop after the statistics -- returns the pre-BatchNorm tensor, scale/shift are left in
         `scale_shift` for the consumer that applies them (the join of a downsample block, the stem's fused
         BN+ReLU+maxpool).  res_affine=(scale2, shift2): `residual` is such a pre-BatchNorm tensor and is normalised
-        inside this unit's apply pass."""
+        inside this unit's apply pass.
+        pending (data parallel only): a list shared by the two BatchNorms that meet at a residual join.  The unit called
+        with apply=False (the downsample branch) leaves its per-rank statistic sums in the first half of a shared buffer
+        and queues its finalize there instead of synchronising; the unit called next with the same list (conv3) puts
+        its sums behind them, all-reduces BOTH in one collective and runs the queued finalize before its own."""
         dev = x.device
         direct = cu.stem and self.direct_stem  # x is the NCHW fp32 image batch, N / H / W its geometry
         if direct:
@@ -454,34 +473,57 @@ class SM3Engine:
             else:
                 ops.conv_gemm(d, x, cu.w_fwd, xo, None, partials)
             count, groups = rows_v, 1
-            if self.stat_sync is not None:
-                sums = self._work("sums", 2 * 2 * 2048, torch.float64)
-                ops.bn_stats_reduce(partials, prow // V, C, sums, views=V)
-                self.stat_sync(sums[: V * 2 * C])  # one all-reduce for both views
-                count = rows_v * self.world_size
-            else:  # single rank: stage B of the reduction is folded into bn_finalize (one launch fewer per BN)
-                sums, groups = ops.bn_stats_reduce(partials, prow // V, C, None, views=V)
             mean = torch.empty(V * C, dtype=torch.float32, device=dev)
             invstd = torch.empty(V * C, dtype=torch.float32, device=dev)
+            deferred = False
+            if self.stat_sync is not None:
+                count = rows_v * self.world_size
+                n = V * 2 * C
+                if pending is not None and not apply:          # downsample branch: sums parked, sync left to conv3
+                    pair = self._work("sums_pair", 2 * 2 * 2 * 2048, torch.float64)
+                    sums = pair[:n]
+                    ops.bn_stats_reduce(partials, prow // V, C, sums, views=V)
+                    deferred = True
+                elif pending:                                  # conv3 of that block: one all-reduce for both units
+                    pair = self._work("sums_pair", 2 * 2 * 2 * 2048, torch.float64)
+                    n0 = pending[0][0]
+                    sums = pair[n0:n0 + n]
+                    ops.bn_stats_reduce(partials, prow // V, C, sums, views=V)
+                    self.stat_sync(pair[: n0 + n])
+                    for _, fin in pending:
+                        fin()
+                    del pending[:]
+                else:
+                    sums = self._work("sums", 2 * 2 * 2048, torch.float64)
+                    ops.bn_stats_reduce(partials, prow // V, C, sums, views=V)
+                    self.stat_sync(sums[:n])  # one all-reduce for both views
+            else:  # single rank: stage B of the reduction is folded into bn_finalize (one launch fewer per BN)
+                sums, groups = ops.bn_stats_reduce(partials, prow // V, C, None, views=V)
             ordered = self._ordered_bn and dev.type == "cuda"
-            if ordered and self._view == 1:
-                # running_mean/var/num_batches_tracked are updated view 0 first, then view 1, as in the reference's
-                # sequential encoder(x1); encoder(x2): the view-1 lane waits for view 0's update of THIS BatchNorm
-                torch.cuda.current_stream().wait_event(self._bn_ev[bu.name])
-            ops.bn_finalize(sums, count, C, gamma, beta, BN_EPS, BN_MOMENTUM, rm if track else None,
-                            rv if track else None, self.buffers[bu.name + ".num_batches_tracked"] if track else None,
-                            scale, shift, mean, invstd, groups=groups, views=V)
-            if ordered and self._view == 0:
-                ev = self._bn_ev.get(bu.name)
-                if ev is None:
-                    ev = self._bn_ev[bu.name] = torch.cuda.Event()
-                ev.record()
+
+            def finalize(sums=sums, groups=groups):
+                if ordered and self._view == 1:
+                    # running_mean/var/num_batches_tracked are updated view 0 first, then view 1, as in the reference's
+                    # sequential encoder(x1); encoder(x2): the view-1 lane waits for view 0's update of THIS BatchNorm
+                    torch.cuda.current_stream().wait_event(self._bn_ev[bu.name])
+                ops.bn_finalize(sums, count, C, gamma, beta, BN_EPS, BN_MOMENTUM, rm if track else None,
+                                rv if track else None,
+                                self.buffers[bu.name + ".num_batches_tracked"] if track else None,
+                                scale, shift, mean, invstd, groups=groups, views=V)
+                if ordered and self._view == 0:
+                    ev = self._bn_ev.get(bu.name)
+                    if ev is None:
+                        ev = self._bn_ev[bu.name] = torch.cuda.Event()
+                    ev.record()
+            if deferred:
+                pending.append((V * 2 * C, finalize))
+            else:
+                finalize()
         elif save is None and not out_f32 and apply:
             # inference: conv + running-statistics BN (+residual) (+ReLU) in ONE launch, no pre-BN tensor in HBM
-            ops.bn_eval_scale_shift(gamma, beta, rm, rv, BN_EPS, C, scale, shift)
             if y_out is None:
                 y_out = xo
-            ops.conv_bn_act_eval(d, x, cu.w_fwd, scale, shift, residual, relu, y_out)
+            ops.conv_bn_eval(d, x, cu.w_fwd, gamma, beta, rm, rv, BN_EPS, residual, relu, y_out)
             return y_out, Ho, Wo
         else:
             if direct:
@@ -735,16 +777,20 @@ class SM3Engine:
             y1, h1, w1 = self.conv_bn(blk["c1"], blk["b1"], cur, N, h, w, True, None, train, br)
             y2, h2, w2 = self.conv_bn(blk["c2"], blk["b2"], y1, N, h1, w1, True, None, train, br)
             ra = None
+            pend = None
             if "cd" in blk and lazy:
                 # downsample branch: convolution + statistics only; its BatchNorm is applied inside the join below
+                # (data parallel: its statistics travel in conv3's all-reduce)
                 ra = (self._work("scale_d", 2 * 2048), self._work("shift_d", 2 * 2048))
+                pend = [] if (train and self.stat_sync is not None) else None
                 idn, _, _ = self.conv_bn(blk["cd"], blk["bd"], cur, N, h, w, False, None, train, br, apply=False,
-                                         scale_shift=ra)
+                                         scale_shift=ra, pending=pend)
             elif "cd" in blk:
                 idn, _, _ = self.conv_bn(blk["cd"], blk["bd"], cur, N, h, w, False, None, train, br)
             else:
                 idn = cur
-            y3, h3, w3 = self.conv_bn(blk["c3"], blk["b3"], y2, N, h2, w2, True, idn, train, br, res_affine=ra)
+            y3, h3, w3 = self.conv_bn(blk["c3"], blk["b3"], y2, N, h2, w2, True, idn, train, br, res_affine=ra,
+                                      pending=pend)
             block_recs.append(br)
             cur, h, w = y3, h3, w3
         ops.avgpool_fwd(self.dtype, cur, feat_f32, feat_t, N, h * w, plan.out_dim)

@@ -268,6 +268,32 @@ def conv_bn_act_eval(desc, x, w, scale, shift, residual, relu, y):
                                                _ptr(residual), int(relu), _ptr(y), _stream()), "sm3_conv_bn_act_eval")
 
 
+def conv_bn_eval(desc, x, w, gamma, beta, running_mean, running_var, eps, residual, relu, y):
+    """conv + eval-mode BN (+residual) (+ReLU) in one launch, scale/shift derived in the epilogue (sm3_conv_bn_eval)."""
+    tdt = TORCH_DTYPE[desc.dtype]
+    _chk(x, tdt, "x"); _chk(w, tdt, "w"); _chk(y, tdt, "y"); _chk(residual, tdt, "residual")
+    for t, n in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
+        _chk(t, torch.float32, n)
+        if t is not None and t.numel() < desc.Co:
+            raise ValueError(f"{n} too small")
+    if running_mean is None or running_var is None:
+        raise ValueError("running statistics are required")
+    if x.numel() != desc.N * desc.Hi * desc.Wi * desc.Ci:
+        raise ValueError("x size does not match descriptor")
+    n_out = desc.N * desc.Hout * desc.Wout * desc.Co
+    if y.numel() != n_out or (residual is not None and residual.numel() != n_out):
+        raise ValueError("y / residual size does not match descriptor")
+    if desc.Ci % K_CHUNK[desc.dtype]:
+        raise ValueError(f"Ci={desc.Ci} is not a multiple of {K_CHUNK[desc.dtype]}")
+    M = desc.N * desc.Ho * desc.Wo
+    sz = _sz(desc.dtype)
+    with _prof("conv_gemm_128x64" if desc.Co <= 64 else "conv_gemm_128x128", 2.0 * M * desc.Co * desc.ntaps * desc.Ci,
+               sz * (min(x.numel(), M * desc.ntaps * desc.Ci) + M * desc.Co * (2 if residual is not None else 1))):
+        check(_lib.load().sm3_conv_bn_eval(C.byref(desc), _ptr(x), _ptr(w), _ptr(gamma), _ptr(beta), _ptr(running_mean),
+                                           _ptr(running_var), float(eps), _ptr(residual), int(relu), _ptr(y), _stream()),
+              "sm3_conv_bn_eval")
+
+
 def conv_wgrad(desc, x, dy, dw):
     tdt = TORCH_DTYPE[desc.dtype]
     _chk(x, tdt, "x"); _chk(dy, tdt, "dy"); _chk(dw, torch.float32, "dw")
@@ -539,11 +565,12 @@ def stem_partial_rows(N, H, W):
     return _lib.load().sm3_stem_partial_rows(N, H, W)
 
 
-def stem_weight_prep(dtype, w_master, w_stem):
-    _chk(w_master, torch.float32, "w_master"); _chk(w_stem, TORCH_DTYPE[dtype], "w_stem")
+def stem_weight_prep(dtype, w_master, w_stem, only_if=None):
+    _chk(w_master, torch.float32, "w_master"); _chk(w_stem, TORCH_DTYPE[dtype], "w_stem"); _chk(only_if, torch.int32, "only_if")
     if w_master.numel() != 64 * 147 or w_stem.numel() != 64 * STEM_KDIRECT:
         raise ValueError("stem_weight_prep: size mismatch")
-    check(_lib.load().sm3_stem_weight_prep(dtype, _ptr(w_master), _ptr(w_stem), _stream()), "sm3_stem_weight_prep")
+    check(_lib.load().sm3_stem_weight_prep_if(dtype, _ptr(w_master), _ptr(w_stem), _ptr(only_if), _stream()),
+          "sm3_stem_weight_prep_if")
 
 
 def stem_conv_fwd(dtype, x_nchw, w_stem, y, partials=None):
@@ -656,11 +683,24 @@ def weight_prep_table(items, device):
     return host.to(device), len(items), total
 
 
-def weight_prep_batch(dtype, table):
+def weight_prep_batch(dtype, table, only_if=None):
+    """only_if: optional 1-element int32 device tensor; the launch does nothing when it holds 0 (see weights_changed)."""
     dev_table, n, total = table
-    _chk(dev_table, torch.uint8, "table")
+    _chk(dev_table, torch.uint8, "table"); _chk(only_if, torch.int32, "only_if")
     with _prof("weight_prep", 0.0, total * (4.0 + 2 * _sz(dtype))):
-        check(_lib.load().sm3_weight_prep_batch(dtype, _ptr(dev_table), n, _stream()), "sm3_weight_prep_batch")
+        check(_lib.load().sm3_weight_prep_batch_if(dtype, _ptr(dev_table), n, _ptr(only_if), _stream()),
+              "sm3_weight_prep_batch_if")
+
+
+def weights_changed(flat, state, changed):
+    """changed[0] = 1 iff the fp32 words of `flat` differ from those of the previous call with this `state` (2 x int64 on
+    the device, zeros before the first call).  Device-side only: no host read."""
+    _chk(flat, torch.float32, "flat"); _chk(state, torch.int64, "state"); _chk(changed, torch.int32, "changed")
+    if state.numel() < 2 or changed.numel() < 1:
+        raise ValueError("weights_changed: state needs 2 words, changed 1")
+    with _prof("weights_hash", 0.0, 4.0 * flat.numel()):
+        check(_lib.load().sm3_weights_changed(_ptr(flat), flat.numel(), _ptr(state), _ptr(changed), _stream()),
+              "sm3_weights_changed")
 
 
 def cast_from_f32(dtype, src, dst):

@@ -245,6 +245,7 @@ class SM3Trainer:
             self.step_count += 1  # calls made; the number of optimizer steps TAKEN lives on the device (steps_taken())
         if self.target_momentum is not None:
             ops.ema_update(self.flat_target, st.flat_p, self.target_momentum)
+        eng.weights_dirty = True  # raw-pointer writes: the engine's filter banks are stale
         self.loss = loss
         return loss
 

@@ -99,6 +99,35 @@ def test_conv_bn_act_eval_kernel():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("affine", [True, False])
+@pytest.mark.parametrize("with_res", [True, False], ids=["general_epilogue", "lean_epilogue"])
+def test_conv_bn_eval_derives_scale_shift_in_the_epilogue(with_res, affine):
+    """sm3_conv_bn_eval (BatchNorm tensors handed to the launch) == sm3_bn_eval_scale_shift + sm3_conv_bn_act_eval, bit for
+    bit, in every dtype; affine=False is the projector's last BatchNorm1d."""
+    from sm3hip import ops
+    D = torch.device("cuda:0")
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        code = ops.dtype_code(dt)
+        g = torch.Generator().manual_seed(5)
+        N, Ci, Co, H, k, s = 3, 128, 200, 9, 3, 1
+        x = torch.randn(N, H, H, Ci, generator=g).to(dt).to(D)
+        w = (torch.randn(Co, k, k, Ci, generator=g) / 34).to(dt).to(D)
+        gamma = (torch.rand(Co, generator=g) + 0.5).to(D) if affine else None
+        beta = torch.randn(Co, generator=g).to(D) if affine else None
+        rm, rv = torch.randn(Co, generator=g).to(D), (torch.rand(Co, generator=g) + 0.1).to(D)
+        d = ops.fwd_desc(code, N, H, H, Ci, Co, k, s, 1)
+        res = torch.randn(N * d.Ho * d.Wo, Co, generator=g).to(dt).to(D) if with_res else None
+        scale, shift = torch.empty(Co, device=D), torch.empty(Co, device=D)
+        ops.bn_eval_scale_shift(gamma, beta, rm, rv, 1e-5, Co, scale, shift)
+        y0 = torch.empty(N * d.Ho * d.Wo, Co, dtype=dt, device=D)
+        ops.conv_bn_act_eval(d, x, w, scale, shift, res, True, y0)
+        y1 = torch.full_like(y0, float("nan"))
+        ops.conv_bn_eval(d, x, w, gamma, beta, rm, rv, 1e-5, res, True, y1)
+        torch.cuda.synchronize()
+        assert torch.equal(y0, y1)
+
+
+@pytest.mark.gpu
 def test_baseline_linear_probe_step_matches_golden(golden_dir):
     """Frozen eval-mode encoders on the fused inference kernels + the 8 heads: logits, weighted loss and head
     gradients of the reference (tools/backbone_eval.py:98-112 with --finetune fc)."""

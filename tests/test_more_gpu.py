@@ -107,6 +107,41 @@ def test_bare_resnet50_forward_backward():
         assert (g - r).norm() <= 6e-2 * r.norm(), k  # the fp32 noise floor of this depth at B=3 (cf. test_e2e_gpu.py)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+def test_frozen_encoder_keeps_its_filter_banks_until_the_weights_really_change(dt):
+    """Frozen-encoder loops skip the per-forward re-layout of the filter banks; the decision is a device-side hash of the
+    fp32 masters, so a write that no version counter sees (`p.data`, the momentum-encoder idiom) is still picked up."""
+    from oracle import procedural
+    import resnet
+    from sm3hip import ops, profiler
+    state = procedural.make_state_dict(procedural.resnet50_spec(""), seed=19)
+
+    def build():
+        m = resnet.resnet50(weights=None)
+        m.fc = torch.nn.Identity()
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+        m.sm3_dtype = dt
+        for p in m.parameters():
+            p.requires_grad = False
+        return m.cuda().eval()
+    m = build()
+    x = _imgs(4, 64, 64, 19)[0][0].cuda()
+    with torch.no_grad():
+        f = [m(x).clone() for _ in range(4)]          # calls 3 and 4 run on the kept banks
+        assert all(torch.equal(f[0], fi) for fi in f[1:])
+        m.layer3[1].conv2.weight.data.mul_(0.5)       # invisible to torch's version counters
+        m.conv1.weight.data.add_(0.01)                # the direct stem's bank too
+        g1 = m(x).clone()
+        g2 = m(x).clone()
+        ref = build()
+        ref.layer3[1].conv2.weight.data.mul_(0.5)
+        ref.conv1.weight.data.add_(0.01)
+        g_ref = ref(x)
+    torch.cuda.synchronize()
+    assert not torch.equal(g1, f[0])
+    assert torch.equal(g1, g_ref) and torch.equal(g2, g_ref)
+
+
 def test_simclr_alone():
     from oracle import procedural, sm3_oracle as O
     from src.models.simclr import SimCLR
