@@ -185,7 +185,7 @@ def linear_probe_bench(args):
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"tools/backbone_eval.py --finetune fc step, Baseline(resnet50 x2), batch {B}, {S}x{S}",
-                   "global_batch": B, "parallelism": "dp1", "loss": round(float(loss), 5)},
+                   "global_batch": B, "parallelism": "dp1", "loss": round(float(loss.detach()), 5)},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4), "traffic": None,
                      "kernel": "conv_igemm_kernel<bf16_t,128,128,2,2,*> with the conv+evalBN+ReLU epilogue"}}), flush=True)
@@ -476,7 +476,8 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}", "encoder_images_per_s": round(4 * pairs_per_s, 1),
                        "negatives": "global (all-gather)" if args.global_negatives else "local (reference)",
                        "extensions": {"metadata_dim": args.metadata_dim, "target_momentum": args.target_momentum},
-                       "loss": round(loss_val, 5)},
+                       "loss": round(loss_val, 5),
+                       "peak_hbm_allocated_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -161,6 +161,15 @@ def conv_partial_rows(desc):
     return _lib.load().sm3_conv_partial_rows(C.byref(desc))
 
 
+def _conv_tag(desc):
+    """Profiler class = the tile the library picks (csrc/conv_igemm.hip, conv_gather_gemm_impl): 128 x 64 for Co <= 64 and
+    for the small-M Linears whose 128-column grid would leave most CUs idle (those also take the 4-stage K-loop)."""
+    M = desc.N * desc.Ho * desc.Wo
+    nsteps = desc.ntaps * (desc.Ci * _sz(desc.dtype) // 128)
+    tiles128 = ((M + 127) // 128) * ((desc.Co + 127) // 128)
+    return "conv_gemm_128x64" if desc.Co <= 64 or (tiles128 <= 96 and nsteps >= 6) else "conv_gemm_128x128"
+
+
 def conv_gemm(desc, x, w, y, addend=None, partials=None):
     tdt = TORCH_DTYPE[desc.dtype]
     _chk(x, tdt, "x"); _chk(w, tdt, "w"); _chk(y, tdt, "y"); _chk(addend, tdt, "addend")
@@ -183,7 +192,7 @@ def conv_gemm(desc, x, w, y, addend=None, partials=None):
     sz = _sz(desc.dtype)
     nbytes = sz * (min(x.numel(), M * desc.ntaps * desc.Ci) + M * desc.Co * (2 if addend is not None else 1)
                    + desc.Co * desc.ntaps * desc.Ci)
-    tag = "conv_gemm_128x64" if desc.Co <= 64 else "conv_gemm_128x128"
+    tag = _conv_tag(desc)
     if _PROFILER is not None and getattr(_PROFILER, "detail", False):
         tag += f"|M{M}_K{desc.ntaps}x{desc.Ci}_N{desc.Co}_s{desc.osy}"
     with _prof(tag, flops, nbytes):
@@ -236,7 +245,7 @@ def conv_dgrad_bnfuse(desc, dy_in, w_dgrad, dz_out, addend, mask, bn_x, mean, in
     f.addend_sp_h, f.addend_sp_w = addend_sparse if addend_sparse is not None else (0, 0)
     M = desc.N * desc.Ho * desc.Wo
     sz = _sz(desc.dtype)
-    tag = "conv_gemm_128x64" if desc.Co <= 64 else "conv_gemm_128x128"
+    tag = _conv_tag(desc)
     if _PROFILER is not None and getattr(_PROFILER, "detail", False):
         tag += f"|M{M}_K{desc.ntaps}x{desc.Ci}_N{desc.Co}_s{desc.osy}_fz"
     with _prof(tag, 2.0 * M * desc.Co * desc.ntaps * desc.Ci,
@@ -262,7 +271,7 @@ def conv_bn_act_eval(desc, x, w, scale, shift, residual, relu, y):
         raise ValueError(f"Ci={desc.Ci} is not a multiple of {K_CHUNK[desc.dtype]}")
     M = desc.N * desc.Ho * desc.Wo
     sz = _sz(desc.dtype)
-    with _prof("conv_gemm_128x64" if desc.Co <= 64 else "conv_gemm_128x128", 2.0 * M * desc.Co * desc.ntaps * desc.Ci,
+    with _prof(_conv_tag(desc), 2.0 * M * desc.Co * desc.ntaps * desc.Ci,
                sz * (min(x.numel(), M * desc.ntaps * desc.Ci) + M * desc.Co * (2 if residual is not None else 1))):
         check(_lib.load().sm3_conv_bn_act_eval(C.byref(desc), _ptr(x), _ptr(w), _ptr(scale), _ptr(shift),
                                                _ptr(residual), int(relu), _ptr(y), _stream()), "sm3_conv_bn_act_eval")
@@ -287,7 +296,7 @@ def conv_bn_eval(desc, x, w, gamma, beta, running_mean, running_var, eps, residu
         raise ValueError(f"Ci={desc.Ci} is not a multiple of {K_CHUNK[desc.dtype]}")
     M = desc.N * desc.Ho * desc.Wo
     sz = _sz(desc.dtype)
-    with _prof("conv_gemm_128x64" if desc.Co <= 64 else "conv_gemm_128x128", 2.0 * M * desc.Co * desc.ntaps * desc.Ci,
+    with _prof(_conv_tag(desc), 2.0 * M * desc.Co * desc.ntaps * desc.Ci,
                sz * (min(x.numel(), M * desc.ntaps * desc.Ci) + M * desc.Co * (2 if residual is not None else 1))):
         check(_lib.load().sm3_conv_bn_eval(C.byref(desc), _ptr(x), _ptr(w), _ptr(gamma), _ptr(beta), _ptr(running_mean),
                                            _ptr(running_var), float(eps), _ptr(residual), int(relu), _ptr(y), _stream()),

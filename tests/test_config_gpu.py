@@ -1,8 +1,8 @@
 """Round-2 parity cases (GPU) on the configurations BASELINE.json names, through the C ABI:
 
-  * config 2 at its own size -- B = 256 pairs, 224x224, bf16, both views of a branch in one batch (the 2.47 GB
-    stem im2col tensor included): identical forward / running statistics to per-view passes, loss against the
-    exact-f32 mode on the same inputs, finite gradients;
+  * config 2 at its own size -- B = 256 pairs, 224x224, bf16, both views of a branch in one batch (512 images per
+    launch, the largest tensors of the path): identical forward / running statistics to per-view passes, loss against
+    the exact-f32 mode on the same inputs (which still goes through the 2.47 GB stem im2col tensor), finite gradients;
   * T2: bf16 vs exact-f32 at random init and from a trained state, with PyTorch's own bf16 autocast of
     the same network (CPU oracle) as the yardstick -- loss, logits, gradient direction;
   * the B = 32 golden generated from the reference itself (oracle/gen_golden.py b32): BatchNorm1d over 32 / 64
