@@ -371,6 +371,42 @@ def test_eval_mode_backward_through_an_encoder():
     assert int(m.state_dict()["bn1.num_batches_tracked"]) == 0
 
 
+def test_train_mode_encoder_gradients_with_torch_fp32_as_yardstick():
+    """How tight can train-mode (batch-statistics) gradients be pinned?  Through 53 BatchNorms at random init the
+    gradient of sum(f^2) is ill-conditioned for ANY fp32 arithmetic: PyTorch's own fp32 run of the oracle differs from
+    its fp64 run by 1.6 % (median over the 161 tensors) / 2.1 % (worst) at B = 16, 64x64, while the forward agrees to
+    3e-5.  The exact-f32 HIP path measures 0.9 % / 1.4 % -- fp64 statistics and f32 MFMA accumulation.  So the bound is
+    the yardstick: never further from fp64 than torch's fp32 is, tensor by tensor in aggregate, and the forward tight.
+    (The eval-mode twin of this test, frozen statistics, holds 2e-3 per tensor: test_eval_mode_backward_...)"""
+    from oracle import procedural, sm3_oracle as O
+    import resnet
+    B, S = 16, 64
+    state = procedural.make_state_dict(procedural.resnet50_spec(""), seed=23)
+    x = torch.from_numpy(procedural.make_images(B, S, 23, "derm0"))
+    grads = {}
+    for name, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        P, Bf = O.split_state(state, dt)
+        f = O.resnet50_features(x.to(dt), P, Bf, "", True)
+        (f ** 2).sum().backward()
+        grads[name] = {k: v.grad.double() for k, v in P.items()}
+        if name == "f64":
+            f_ref = f.detach()
+    m = resnet.resnet50(weights=None)
+    m.fc = torch.nn.Identity()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    m.sm3_dtype = torch.float32
+    m.to(DEV).train()
+    f = m(x.to(DEV))
+    (f.double() ** 2).sum().backward()
+    torch.cuda.synchronize()
+    assert float((f.detach().cpu().double() - f_ref).norm() / f_ref.norm()) < 2e-4
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+    hip = sorted(rel(p.grad.double().cpu(), grads["f64"][k]) for k, p in m.named_parameters())
+    tch = sorted(rel(grads["f32"][k], grads["f64"][k]) for k in grads["f64"])
+    assert hip[len(hip) // 2] <= 1.25 * tch[len(tch) // 2] + 1e-3, (hip[len(hip) // 2], tch[len(tch) // 2])
+    assert hip[-1] <= 1.5 * tch[-1] + 1e-3, (hip[-1], tch[-1])
+
+
 def test_fp16_mode_with_dynamic_loss_scaling():
     """The reference's own AMP recipe (fp16 autocast + GradScaler, tools/backbone_train.py:27,98,125-127,480) as an
     arithmetic mode of the engine: fp16 storage + f16 MFMA, loss scaling with GradScaler's state on the device.
