@@ -106,6 +106,39 @@ def test_config2_b256_224_bf16():
             assert float(d) < 2e-2, (k, float(d))
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_b512_both_views_one_batch(dt):
+    """B = 512 pairs per GPU: 1 024 images per launch, activation tensors up to 1.6 GB.  Possible in the one-batch mode only
+    since the stem reads the images directly (the 2B-image im2col matrix would pass the 3 GB buffer-offset limit); equal
+    to the per-view passes (running statistics bit for bit, loss to the order of the float-atomic loss terms)."""
+    from sm3hip.trainer import SM3Trainer
+    B, S = 512, 224
+    g = torch.Generator(device=DEV).manual_seed(11)
+    derm = [torch.randn(B, 3, S, S, device=DEV, generator=g) for _ in range(2)]
+    clinic = [torch.randn(B, 3, S, S, device=DEV, generator=g) for _ in range(2)]
+    torch.manual_seed(11)
+    from src.models.simclr import SimCLRSkinV32
+    init = {k: v.clone() for k, v in SimCLRSkinV32("resnet50", None, 128, 0.1).state_dict().items()}
+    runs = {}
+    for pair in (True, False):
+        model = _build(0, dt, init)
+        tr = SM3Trainer(model, lr=1e-6, weight_decay=5e-2, eps=1e-5, style=0)
+        eng = tr._engine()
+        assert eng.pair_ok(B, S, S)
+        eng.pair_views = pair
+        loss = float(tr.step(derm, clinic))
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(eng.store.flat_g).all())
+        runs[pair] = (loss, float(eng.store.flat_g.double().norm()),
+                      {k: v.clone() for k, v in model.state_dict().items() if "running" in k})
+        del tr, eng, model
+        torch.cuda.empty_cache()
+    assert abs(runs[True][0] - runs[False][0]) < 1e-5, (runs[True][0], runs[False][0])
+    for k, v in runs[True][2].items():
+        assert torch.equal(v, runs[False][2][k]), k
+    assert abs(runs[True][1] - runs[False][1]) < 2e-3 * runs[False][1]
+
+
 def _flat(grads, names):
     return torch.cat([grads[k].detach().double().cpu().flatten() for k in names])
 
