@@ -35,7 +35,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     // general epilogue: one wave-row (WTM rows) of the tile at a time in f32; lean epilogue: the whole tile in bf16
     constexpr int LEAN_PITCH = BN * 2 + 16;  // bytes; +16 puts rows r and r+4 (the lane halves of a C register) on different banks
-    constexpr int C_BYTES = LEAN ? BM * LEAN_PITCH : WTM * BN * 4;
+    // general epilogue staging: rows of BN floats + 4 (16 B): the 16-byte read-back of 16 lanes x 32 B per row no longer
+    // puts channel vectors cc and cc + 8 of neighbouring rows on the same banks (29 % LDS conflict cycles measured)
+    constexpr int CP = BN + 4;
+    constexpr int C_BYTES = LEAN ? BM * LEAN_PITCH : WTM * CP * 4;
     constexpr int MAIN_BYTES = (STAGES * STAGE > C_BYTES) ? STAGES * STAGE : C_BYTES;
     static_assert(AI >= 1 && BI >= 1 && TM >= 1 && TN >= 1, "tile too small");
 
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
                     for (int r = 0; r < 16; ++r) {
                         const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                         const int col = wn * WTN + j * 32 + frow;
-                        sC[row * BN + col] = acc[i][j][r];
+                        sC[row * CP + col] = acc[i][j][r];
                     }
         }
         __syncthreads();
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
             float v[EPC];
 #pragma unroll
             for (int e = 0; e < EPC; e += 4) {
-                const float4 q = *reinterpret_cast<const float4*>(&sC[r * BN + cc * EPC + e]);
+                const float4 q = *reinterpret_cast<const float4*>(&sC[r * CP + cc * EPC + e]);
                 v[e] = q.x;
                 v[e + 1] = q.y;
                 v[e + 2] = q.z;
@@ -476,7 +479,7 @@ template <typename T, int BM, int BN, int WM, int WN, int STAGES, bool LEAN>
 int launch_conv_st(const ConvParams& p0, hipStream_t st) {
     ConvParams p = p0;
     constexpr int STAGE = (BM + BN) * 128;
-    constexpr int C_BYTES = LEAN ? BM * (BN * 2 + 16) : (BM / WM) * BN * 4;
+    constexpr int C_BYTES = LEAN ? BM * (BN * 2 + 16) : (BM / WM) * (BN + 4) * 4;
     constexpr int MAIN = (STAGES * STAGE > C_BYTES) ? STAGES * STAGE : C_BYTES;
     constexpr int LDS = MAIN + WM * BN * 2 * 4;
     static_assert(LEAN || MAIN >= 256 * 2 * 8 * 4, "reduction scratch of the fused BN-backward epilogue must fit");
