@@ -81,20 +81,25 @@ __device__ __forceinline__ void store_patch(float* patch, const PatchRegs& r) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const uint4* __restrict__ w,
+__global__ __launch_bounds__(256, 3) void stem_fwd_kernel(const float* __restrict__ x, const uint4* __restrict__ w,
                                                        T* __restrict__ y, float* __restrict__ partials, int N,
                                                        int H, int W, int Ho, int Wo, int xblocks, long tiles) {
     __shared__ __attribute__((aligned(16))) float patch[NG * PW];  // reused as the bf16 output tile
     __shared__ float sStat[4][64][2];
+    // The filter bank (64 x 176 values, 22.5 KB) lives in LDS for the whole (persistent) workgroup: as 88 registers per
+    // lane it held the kernel at 184 VGPRs = two workgroups per CU, and the tile loop is bound by the latency of its
+    // one-tile-ahead patch loads.  Row pitch 184 values (368 B): the 16 rows of a ds_read_b128 group fall on 16
+    // different 16-byte bank slots.
+    constexpr int WP = KPAD + 8;
+    __shared__ __attribute__((aligned(16))) uint16_t sW[64 * WP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, h = lane >> 5;
-
-    // filter bank fragments: lane (col, h) holds w[nb*32 + col][ks*16 + 8h .. +8) for every (ks, nb)
-    uint4 bfrag[KS][2];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) bfrag[ks][nb] = w[((nb * 32 + col) * KPAD + ks * 16 + 8 * h) / 8];
+    for (int i = tid; i < 64 * (KPAD / 8); i += 256) {
+        const int co = i / (KPAD / 8), c8 = i - co * (KPAD / 8);
+        *reinterpret_cast<uint4*>(&sW[co * WP + c8 * 8]) = w[i];
+    }
+    // lane (col, h) reads w[nb*32 + col][ks*16 + 8h .. +8) for every (ks, nb)
+    const uint16_t* wlane = &sW[col * WP + 8 * h];
 
     PatchRegs pre;
     if ((long)blockIdx.x < tiles) {
@@ -122,7 +127,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
                 a = make_uint4(pack2<T>(v0.x, v0.y), pack2<T>(v1.x, v1.y), pack2<T>(v2.x, v2.y), pack2<T>(v3.x, v3.y));
             }
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) sm3conv::mma_frag<T>(a, bfrag[ks][nb], acc[nb]);
+            for (int nb = 0; nb < 2; ++nb)
+                sm3conv::mma_frag<T>(a, *reinterpret_cast<const uint4*>(wlane + nb * 32 * WP + ks * 16), acc[nb]);
         }
         __syncthreads();  // everyone is done reading the patch: its LDS becomes the output tile
         char* sOut = reinterpret_cast<char*>(patch);
@@ -186,7 +192,7 @@ struct StemWgradParams {
 __device__ __forceinline__ uint32_t swz128(int row) { return (uint32_t)((row >> 1) & 1) << 6; }
 
 template <typename T>
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradParams p) {
+__global__ __launch_bounds__(256, 3) void stem_wgrad_kernel(const StemWgradParams p) {
     __shared__ __attribute__((aligned(16))) float patch[NG * PW];
     __shared__ __attribute__((aligned(16))) char sD[128 * 128];  // dxo tile [pixel][64 co] bf16, swizzled for tr reads
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -207,7 +213,9 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradParams p
 
     // staging role: 16-byte channel vector ch of rows r0 + 32k
     const int ch = tid & 7, r0 = tid >> 3;
-    float mu[8], k0[8], k1[8], q[8];
+    // per-channel coefficients of the fused BN-backward apply, [A | B | C][64], refreshed when the view changes
+    // (kept in LDS: as 32 registers per lane they helped pin the kernel at two workgroups per CU)
+    __shared__ __attribute__((aligned(16))) float sCoef[3][64];
     int cur_view = -1;
 
     // transposing-read addressing of the dxo tile (as conv_wgrad.hip): 16-lane group g16 reads a 4(k) x 16(co) block
@@ -217,48 +225,62 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradParams p
     const int bn = lane & 31, bh = lane >> 5;
 
     // operand loads of a tile: its patch and the (dz, xo) rows of this thread's channel vector
+    // Only the patch is prefetched across the MFMA loop; the (dz, xo) vectors are fetched when the tile is staged.  Holding
+    // them too (32 more registers) pinned the kernel at two workgroups per CU; with three, the other workgroups cover
+    // that fetch.
     PatchRegs pre;
-    uint4 gu[4], xu[4];
-    auto load_tile = [&](const StemTile& tl) {
-        const long pix0 = ((long)tl.n * p.Ho + tl.oy) * p.Wo + tl.x0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int row = r0 + 32 * k;
-            const bool ok = tl.x0 + row < p.Wo;
-            gu[k] = ok ? ldg16<true>(p.dz + ((pix0 + row) * 64 + ch * 8) * 2) : make_uint4(0, 0, 0, 0);
-            xu[k] = ok ? ldg16<true>(p.xo + ((pix0 + row) * 64 + ch * 8) * 2) : make_uint4(0, 0, 0, 0);
-        }
-        load_patch(pre, p.x, tl, p.H, p.W);
-    };
+    auto load_tile = [&](const StemTile& tl) { load_patch(pre, p.x, tl, p.H, p.W); };
     auto store_tile = [&](const StemTile& tl) {
         const int view = tl.n / p.n_per_view;
-        if (view != cur_view) {  // tiles are view-major: happens once or twice per workgroup
+        if (view != cur_view) {  // tiles are view-major: happens once or twice per workgroup (block-uniform branch)
             cur_view = view;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int c = ch * 8 + e;
-                mu[e] = p.mean[view * 64 + c];
+            if (tid < 64) {
+                // dx = k0*(dz - k1) - (x - mu)*q  =  A*dz - B*x + C   with A = k0, B = q, C = q*mu - k0*k1
+                const int c = tid;
                 const float is = p.invstd[view * 64 + c];
                 const float g = p.gamma ? p.gamma[c] : 1.f;
-                k0[e] = g * is;
-                k1[e] = (float)(p.gsums[view * 128 + c] * p.inv_count);
-                q[e] = k0[e] * is * (float)(p.gsums[view * 128 + 64 + c] * p.inv_count);
+                const float k0c = g * is;
+                const float k1c = (float)(p.gsums[view * 128 + c] * p.inv_count);
+                const float qc = k0c * is * (float)(p.gsums[view * 128 + 64 + c] * p.inv_count);
+                sCoef[0][c] = k0c;
+                sCoef[1][c] = qc;
+                sCoef[2][c] = qc * p.mean[view * 64 + c] - k0c * k1c;
             }
+            __syncthreads();
         }
         store_patch(patch, pre);
+        float cA[8], cB[8], cC[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int row = r0 + 32 * k;
-            uint4 out = make_uint4(0, 0, 0, 0);
-            if (tl.x0 + row < p.Wo) {
-                float g[8], xv[8];
-                unpack16<T>(gu[k], g);
-                unpack16<T>(xu[k], xv);
+        for (int e = 0; e < 8; e += 4) {
+            *reinterpret_cast<float4*>(cA + e) = *reinterpret_cast<const float4*>(&sCoef[0][ch * 8 + e]);
+            *reinterpret_cast<float4*>(cB + e) = *reinterpret_cast<const float4*>(&sCoef[1][ch * 8 + e]);
+            *reinterpret_cast<float4*>(cC + e) = *reinterpret_cast<const float4*>(&sCoef[2][ch * 8 + e]);
+        }
+        const long pix0 = ((long)tl.n * p.Ho + tl.oy) * p.Wo + tl.x0;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) g[e] = k0[e] * (g[e] - k1[e]) - (xv[e] - mu[e]) * q[e];
-                out = pack16<T>(g);
+        for (int kb = 0; kb < 4; kb += 2) {  // two rows of this thread's channel vector at a time (register budget)
+            uint4 gu[2], xu[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int row = r0 + 32 * (kb + k);
+                const bool ok = tl.x0 + row < p.Wo;
+                gu[k] = ok ? ldg16<true>(p.dz + ((pix0 + row) * 64 + ch * 8) * 2) : make_uint4(0, 0, 0, 0);
+                xu[k] = ok ? ldg16<true>(p.xo + ((pix0 + row) * 64 + ch * 8) * 2) : make_uint4(0, 0, 0, 0);
             }
-            *reinterpret_cast<uint4*>(sD + row * 128 + (((uint32_t)ch * 16u) ^ swz128(row))) = out;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int row = r0 + 32 * (kb + k);
+                uint4 out = make_uint4(0, 0, 0, 0);
+                if (tl.x0 + row < p.Wo) {
+                    float g[8], xv[8];
+                    unpack16<T>(gu[k], g);
+                    unpack16<T>(xu[k], xv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) g[e] = cA[e] * g[e] - cB[e] * xv[e] + cC[e];
+                    out = pack16<T>(g);
+                }
+                *reinterpret_cast<uint4*>(sD + row * 128 + (((uint32_t)ch * 16u) ^ swz128(row))) = out;
+            }
         }
     };
     if ((long)blockIdx.x < p.tiles) {
