@@ -269,50 +269,77 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_kernel(const uint8_t* __re
             mu[e] = mean[view * C + cv * E + e];
             is[e] = invstd[view * C + cv * E + e];
         }
+        // U = 2 rows per thread in flight: every load of both rows (the pre-BN vector and up to four (argmax, dy) pairs
+        // each, a chain of dependent address arithmetic otherwise) is issued before the first use -- with one row per
+        // iteration the kernel ran at the latency of that chain (3.6 TB/s).
+        constexpr int U = 2;
         const int64_t rstep = (int64_t)gridDim.y * tby;
-        for (int64_t r = (int64_t)blockIdx.y * tby + ty; r < rows; r += rstep) {
-            const uint32_t nl = fdiv((uint32_t)r, div_hw);
-            const uint32_t rem = (uint32_t)r - nl * div_hw.d;
-            const int iy = (int)fdiv(rem, div_w), ix = (int)(rem - (uint32_t)iy * div_w.d);
-            const int64_t n = (int64_t)view * n_per_view + nl;
-            const int64_t pix = (int64_t)view * rows + r;
-            const uint4 xu = ldg16<true>(x + pix * C + (int64_t)cv * E);
-            float g[E];
+        for (int64_t r0 = (int64_t)blockIdx.y * tby + ty; r0 < rows; r0 += U * rstep) {
+            uint4 xu[U], du[U][4];
+            unsigned au[U][4][2];
+            int selfs[U][4];
+            int64_t pixs[U];
 #pragma unroll
-            for (int e = 0; e < E; ++e) g[e] = 0.f;
-            const int oy_lo = iy / 2, oy_hi = min(Ho - 1, (iy + 1) / 2);
-            const int ox_lo = ix / 2, ox_hi = min(Wo - 1, (ix + 1) / 2);
-            for (int oy = oy_lo; oy <= oy_hi; ++oy)
-                for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-                    const int self = (iy - (oy * 2 - 1)) * 3 + (ix - (ox * 2 - 1));
+            for (int u = 0; u < U; ++u) {
+                const int64_t r = r0 + u * rstep;
+                pixs[u] = -1;
+                xu[u] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) selfs[u][w] = -1;
+                if (r >= rows) continue;
+                const uint32_t nl = fdiv((uint32_t)r, div_hw);
+                const uint32_t rem = (uint32_t)r - nl * div_hw.d;
+                const int iy = (int)fdiv(rem, div_w), ix = (int)(rem - (uint32_t)iy * div_w.d);
+                const int64_t n = (int64_t)view * n_per_view + nl;
+                pixs[u] = (int64_t)view * rows + r;
+                xu[u] = ldg16<true>(x + pixs[u] * C + (int64_t)cv * E);
+                const int oy_lo = iy / 2, oy_hi = min(Ho - 1, (iy + 1) / 2);
+                const int ox_lo = ix / 2, ox_hi = min(Wo - 1, (ix + 1) / 2);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {  // the (at most) 2 x 2 pooling windows that contain this input pixel
+                    const int oy = oy_lo + (w >> 1), ox = ox_lo + (w & 1);
+                    if (oy > oy_hi || ox > ox_hi) continue;
+                    selfs[u][w] = (iy - (oy * 2 - 1)) * 3 + (ix - (ox * 2 - 1));
                     const int64_t o = ((n * Ho + oy) * Wo + ox) * C + (int64_t)cv * E;
-                    unsigned a[2];
                     if constexpr (E == 8) {
                         const uint2 q = *reinterpret_cast<const uint2*>(argmax + o);
-                        a[0] = q.x;
-                        a[1] = q.y;
+                        au[u][w][0] = q.x;
+                        au[u][w][1] = q.y;
                     } else {
-                        a[0] = *reinterpret_cast<const unsigned*>(argmax + o);
-                        a[1] = 0;
+                        au[u][w][0] = *reinterpret_cast<const unsigned*>(argmax + o);
+                        au[u][w][1] = 0;
                     }
+                    du[u][w] = *reinterpret_cast<const uint4*>(dy + o);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (pixs[u] < 0) continue;
+                float g[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) g[e] = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    if (selfs[u][w] < 0) continue;
                     float d[E];
-                    unpack16<T>(*reinterpret_cast<const uint4*>(dy + o), d);
+                    unpack16<T>(du[u][w], d);
 #pragma unroll
                     for (int e = 0; e < E; ++e)
-                        if ((int)((a[e >> 2] >> (8 * (e & 3))) & 0xff) == self) g[e] += d[e];
+                        if ((int)((au[u][w][e >> 2] >> (8 * (e & 3))) & 0xff) == selfs[u][w]) g[e] += d[e];
                 }
-            float xv[E];
-            unpack16<T>(xu, xv);
+                float xv[E];
+                unpack16<T>(xu[u], xv);
 #pragma unroll
-            for (int e = 0; e < E; ++e) g[e] = (xv[e] * sc[e] + sh[e] > 0.f) ? g[e] : 0.f;
-            const uint4 packed = pack16<T>(g);
-            stg16<true>(dz + pix * C + (int64_t)cv * E, packed);
-            float gr[E];
-            unpack16<T>(packed, gr);  // sums of the STORED (rounded) dz: what the apply pass will read
+                for (int e = 0; e < E; ++e) g[e] = (xv[e] * sc[e] + sh[e] > 0.f) ? g[e] : 0.f;
+                const uint4 packed = pack16<T>(g);
+                stg16<true>(dz + pixs[u] * C + (int64_t)cv * E, packed);
+                float gr[E];
+                unpack16<T>(packed, gr);  // sums of the STORED (rounded) dz: what the apply pass will read
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                s1[e] += gr[e];
-                s2[e] += gr[e] * (xv[e] - mu[e]) * is[e];
+                for (int e = 0; e < E; ++e) {
+                    s1[e] += gr[e];
+                    s2[e] += gr[e] * (xv[e] - mu[e]) * is[e];
+                }
             }
         }
     }
