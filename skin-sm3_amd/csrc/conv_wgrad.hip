@@ -54,8 +54,11 @@ __device__ __forceinline__ uint32_t swz_bytes(int row) {
 
 // DENSE: 1x1 / stride 1 / no offset forward conv (X row of output pixel m is simply row m): every DMA offset is
 // a per-lane constant plus a scalar that advances by one K-step -- no VALU at all in the loop.
-template <typename T, int BMW, int BNW, int KP, bool DENSE, int NST>  // KP = pixels per K-step, NST = LDS stages
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+// KG = 2: two groups of 4 waves share a workgroup, each walks half of the workgroup's pixel slice with its own LDS ring
+// and accumulators; group 1 hands its tile to group 0 through LDS and ONE set of f32 atomics leaves the workgroup --
+// the same waves per CU as two 4-wave workgroups at half the atomic traffic (the 1x1 layers paid 20 % for atomics).
+template <typename T, int BMW, int BNW, int KP, bool DENSE, int NST, int KG = 1>  // KP = pixels per K-step, NST = LDS stages
+__global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int SZ = sizeof(T);
     constexpr bool kBf16 = (SZ == 2);
     constexpr int RA = BMW * SZ, RB = BNW * SZ;                 // bytes per tile row (one pixel)
@@ -67,7 +70,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_all & 3, grp = wave_all >> 2;  // role inside the group of 4 waves; K-group
     const int wm = wave >> 1, wn = wave & 1;
 
     // Block -> (tile, pixel slice).  Workgroups are dealt round-robin over the 8 XCDs, so id & 7 labels the
@@ -90,9 +94,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     const int tap = bx % p.ntaps;
     const int tco = bx / p.ntaps;
     const int co0 = tco * BMW, ci0 = tci * BNW;
-    const int kbeg = slice * p.k_per_split;
-    const int kend = min(p.M, kbeg + p.k_per_split);
-    if (kbeg >= kend) return;
+    const int kbeg0 = slice * p.k_per_split;
+    const int kend = min(p.M, kbeg0 + p.k_per_split);
+    if (kbeg0 >= kend) return;
+    // K-steps per group (both groups run the same number: rows past kend read as zero), and this group's first pixel
+    const int nsteps = ((kend - kbeg0 + KP - 1) / KP + KG - 1) / KG;
+    const int kbeg = kbeg0 + grp * nsteps * KP;
     const int ddy = p.dyt[tap], ddx = p.dxt[tap];
 
     // descriptors: dY rows end at kend (rows of the next slice must read as zero); X is the whole tensor
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
 
     auto dma_stage = [&](int stage, int step) {
-        const uint32_t sA = smem_lds + (uint32_t)(stage * STAGE) + (uint32_t)wave * 1024u;
+        const uint32_t sA = smem_lds + (uint32_t)((grp * NST + stage) * STAGE) + (uint32_t)wave * 1024u;
         const uint32_t sB = sA + A_BYTES;
         const uint32_t soff_a = (uint32_t)(step * KP) * (uint32_t)(p.Co * SZ);
 #pragma unroll
@@ -208,7 +215,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     // Ring of NST stages, NST - 1 of them in flight: a K-step's MFMAs (0.1-0.25 us) are far shorter than the round
     // trip of its DMA, so with one stage in flight (NST = 2) the loop runs at the DMA latency; each step waits (counted
     // vmcnt) only for its own stage and passes one barrier.
-    const int nsteps = (kend - kbeg + KP - 1) / KP;
     constexpr int PER = AI + BI;  // DMA instructions per stage per wave
     static_assert(NST >= 2 && NST <= 4 && 2 * PER <= 63, "vmcnt immediates below cover NST <= 4");
     for (int s = 0; s < NST - 1 && s < nsteps; ++s) dma_stage(s, s);
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         else dma_drain();
         __syncthreads();  // stage s has landed for everyone; everyone is done computing stage s - 1
         if (s + NST - 1 < nsteps) dma_stage((s + NST - 1) % NST, s + NST - 1);
-        const char* sS = smem + (s % NST) * STAGE;
+        const char* sS = smem + (grp * NST + s % NST) * STAGE;
         if constexpr (kBf16) {
 #pragma unroll
             for (int ks = 0; ks < KP / 16; ++ks) {
@@ -266,6 +272,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         }
     }
 
+    if constexpr (KG == 2) {
+        static_assert(NST * STAGE >= BMW * BNW * 4, "group 1's tile must fit its own stage ring");
+        __syncthreads();  // both groups are done with their rings
+        float* xch = reinterpret_cast<float*>(smem + NST * STAGE);  // group 1's ring: [wave][register][lane]
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xch[((wave * TM * TN + i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += xch[((wave * TM * TN + i * TN + j) * 16 + r) * 64 + lane];
+    }
     const int frow = lane & 31, fh = lane >> 5;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -299,17 +326,17 @@ static int cus_per_xcd() {
     return v;
 }
 
-template <typename T, int BMW, int BNW, int KP, bool DENSE, int NST>
+template <typename T, int BMW, int BNW, int KP, bool DENSE, int NST, int KG = 1>
 int launch_wgrad_kp(WgradParams p, hipStream_t st) {
     constexpr int SZ = sizeof(T);
-    constexpr int LDS = NST * KP * (BMW * SZ + BNW * SZ);
+    constexpr int LDS = KG * NST * KP * (BMW * SZ + BNW * SZ);
     p.tilesCo = (p.Co + BMW - 1) / BMW;
     p.tilesCi = (p.Ci + BNW - 1) / BNW;
     p.adv_n = KP / p.HoWo;
     p.adv_oy = (KP % p.HoWo) / p.Wo;
     p.adv_ox = (KP % p.HoWo) % p.Wo;
     const long gx = (long)p.tilesCo * p.ntaps * p.tilesCi;
-    auto kern = conv_wgrad_kernel<T, BMW, BNW, KP, DENSE, NST>;
+    auto kern = conv_wgrad_kernel<T, BMW, BNW, KP, DENSE, NST, KG>;
     static int per_cu = 0;  // resident workgroups per CU
     if (!per_cu) {
         if (LDS > 65536) {
@@ -318,7 +345,7 @@ int launch_wgrad_kp(WgradParams p, hipStream_t st) {
             if (e != hipSuccess) return (int)e;
         }
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, LDS) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256 * KG, LDS) != hipSuccess || n < 1) n = 1;
         per_cu = n;
     }
     // Split the pixel axis so that the launch is ONE full wave of workgroups: every XCD holds whole pixel slices (all
@@ -333,7 +360,7 @@ int launch_wgrad_kp(WgradParams p, hipStream_t st) {
     if (target > 0) splits = (target + gx - 1) / gx;
     else if (gx <= slots_xcd) splits = 8 * (slots_xcd / gx);
     else splits = 8 * slots_xcd / gx;  // < 8 slices: tiles go round-robin over the XCDs (see the kernel)
-    const long max_splits = (p.M + KP * 8 - 1) / (KP * 8);
+    const long max_splits = (p.M + KP * 8 * KG - 1) / (KP * 8 * KG);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     long kps = (p.M + splits - 1) / splits;
@@ -344,7 +371,7 @@ int launch_wgrad_kp(WgradParams p, hipStream_t st) {
     p.splits = (int)splits;
     const long nblocks = gx * (splits >= 8 ? (splits + 7) / 8 * 8 : splits);
     if (gx > 0x7fffffffL || nblocks > 0x7fffffffL) return SM3_EINVAL;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), LDS, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256 * KG), LDS, st, p);
     SM3_CHECK_LAUNCH();
     return 0;
 }
@@ -357,7 +384,11 @@ int launch_wgrad(WgradParams p, hipStream_t st) {
     constexpr int KP = sizeof(T) == 2 ? 32 : 16;
     const bool dense = p.ntaps == 1 && p.sy == 1 && p.sx == 1 && p.dyt[0] == 0 && p.dxt[0] == 0 &&
                        p.HoWo == p.Hi * p.Wi;
-    if (dense) return launch_wgrad_kp<T, BMW, BNW, KP, true, 4>(p, st);
+    if (dense) {
+        static const bool kg2 = !(getenv("SM3_WGRAD_KG") && atoi(getenv("SM3_WGRAD_KG")) == 1);
+        if (kg2) return launch_wgrad_kp<T, BMW, BNW, KP, true, 4, 2>(p, st);
+        return launch_wgrad_kp<T, BMW, BNW, KP, true, 4>(p, st);
+    }
     return launch_wgrad_kp<T, BMW, BNW, KP, false, 2>(p, st);
 }
 
