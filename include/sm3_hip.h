@@ -92,6 +92,27 @@ typedef struct sm3_bn_bwd_fuse {
 } sm3_bn_bwd_fuse;
 int sm3_conv_dgrad_bnfuse(const sm3_conv_desc* d, const void* dy_in, const void* w_dgrad, void* dz_out,
                           const void* addend, const sm3_bn_bwd_fuse* fuse, void* stream);
+/* fuse->x == NULL (with mean / invstd then unused): the epilogue applies the ReLU mask and sums dz only -- the
+ * sum(dz * xhat) slot of every partial row is written as 0.  For a producer BatchNorm whose backward goes through
+ * sm3_linbn_stats, which derives that sum from the weight-gradient product instead of a read of x. */
+
+/* The same launch over TWO K segments: dz_out = mask( x0 w0^T + x1 w1^T + col_bias (+ addend) ), for a 1x1 / stride-1
+ * descriptor d (x0: [pixels][d->Ci], w0: [d->Co][d->w_row_stride]) and a second operand pair over the same pixels.
+ * With x0 = dz of an expanding conv's BatchNorm, w0 = diag(a) W, x1 = that conv's input, w1 = -H, col_bias = const
+ * (sm3_linbn_coeffs, sm3_conv_gather_gemm) this is the data gradient of conv -> BatchNorm with the BatchNorm-backward
+ * apply pass folded into the GEMM by linearity (see "BatchNorm backward by linearity" below).  16-bit dtypes only.
+ * Two views in one launch (fuse->views == 2): view 1's tiles read w0 + w_view_stride, w1 + w1_view_stride (elements)
+ * and col_bias + Co. */
+typedef struct sm3_conv_seg {
+    const void* x1;            /* [pixels][Ci1] */
+    const void* w1;            /* [views][Co][Ci1] */
+    int32_t Ci1;               /* multiple of 64 */
+    int64_t w_view_stride;     /* elements between the views' w0 banks (0: shared) */
+    int64_t w1_view_stride;
+    const float* col_bias;     /* [views][Co], nullable */
+} sm3_conv_seg;
+int sm3_conv_dgrad_seg_bnfuse(const sm3_conv_desc* d, const void* x0, const void* w0, const sm3_conv_seg* seg,
+                              void* dz_out, const void* addend, const sm3_bn_bwd_fuse* fuse, void* stream);
 
 /* Inference: conv + eval-mode BatchNorm (+ residual) (+ ReLU) in one launch,
  *   y = relu?( conv(x, w) * scale[co] + shift[co] (+ residual) ),
@@ -113,6 +134,12 @@ int sm3_conv_bn_eval(const sm3_conv_desc* d, const void* x, const void* w, const
  * dy is dense [N*Ho*Wo, Co]; dw is fp32 and is accumulated into (float atomics, split over pixels).
  * Columns wtap[t]*Ci+ci >= w_row_stride are dropped (the zero-padded K tail of the stem im2col). */
 int sm3_conv_wgrad(const sm3_conv_desc* d, const void* x, const void* dy, float* dw, void* stream);
+/* The same product with dY the channel concatenation [dy (d->Co) | dy1 (Co1)] of two tensors over the same pixels (rows
+ * of the second part accumulate into dw1, same row layout), over `views` equal pixel ranges that accumulate into
+ * dw + v * dw_view_stride / dw1 + v * dw1_view_stride: with dy = dz, dy1 = x = the convolution's input this gives
+ * P = dz^T x and the Gram matrix G = x^T x per view in ONE launch that reads dz once.  d->Co a multiple of 128. */
+int sm3_conv_wgrad_cat(const sm3_conv_desc* d, const void* x, const void* dy, float* dw, const void* dy1, int Co1,
+                       float* dw1, int views, int64_t dw_view_stride, int64_t dw1_view_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm (2d and 1d: rows x C), train and eval.  replaces nn.BatchNorm2d/1d (+SyncBatchNorm,
@@ -149,6 +176,12 @@ int sm3_bn_eval_scale_shift(const float* gamma, const float* beta, const float* 
  * replaces the bn->relu / bn->add->relu chains of Bottleneck.forward (resnet.py:154-174). */
 int sm3_bn_act(int dtype, const void* x, const float* scale, const float* shift, const void* residual,
                int relu, int out_f32, void* y, uint8_t* relu_mask, int64_t rows, int C, int views, void* stream);
+/* sm3_bn_act (16-bit or f32 storage, no fp32 output) that also leaves per-block column sums of the stored outputs:
+ * colsum_partials [views][sm3_bn_act_colsum_rows(rows, C, dtype, views)][C] fp32 -- the first moment of a convolution
+ * input, summed by sm3_linbn_stats. */
+int sm3_bn_act_colsum_rows(int64_t rows, int C, int dtype, int views);
+int sm3_bn_act_colsum(int dtype, const void* x, const float* scale, const float* shift, const void* residual, int relu,
+                      void* y, uint8_t* relu_mask, float* colsum_partials, int64_t rows, int C, int views, void* stream);
 /* The join of a Bottleneck with a downsample branch in ONE pass (resnet.py:164-172: out = bn3(conv3); identity =
  * downsample(x) [conv + BatchNorm]; out += identity; relu):  y = [relu]( x*scale + shift + x2*scale2 + shift2 ),
  * x2 the pre-BatchNorm output of the downsample convolution, scale2/shift2 [views][C] from its sm3_bn_finalize.
@@ -185,6 +218,33 @@ typedef struct sm3_bn_apply_side {
 } sm3_bn_apply_side;
 int sm3_bn_bwd_apply2(int dtype, const void* dz, double count, const sm3_bn_apply_side* a,
                       const sm3_bn_apply_side* b, int64_t rows, int C, int views, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm backward by linearity, for an expanding 1x1 convolution followed by train-mode BatchNorm (Bottleneck
+ * conv3 -> bn3: resnet.py:162-163 and their autograd backward; 16-bit dtypes).  With x = y W^T (y: [M, p] conv input,
+ * W: [C, p]) and dx = a (dz - m1) - b (x - mu) [a = gamma invstd, b = a invstd mean(dz xhat), m1 = mean(dz)]:
+ *   P = dz^T y, G = y^T y (sm3_conv_wgrad_cat), s = sum_m y (sm3_bn_act_colsum)
+ *   sum_m dz xhat = invstd (rowdot(W, P) - mu sum_m dz)                                  (sm3_linbn_stats)
+ *   dy = dz (diag(a) W) - y H + const, H = W^T diag(b) W          (sm3_linbn_coeffs, sm3_conv_gather_gemm for H,
+ *                                                                   sm3_conv_dgrad_seg_bnfuse)
+ *   dW += diag(a)(P - m1 s^T) - diag(b)(W G - mu s^T)             (sm3_conv_gather_gemm in SM3_F32 for W G,
+ *                                                                   sm3_linbn_wgrad_finish)
+ * so sm3_bn_bwd_apply's pass over dz / x / dx (and every backward read of x) is never made.  All per-channel vectors
+ * are [views][C].
+ * ------------------------------------------------------------------------------------------ */
+/* lsums: [views][2C] fp64 with sum(dz) in [0, C) on entry; [C, 2C) is written.  P: [views][C][p] fp32; w_fwd: dtype
+ * [C][p]; colsum_partials: [views][colsum_rows][p]; s_out: [views][p] fp32. */
+int sm3_linbn_stats(int dtype, const float* P, const void* w_fwd, const float* mean, const float* invstd, double* lsums,
+                    const float* colsum_partials, int colsum_rows, float* s_out, int C, int p, int views, void* stream);
+/* From the (all-reduced) sums: wa = diag(a) W and wbn = -diag(b) W in data-gradient order (dtype [views][p][C], from
+ * w_dgrad [p][C]), col_const [views][p] = (b mu - a m1) W, coef [views][4][C] = (a, b, m1, mu);
+ * dgamma += local sum(dz xhat), dbeta += local sum(dz) (NULL to skip).  count: elements per channel of one view. */
+int sm3_linbn_coeffs(int dtype, const void* w_dgrad, const float* gamma, const float* mean, const float* invstd,
+                     const double* global_sums, double count, const double* local_sums, float* dgamma, float* dbeta,
+                     void* wa, void* wbn, float* col_const, float* coef, int C, int p, int views, void* stream);
+/* dw[C][p] += sum_v diag(a_v)(P_v - m1_v s_v^T) - diag(b_v)(Tm[:, v p : (v+1) p] - mu_v s_v^T), Tm = W G: [C][views p] */
+int sm3_linbn_wgrad_finish(const float* P, const float* Tm, const float* s, const float* coef, float* dw, int C, int p,
+                           int views, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Stem, pooling.  replaces resnet.py:208-213,224,294-305.

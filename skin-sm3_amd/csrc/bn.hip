@@ -173,11 +173,19 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x, co
                                                      const float* __restrict__ res_scale,
                                                      const float* __restrict__ res_shift, int relu,
                                                      void* __restrict__ y, uint8_t* __restrict__ mask, int64_t rows,
-                                                     int C, int tbx, int tby) {
+                                                     int C, int tbx, int tby, float* __restrict__ colsum) {
     constexpr int E = ElemTraits<T>::kPer16B;
+    __shared__ float scol[256 * 8];  // colsum only: per-thread column sums, folded over ty
     const int tx = threadIdx.x % tbx, ty = threadIdx.x / tbx;
     const int cv = blockIdx.x * tbx + tx;
-    if (cv * E >= C || ty >= tby) return;
+    const bool active = !(cv * E >= C || ty >= tby);
+    if (!active && !colsum) return;
+    // colsum (nullable): [views][gridDim.y][C] f32, the block's column sums of the STORED (rounded) outputs -- the
+    // first moment of a convolution input that the linear BatchNorm backward needs (linbn.hip)
+    float cs[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) cs[e] = 0.f;
+    if (active) {
     {  // view blockIdx.z: its own row range and scale/shift
         const int64_t vo = (int64_t)blockIdx.z * rows * C;
         x += vo;
@@ -234,7 +242,14 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x, co
             for (int e = 0; e < E; e += 4)
                 *reinterpret_cast<float4*>(yo + e) = make_float4(v[e], v[e + 1], v[e + 2], v[e + 3]);
         } else {
-            stg16<NT>(reinterpret_cast<T*>(y) + off, pack16<T>(v));
+            const uint4 pk = pack16<T>(v);
+            stg16<NT>(reinterpret_cast<T*>(y) + off, pk);
+            if (colsum) {
+                float q[E];
+                unpack16<T>(pk, q);
+#pragma unroll
+                for (int e = 0; e < E; ++e) cs[e] += q[e];
+            }
         }
     };
     int64_t r = (int64_t)blockIdx.y * tby + ty;
@@ -252,6 +267,22 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x, co
     for (; r < rows; r += rstep) {
         const int64_t off = r * C + (int64_t)cv * E;
         finish(r, ldg16<false>(x + off), res ? ldg16<false>(res + off) : make_uint4(0, 0, 0, 0));
+    }
+    }  // active
+    if (colsum) {  // kernel-uniform: every thread of the block gets here
+        if constexpr (E <= 8) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) scol[threadIdx.x * E + e] = cs[e];
+        }
+        __syncthreads();
+        if (active && ty == 0) {
+            for (int j = 1; j < tby; ++j)
+#pragma unroll
+                for (int e = 0; e < E; ++e) cs[e] += scol[(j * tbx + tx) * E + e];
+            float* o = colsum + ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * C + (int64_t)cv * E;
+#pragma unroll
+            for (int e = 0; e < E; ++e) o[e] = cs[e];
+        }
     }
 }
 
@@ -586,22 +617,24 @@ extern "C" int sm3_bn_eval_scale_shift(const float* gamma, const float* beta, co
 
 static int bn_act_impl(int dtype, const void* x, const float* scale, const float* shift, const void* residual,
                        const float* res_scale, const float* res_shift, int relu, int out_f32, void* y,
-                       uint8_t* relu_mask, int64_t rows, int C, int views, void* stream) {
+                       uint8_t* relu_mask, int64_t rows, int C, int views, void* stream, float* colsum = nullptr) {
     if (!x || !scale || !shift || !y || rows <= 0 || C <= 0 || views < 1) return SM3_EINVAL;
     if ((res_scale != nullptr) != (res_shift != nullptr) || (res_scale && !residual)) return SM3_EINVAL;
     if (!SM3_DTYPE_OK(dtype)) return SM3_EDTYPE;
     const int E = dtype == SM3_F32 ? 4 : 8;
     if (C % E) return SM3_EALIGN;
+    if (colsum && out_f32) return SM3_EINVAL;
     const RowWalk w = make_walk(rows, C / E, 8192, views);
     dim3 grid(w.gx, w.gy, views), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define SM3_ACT_T(T, U, NT)                                                                                          \
     if (out_f32 && sizeof(T) == 2)                                                                                      \
         hipLaunchKernelGGL((bn_act_kernel<T, true, U, NT>), grid, block, 0, st, (const T*)x, scale, shift,              \
-                           (const T*)residual, res_scale, res_shift, relu, y, relu_mask, rows, C, w.tbx, w.tby);        \
+                           (const T*)residual, res_scale, res_shift, relu, y, relu_mask, rows, C, w.tbx, w.tby,         \
+                           (float*)nullptr);                                                                            \
     else /* f32 storage: the two output forms coincide */                                                               \
         hipLaunchKernelGGL((bn_act_kernel<T, false, U, NT>), grid, block, 0, st, (const T*)x, scale, shift,             \
-                           (const T*)residual, res_scale, res_shift, relu, y, relu_mask, rows, C, w.tbx, w.tby)
+                           (const T*)residual, res_scale, res_shift, relu, y, relu_mask, rows, C, w.tbx, w.tby, colsum)
 #define SM3_ACT(U, NT)                                            \
     if (dtype == SM3_F32) { SM3_ACT_T(float, U, NT); }            \
     else if (dtype == SM3_BF16) { SM3_ACT_T(bf16_t, U, NT); }     \
@@ -618,6 +651,21 @@ extern "C" int sm3_bn_act(int dtype, const void* x, const float* scale, const fl
                           void* stream) {
     return bn_act_impl(dtype, x, scale, shift, residual, nullptr, nullptr, relu, out_f32, y, relu_mask, rows, C, views,
                        stream);
+}
+
+extern "C" int sm3_bn_act_colsum_rows(int64_t rows, int C, int dtype, int views) {
+    if (rows <= 0 || C <= 0 || views < 1 || !SM3_DTYPE_OK(dtype)) return SM3_EINVAL;
+    const int E = dtype == SM3_F32 ? 4 : 8;
+    if (C % E) return SM3_EALIGN;
+    return make_walk(rows, C / E, 8192, views).gy;
+}
+
+extern "C" int sm3_bn_act_colsum(int dtype, const void* x, const float* scale, const float* shift, const void* residual,
+                                 int relu, void* y, uint8_t* relu_mask, float* colsum_partials, int64_t rows, int C,
+                                 int views, void* stream) {
+    if (!colsum_partials) return SM3_EINVAL;
+    return bn_act_impl(dtype, x, scale, shift, residual, nullptr, nullptr, relu, 0, y, relu_mask, rows, C, views, stream,
+                       colsum_partials);
 }
 
 extern "C" int sm3_bn_add_bn_act(int dtype, const void* x, const float* scale, const float* shift, const void* x2,

@@ -43,6 +43,17 @@ struct ConvParams {
     const float* ep_rm;
     const float* ep_rv;
     float ep_eps;
+    // ---- second K segment (SEG kernels, "BatchNorm backward by linearity": csrc/linbn.hip) ----------------------------
+    // taps with tap_src[t] = 1 take their A rows from x1 ([pixels][Ci1], same pixel geometry) and their B rows from w1
+    // ([Co][w1_row_stride]); nsteps_seg = sum over taps of that tap's K-steps.  Two views in one launch (fz_view_tiles > 0)
+    // may use different banks: view 1's tiles read w + w_view_bytes / w1 + w1_view_bytes.
+    const char* x1;
+    const char* w1;
+    uint32_t x1_bytes, w1_bytes;
+    int Ci1, kchunks1, w1_row_stride, nsteps_seg;
+    uint8_t tap_src[SM3_MAX_TAPS];
+    uint32_t w_view_bytes, w1_view_bytes;
+    const float* col_bias;  // [views][Co] f32 added to the accumulators (before the addend), or null
 };
 
 // eval-mode BatchNorm as y = x * scale + shift, the arithmetic of bn_eval_kernel (bn.hip)

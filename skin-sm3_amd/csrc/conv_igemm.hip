@@ -25,8 +25,12 @@ namespace {
 // per CU).  STAGES = 1 (host picks it for <= 8 K-steps, the memory-bound 1x1 layers; measured: scratch/bench_kernels.py): one 32 KB stage, no
 // intra-workgroup overlap, but 34 KB of LDS lets 4 workgroups share a CU and overlap each other's load latency,
 // K-step and store tail -- which is what those short workgroups need.
-template <typename T, int BM, int BN, int WM, int WN, int STAGES, bool LEAN>
+// SEG: the K loop may draw taps from a SECOND (A, B) operand pair (ConvParams::x1 / w1, tap_src): Y = sum_t A_t B_t^T
+// over two tensors with different channel counts -- the data gradient of "BatchNorm backward by linearity" (linbn.hip),
+// [dz | y_in] x [diag(a) W ; -H]^T.  Only the general epilogue has it; the production forward kernels are untouched.
+template <typename T, int BM, int BN, int WM, int WN, int STAGES, bool LEAN, bool SEG = false>
 __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvParams p) {
+    static_assert(!(SEG && LEAN) && !(SEG && STAGES > 2), "segments: general epilogue, 1 or 2 stages");
     constexpr int NT = WM * WN * 64;
     constexpr int RPP = NT / 8;  // rows covered per loader pass
     constexpr int AI = BM / RPP, BI = BN / RPP;
@@ -59,12 +63,20 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    // second segment's operands (SEG only; otherwise aliases that the optimiser drops)
+    const __amdgpu_buffer_rsrc_t rx1 =
+        SEG ? __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.x1_bytes, 0x00020000) : rx;
+    const __amdgpu_buffer_rsrc_t rw1 =
+        SEG ? __builtin_amdgcn_make_buffer_rsrc((void*)p.w1, 0, p.w1_bytes, 0x00020000) : rw;
+    // two views in one launch: a tile belongs to exactly one of them (view rows are a multiple of BM)
+    const int tile_view = (p.fz_view_tiles > 0 && bm >= p.fz_view_tiles) ? 1 : 0;
 
     // ---- loader state -------------------------------------------------------------------
     // lane (row = (tid>>3) + i*RPP, pos = tid&7) of DMA instruction i; rows 8*wave + 32*i .. +7 per instruction
     const int pos = tid & 7;
     int a_pix[AI], a_iy0[AI], a_ix0[AI];  // pixel index of tap (0,0) and its coordinates; a_iy0 = -2^20 if row >= M
     uint32_t a_ch[AI], a_off[AI], b_off[BI];
+    uint32_t b_off1[SEG ? BI : 1];
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
         const int r = (tid >> 3) + i * RPP;
@@ -90,23 +102,40 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
         const int co = n0 + r;
         b_off[i] = (co < p.Co) ? (uint32_t)co * (uint32_t)(p.w_row_stride * SZ) + (uint32_t)((pos ^ (r >> 1)) & 7) * 16u
                                : kOOB;
+        if constexpr (SEG) {
+            if (co < p.Co) b_off[i] += (uint32_t)tile_view * p.w_view_bytes;
+            b_off1[i] = (co < p.Co) ? (uint32_t)co * (uint32_t)(p.w1_row_stride * SZ) + (uint32_t)((pos ^ (r >> 1)) & 7) * 16u +
+                                          (uint32_t)tile_view * p.w1_view_bytes
+                                    : kOOB;
+        }
     }
     const uint32_t row_bytes = (uint32_t)p.Ci * SZ;
+    const uint32_t row_bytes1 = SEG ? (uint32_t)p.Ci1 * SZ : row_bytes;
+    int cur_src = 0;  // segment of the tap being staged (wave-uniform)
 
     auto set_tap = [&](int t) {
         const int ddy = p.dy[t], ddx = p.dx[t];
         const int dpix = ddy * p.Wi + ddx;
+        if constexpr (SEG) cur_src = __builtin_amdgcn_readfirstlane((int)p.tap_src[t]);
+        const uint32_t rb = (SEG && cur_src) ? row_bytes1 : row_bytes;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             const int iy = a_iy0[i] + ddy, ix = a_ix0[i] + ddx;
             const bool ok = ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi);
-            a_off[i] = ok ? (uint32_t)(a_pix[i] + dpix) * row_bytes + a_ch[i] : kOOB;
+            a_off[i] = ok ? (uint32_t)(a_pix[i] + dpix) * rb + a_ch[i] : kOOB;
         }
     };
     const uint32_t smem_lds = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
     auto dma_stage = [&](int stage, uint32_t soff_a, uint32_t soff_b) {
         const uint32_t sA = smem_lds + (uint32_t)(stage * STAGE + wave * (8 * 128));
         const uint32_t sB = sA + A_BYTES;
+        if (SEG && cur_src) {
+#pragma unroll
+            for (int i = 0; i < AI; ++i) dma16(rx1, sA + i * (RPP * 128), a_off[i], soff_a);
+#pragma unroll
+            for (int i = 0; i < BI; ++i) dma16(rw1, sB + i * (RPP * 128), b_off1[SEG ? i : 0], soff_b);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < AI; ++i) dma16(rx, sA + i * (RPP * 128), a_off[i], soff_a);
 #pragma unroll
@@ -146,18 +175,20 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
         }
     };
 
-    const int nsteps = p.ntaps * p.kchunks;
+    const int nsteps = SEG ? p.nsteps_seg : p.ntaps * p.kchunks;
     int t = 0, kc = 0;
-    uint32_t wtap_off = (uint32_t)p.wtap[0] * row_bytes;
+    set_tap(0);
+    int kch = (SEG && cur_src) ? p.kchunks1 : p.kchunks;  // K-steps of the current tap
+    uint32_t wtap_off = (uint32_t)p.wtap[0] * ((SEG && cur_src) ? row_bytes1 : row_bytes);
     auto advance = [&]() {
-        if (++kc == p.kchunks) {
+        if (++kc == kch) {
             kc = 0;
             ++t;
             set_tap(t);
-            wtap_off = (uint32_t)p.wtap[t] * row_bytes;
+            if constexpr (SEG) kch = cur_src ? p.kchunks1 : p.kchunks;
+            wtap_off = (uint32_t)p.wtap[t] * ((SEG && cur_src) ? row_bytes1 : row_bytes);
         }
     };
-    set_tap(0);
     dma_stage(0, 0, wtap_off);
     if constexpr (STAGES > 2) {
         // Deep pipeline for launches of at most one workgroup per CU (projector Linears: M = 256..512 rows, 32 K-steps):
@@ -292,7 +323,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
     constexpr int NROW = WTM / RSTEP;  // stores per thread per wave-row
     static_assert(NT % CPR == 0 && WTM % RSTEP == 0, "a thread must keep one channel vector across its rows");
     const bool dense = (p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.HWout == p.HoWo);
-    const bool fz = p.fz_x != nullptr;
+    const bool fz = p.fz_partials != nullptr;  // BatchNorm-backward phase 1 of the producer unit in this epilogue
+    const bool fzx = p.fz_x != nullptr;        // ... including sum(dz * xhat); without x only the mask and sum(dz)
     const int cc = tid % CPR;  // fixed per thread
     const int ncol = n0 + cc * EPC;
     float* sC = reinterpret_cast<float*>(smem);
@@ -322,8 +354,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
 
     // f_mu/f_is double as the inference epilogue's per-channel scale/shift (the two modes are exclusive)
     const bool ep = p.ep_scale != nullptr || p.ep_rv != nullptr;
-    // two views in one launch: a tile belongs to exactly one of them (view rows are a multiple of BM)
-    const int fz_view = (p.fz_view_tiles > 0 && bm >= p.fz_view_tiles) ? 1 : 0;
+    const int fz_view = tile_view;
     const int fz_prow = fz_view ? p.fz_row_off1 + bm - p.fz_view_tiles : p.fz_row_off + bm;
     float f_mu[EPC], f_is[EPC], f_s1[EPC], f_s2[EPC];
 #pragma unroll
@@ -333,7 +364,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
         f_mu[e] = 0.f;
         f_is[e] = 0.f;
         if (ncol < p.Co) {
-            if (fz) {
+            if (fzx) {
                 f_mu[e] = p.fz_mean[fz_view * p.Co + ncol + e];
                 f_is[e] = p.fz_invstd[fz_view * p.Co + ncol + e];
             } else if (ep) {
@@ -377,7 +408,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
                     }
                 }
                 if (fz) {
-                    pre_x[k] = ldg16<true>(p.fz_x + e_off[k] * SZ);
+                    if (fzx) pre_x[k] = ldg16<true>(p.fz_x + e_off[k] * SZ);
                     if (p.fz_mask) pre_mk[k] = p.fz_mask[e_off[k] / EPC];
                 }
             }
@@ -424,6 +455,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) v[e] = v[e] * f_is[e] + f_mu[e];
             }
+            if constexpr (SEG) {
+                if (p.col_bias) {  // constant term of the linear BatchNorm backward (per output channel and view)
+                    const float* cb = p.col_bias + (long)tile_view * p.Co + ncol;
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[e] += cb[e];
+                }
+            }
             if (p.addend) {
                 float a[EPC];
                 unpack16<T>(pre_add[k], a);
@@ -449,7 +487,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     f_s1[e] += dzr[e];
-                    f_s2[e] += dzr[e] * (xv[e] - f_mu[e]) * f_is[e];
+                    f_s2[e] += dzr[e] * (xv[e] - f_mu[e]) * f_is[e];  // f_mu = f_is = 0 without x: the slot stays 0
                 }
                 stg16<true>(p.y + boff, packed);
             } else {
@@ -475,7 +513,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int STAGES, bool LEAN>
+template <typename T, int BM, int BN, int WM, int WN, int STAGES, bool LEAN, bool SEG = false>
 int launch_conv_st(const ConvParams& p0, hipStream_t st) {
     ConvParams p = p0;
     constexpr int STAGE = (BM + BN) * 128;
@@ -485,7 +523,7 @@ int launch_conv_st(const ConvParams& p0, hipStream_t st) {
     static_assert(LEAN || MAIN >= 256 * 2 * 8 * 4, "reduction scratch of the fused BN-backward epilogue must fit");
     p.tilesM = (p.M + BM - 1) / BM;
     p.tilesN = (p.Co + BN - 1) / BN;
-    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, STAGES, LEAN>;
+    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, STAGES, LEAN, SEG>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -504,6 +542,14 @@ template <typename T, int BM, int BN, int WM, int WN>
 int launch_conv(const ConvParams& p, hipStream_t st) {
     const char* v = getenv("SM3_CONV_SINGLE_STAGE_MAX");
     const int single_max = v ? atoi(v) : 8;
+    if (p.x1) {  // two K segments (16-bit types only: the exact-f32 parity mode never takes the linear BatchNorm backward)
+        if constexpr (sizeof(T) == 2) {
+            return p.nsteps_seg <= single_max ? launch_conv_st<T, BM, BN, WM, WN, 1, false, true>(p, st)
+                                              : launch_conv_st<T, BM, BN, WM, WN, 2, false, true>(p, st);
+        } else {
+            return SM3_EDTYPE;
+        }
+    }
     const bool single = p.ntaps * p.kchunks <= single_max;
     // at most one workgroup per CU and a K-loop worth pipelining: 3 stages in flight (128 KB of LDS, see the kernel)
     const long nblocks = (long)((p.M + BM - 1) / BM) * ((p.Co + BN - 1) / BN);
@@ -512,7 +558,7 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         const char* lv = getenv("SM3_CONV_LEAN");
         const bool dense = p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.HWout == p.HoWo;
-        if (!(lv && atoi(lv) == 0) && dense && !p.addend && !p.fz_x) {  // train-mode forward, and conv+evalBN(+ReLU)
+        if (!(lv && atoi(lv) == 0) && dense && !p.addend && !p.fz_partials) {  // train-mode forward, and conv+evalBN(+ReLU)
             if (deep) return launch_conv_st<T, BM, BN, WM, WN, 4, true>(p, st);
             return single ? launch_conv_st<T, BM, BN, WM, WN, 1, true>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, true>(p, st);
         }
@@ -572,9 +618,10 @@ struct EvalBn {  // eval-mode BatchNorm folded into the epilogue: precomputed ve
 
 static int conv_gather_gemm_impl(const sm3_conv_desc* d, const void* x, const void* w, void* y, const void* addend,
                                  float* stat_partials, const sm3_bn_bwd_fuse* fuse, void* stream,
-                                 const EvalBn* ebn = nullptr) {
+                                 const EvalBn* ebn = nullptr, const sm3_conv_seg* seg = nullptr) {
     if (!d || !x || !w || !y) return SM3_EINVAL;
-    if (fuse && (!fuse->x || !fuse->mean || !fuse->invstd || !fuse->partials || fuse->partial_row_offset < 0))
+    // fuse->x NULL: ReLU mask + sum(dz) only (the sum(dz * xhat) slot of the partial rows is written as 0)
+    if (fuse && ((fuse->x && (!fuse->mean || !fuse->invstd)) || !fuse->partials || fuse->partial_row_offset < 0))
         return SM3_EINVAL;
     if (!SM3_DTYPE_OK(d->dtype)) return SM3_EDTYPE;
     ConvParams p;
@@ -611,6 +658,41 @@ static int conv_gather_gemm_impl(const sm3_conv_desc* d, const void* x, const vo
     p.ep_rv = ebn ? ebn->rv : nullptr;
     p.ep_eps = ebn ? ebn->eps : 0.f;
     p.ep_relu = ebn ? ebn->relu : 0;
+    p.x1 = p.w1 = nullptr;
+    p.col_bias = nullptr;
+    p.x1_bytes = p.w1_bytes = p.w_view_bytes = p.w1_view_bytes = 0;
+    p.Ci1 = p.kchunks1 = p.w1_row_stride = p.nsteps_seg = 0;
+    for (int t = 0; t < SM3_MAX_TAPS; ++t) p.tap_src[t] = 0;
+    if (seg) {
+        // Y = X W^T + X1 W1^T (+ col_bias): a 1x1 / stride-1 / dense product over the same pixels
+        const bool plain = d->ntaps == 1 && d->sy == 1 && d->sx == 1 && d->dy[0] == 0 && d->dx[0] == 0 && d->wtap[0] == 0 &&
+                           d->osy == 1 && d->osx == 1 && d->ooy == 0 && d->oox == 0 && d->Hout == d->Ho &&
+                           d->Wout == d->Wo && d->Ho == d->Hi && d->Wo == d->Wi;
+        if (!plain || !seg->x1 || !seg->w1 || seg->Ci1 <= 0 || sz != 2 || ebn) return SM3_EINVAL;
+        if ((seg->Ci1 * sz) % 128 != 0) return SM3_EALIGN;
+        const int nviews = (fuse && fuse->views > 1) ? 2 : 1;
+        if (seg->w_view_stride < 0 || seg->w1_view_stride < 0) return SM3_EINVAL;
+        const long x1b = (long)p.M * seg->Ci1 * sz;
+        const long w0b = ((long)(nviews - 1) * seg->w_view_stride + (long)(d->Co - 1) * d->w_row_stride + d->Ci) * sz;
+        const long w1b = ((long)(nviews - 1) * seg->w1_view_stride + (long)d->Co * seg->Ci1) * sz;
+        if (x1b >= 0xC0000000L || w0b >= 0xC0000000L || w1b >= 0xC0000000L) return SM3_EINVAL;
+        p.x1 = (const char*)seg->x1;
+        p.w1 = (const char*)seg->w1;
+        p.x1_bytes = (uint32_t)x1b;
+        p.w1_bytes = (uint32_t)w1b;
+        p.w_bytes = (uint32_t)w0b;
+        p.Ci1 = seg->Ci1;
+        p.kchunks1 = seg->Ci1 * sz / 128;
+        p.w1_row_stride = seg->Ci1;
+        p.ntaps = 2;
+        p.dy[1] = p.dx[1] = 0;
+        p.wtap[1] = 0;
+        p.tap_src[1] = 1;
+        p.nsteps_seg = p.kchunks + p.kchunks1;
+        p.w_view_bytes = (uint32_t)(seg->w_view_stride * sz);
+        p.w1_view_bytes = (uint32_t)(seg->w1_view_stride * sz);
+        p.col_bias = seg->col_bias;
+    }
     hipStream_t st = (hipStream_t)stream;
     // 64-column tiles for Co <= 64, and for the small-M Linears whose 128-column grid would leave most CUs idle
     const long tiles128 = (long)((p.M + kBM - 1) / kBM) * ((d->Co + 127) / 128);
@@ -631,6 +713,12 @@ extern "C" int sm3_conv_dgrad_bnfuse(const sm3_conv_desc* d, const void* dy_in, 
                                      const void* addend, const sm3_bn_bwd_fuse* fuse, void* stream) {
     if (!fuse) return SM3_EINVAL;
     return conv_gather_gemm_impl(d, dy_in, w_dgrad, dz_out, addend, nullptr, fuse, stream);
+}
+
+extern "C" int sm3_conv_dgrad_seg_bnfuse(const sm3_conv_desc* d, const void* x0, const void* w0, const sm3_conv_seg* seg,
+                                         void* dz_out, const void* addend, const sm3_bn_bwd_fuse* fuse, void* stream) {
+    if (!seg) return SM3_EINVAL;
+    return conv_gather_gemm_impl(d, x0, w0, dz_out, addend, nullptr, fuse, stream, nullptr, seg);
 }
 
 extern "C" int sm3_conv_bn_act_eval(const sm3_conv_desc* d, const void* x, const void* w, const float* scale,

@@ -34,6 +34,13 @@ struct WgradParams {
     int k_per_split;        // pixels per slice (multiple of KP)
     int gx, splits;         // grid = gx * round_up(splits, 8), see the block -> (tile, slice) map in the kernel
     uint32_t x_bytes;
+    // sm3_conv_wgrad_cat: dY is the channel concatenation [dy (Co) | dy1 (Co1)] of two tensors over the same pixels, the
+    // rows of the second part go to dw1; `views` independent row ranges of Mv pixels each (slices never straddle them),
+    // view v accumulating into dw + v * dw_view_stride / dw1 + v * dw1_view_stride.  Plain wgrad: Co1 = 0, views = 1.
+    const char* dy1;
+    float* dw1;
+    int Co1, views, Mv, splits_view;
+    long dw_view_stride, dw1_view_stride;
 };
 
 using sm3conv::dma16;       // LDS-DMA from inline asm, zero-fill by the buffer range check: see conv_common.h
@@ -93,9 +100,15 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const WgradParams 
     bx /= p.tilesCi;
     const int tap = bx % p.ntaps;
     const int tco = bx / p.ntaps;
-    const int co0 = tco * BMW, ci0 = tci * BNW;
-    const int kbeg0 = slice * p.k_per_split;
-    const int kend = min(p.M, kbeg0 + p.k_per_split);
+    const int ci0 = tci * BNW;
+    // channel tile of dY: in the first tensor, or (sm3_conv_wgrad_cat) in the second one
+    const bool second = tco * BMW >= p.Co;
+    const int co0 = second ? tco * BMW - p.Co : tco * BMW;
+    const int dyC = second ? p.Co1 : p.Co;  // channels (row pitch) of the tensor this tile reads
+    const char* const dy_base = second ? p.dy1 : p.dy;
+    const int view = slice / p.splits_view;
+    const int kbeg0 = view * p.Mv + (slice - view * p.splits_view) * p.k_per_split;
+    const int kend = min((view + 1) * p.Mv, kbeg0 + p.k_per_split);
     if (kbeg0 >= kend) return;
     // K-steps per group (both groups run the same number: rows past kend read as zero), and this group's first pixel
     const int nsteps = ((kend - kbeg0 + KP - 1) / KP + KG - 1) / KG;
@@ -104,7 +117,7 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const WgradParams 
 
     // descriptors: dY rows end at kend (rows of the next slice must read as zero); X is the whole tensor
     const __amdgpu_buffer_rsrc_t rdy =
-        __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (uint32_t)kend * (uint32_t)(p.Co * SZ), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)dy_base, 0, (uint32_t)kend * (uint32_t)(dyC * SZ), 0x00020000);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.x, 0, DENSE ? (uint32_t)kend * (uint32_t)(p.Ci * SZ) : p.x_bytes, 0x00020000);
 
@@ -118,8 +131,8 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const WgradParams 
     for (int i = 0; i < AI; ++i) {
         const int r = (wave + 4 * i) * RPI_A + a_rin;  // pixel row inside the K-step
         const uint32_t lchunk = ((uint32_t)a_pos * 16u) ^ swz_bytes<RA, kBf16>(r);
-        const bool col_ok = co0 + (int)(lchunk / SZ) < p.Co;
-        a_off[i] = col_ok ? (uint32_t)(kbeg + r) * (uint32_t)(p.Co * SZ) + (uint32_t)(co0 * SZ) + lchunk : kOOB;
+        const bool col_ok = co0 + (int)(lchunk / SZ) < dyC;
+        a_off[i] = col_ok ? (uint32_t)(kbeg + r) * (uint32_t)(dyC * SZ) + (uint32_t)(co0 * SZ) + lchunk : kOOB;
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
@@ -145,7 +158,7 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const WgradParams 
     auto dma_stage = [&](int stage, int step) {
         const uint32_t sA = smem_lds + (uint32_t)((grp * NST + stage) * STAGE) + (uint32_t)wave * 1024u;
         const uint32_t sB = sA + A_BYTES;
-        const uint32_t soff_a = (uint32_t)(step * KP) * (uint32_t)(p.Co * SZ);
+        const uint32_t soff_a = (uint32_t)(step * KP) * (uint32_t)(dyC * SZ);
 #pragma unroll
         for (int i = 0; i < AI; ++i) dma16(rdy, sA + i * 4096, a_off[i], soff_a);
         if constexpr (DENSE) {
@@ -294,6 +307,7 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const WgradParams 
                 for (int r = 0; r < 16; ++r) acc[i][j][r] += xch[((wave * TM * TN + i * TN + j) * 16 + r) * 64 + lane];
     }
     const int frow = lane & 31, fh = lane >> 5;
+    float* const dw_out = second ? p.dw1 + (long)view * p.dw1_view_stride : p.dw + (long)view * p.dw_view_stride;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -303,8 +317,8 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const WgradParams 
                 const int co = co0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 const int ci = ci0 + wn * WTN + j * 32 + frow;
                 const long kcol = (long)p.wtap[tap] * p.Ci + ci;  // column inside the dw row
-                if (co < p.Co && ci < p.Ci && kcol < p.w_row_stride)
-                    atomicAdd(p.dw + (long)co * p.w_row_stride + kcol, acc[i][j][r]);
+                if (co < dyC && ci < p.Ci && kcol < p.w_row_stride)
+                    atomicAdd(dw_out + (long)co * p.w_row_stride + kcol, acc[i][j][r]);
             }
 }
 
@@ -330,7 +344,8 @@ template <typename T, int BMW, int BNW, int KP, bool DENSE, int NST, int KG = 1>
 int launch_wgrad_kp(WgradParams p, hipStream_t st) {
     constexpr int SZ = sizeof(T);
     constexpr int LDS = KG * NST * KP * (BMW * SZ + BNW * SZ);
-    p.tilesCo = (p.Co + BMW - 1) / BMW;
+    if (p.Co1 > 0 && p.Co % BMW) return SM3_EALIGN;  // a channel tile reads ONE of the two dY tensors
+    p.tilesCo = (p.Co + BMW - 1) / BMW + (p.Co1 + BMW - 1) / BMW;
     p.tilesCi = (p.Ci + BNW - 1) / BNW;
     p.adv_n = KP / p.HoWo;
     p.adv_oy = (KP % p.HoWo) / p.Wo;
@@ -356,18 +371,21 @@ int launch_wgrad_kp(WgradParams p, hipStream_t st) {
     // 64 KB-per-workgroup variant (fewer, longer workgroups) ahead for the 1x1 layers.  SM3_WGRAD_TARGET_CTAS overrides.
     const long slots_xcd = (long)cus_per_xcd() * per_cu;
     const long target = env_int("SM3_WGRAD_TARGET_CTAS", 0);
-    long splits;
+    long splits;  // of the whole launch; each of the `views` row ranges gets splits / views slices of its own
     if (target > 0) splits = (target + gx - 1) / gx;
     else if (gx <= slots_xcd) splits = 8 * (slots_xcd / gx);
     else splits = 8 * slots_xcd / gx;  // < 8 slices: tiles go round-robin over the XCDs (see the kernel)
-    const long max_splits = (p.M + KP * 8 * KG - 1) / (KP * 8 * KG);
+    splits = (splits + p.views - 1) / p.views;  // per view from here on
+    const long max_splits = (p.Mv + KP * 8 * KG - 1) / (KP * 8 * KG);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
-    long kps = (p.M + splits - 1) / splits;
+    long kps = (p.Mv + splits - 1) / splits;
     kps = (kps + KP - 1) / KP * KP;
-    splits = (p.M + kps - 1) / kps;
+    splits = (p.Mv + kps - 1) / kps;
     p.k_per_split = (int)kps;
     p.gx = (int)gx;
+    p.splits_view = (int)splits;
+    splits *= p.views;
     p.splits = (int)splits;
     const long nblocks = gx * (splits >= 8 ? (splits + 7) / 8 * 8 : splits);
     if (gx > 0x7fffffffL || nblocks > 0x7fffffffL) return SM3_EINVAL;
@@ -394,19 +412,24 @@ int launch_wgrad(WgradParams p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int sm3_conv_wgrad(const sm3_conv_desc* d, const void* x, const void* dy, float* dw, void* stream) {
+static int wgrad_impl(const sm3_conv_desc* d, const void* x, const void* dy, float* dw, const void* dy1, int Co1,
+                      float* dw1, int views, long dw_view_stride, long dw1_view_stride, void* stream) {
     if (!d || !x || !dy || !dw) return SM3_EINVAL;
     if (!SM3_DTYPE_OK(d->dtype)) return SM3_EDTYPE;
     const int sz = d->dtype == SM3_F32 ? 4 : 2;
     if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ci <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Co <= 0) return SM3_EINVAL;
     if (d->ntaps < 1 || d->ntaps > SM3_MAX_TAPS) return SM3_EINVAL;
-    if ((d->Ci * sz) % 16 != 0 || (d->Co * sz) % 16 != 0) return SM3_EALIGN;
+    if ((d->Ci * sz) % 16 != 0 || (d->Co * sz) % 16 != 0 || (Co1 * sz) % 16 != 0) return SM3_EALIGN;
     if (d->osy != 1 || d->osx != 1 || d->ooy != 0 || d->oox != 0 || d->Hout != d->Ho || d->Wout != d->Wo)
         return SM3_EINVAL;  // dy must be the dense output of the forward conv
     const long M = (long)d->N * d->Ho * d->Wo;
     if (M > 0x7fffffffL || (long)d->N * d->Hi * d->Wi > 0x7fffffffL) return SM3_EINVAL;
+    if (views < 1 || M % views || Co1 < 0 || (Co1 > 0 && (!dy1 || !dw1))) return SM3_EINVAL;
     WgradParams p;
     p.x = (const char*)x; p.dy = (const char*)dy; p.dw = dw;
+    p.dy1 = (const char*)dy1; p.dw1 = dw1; p.Co1 = Co1;
+    p.views = views; p.Mv = (int)(M / views);
+    p.dw_view_stride = dw_view_stride; p.dw1_view_stride = dw1_view_stride;
     p.M = (int)M; p.Hi = d->Hi; p.Wi = d->Wi; p.Ci = d->Ci; p.Co = d->Co;
     p.sy = d->sy; p.sx = d->sx; p.ntaps = d->ntaps;
     for (int t = 0; t < SM3_MAX_TAPS; ++t) { p.dyt[t] = d->dy[t]; p.dxt[t] = d->dx[t]; p.wtap[t] = d->wtap[t]; }
@@ -414,11 +437,11 @@ extern "C" int sm3_conv_wgrad(const sm3_conv_desc* d, const void* x, const void*
     p.HoWo = d->Ho * d->Wo; p.Wo = d->Wo; p.Ho = d->Ho;
     p.div_HoWo = make_fastdiv((uint32_t)p.HoWo);
     p.div_Wo = make_fastdiv((uint32_t)p.Wo);
-    const long xb = (long)d->N * d->Hi * d->Wi * d->Ci * sz, yb = M * d->Co * sz;
-    if (xb >= 0xC0000000L || yb >= 0xC0000000L) return SM3_EINVAL;  // 32-bit buffer offsets
+    const long xb = (long)d->N * d->Hi * d->Wi * d->Ci * sz, yb = M * d->Co * sz, y1b = M * Co1 * sz;
+    if (xb >= 0xC0000000L || yb >= 0xC0000000L || y1b >= 0xC0000000L) return SM3_EINVAL;  // 32-bit buffer offsets
     p.x_bytes = (uint32_t)xb;
     hipStream_t st = (hipStream_t)stream;
-    const bool nco = d->Co <= 64, nci = d->Ci <= 64;
+    const bool nco = d->Co + Co1 <= 64, nci = d->Ci <= 64;
     if (d->dtype == SM3_BF16) {
         if (nco && nci) return launch_wgrad<bf16_t, 64, 64>(p, st);
         if (nco) return launch_wgrad<bf16_t, 64, 128>(p, st);
@@ -435,4 +458,15 @@ extern "C" int sm3_conv_wgrad(const sm3_conv_desc* d, const void* x, const void*
     if (nco) return launch_wgrad<float, 64, 128>(p, st);
     if (nci) return launch_wgrad<float, 128, 64>(p, st);
     return launch_wgrad<float, 128, 128>(p, st);
+}
+
+extern "C" int sm3_conv_wgrad(const sm3_conv_desc* d, const void* x, const void* dy, float* dw, void* stream) {
+    return wgrad_impl(d, x, dy, dw, nullptr, 0, nullptr, 1, 0, 0, stream);
+}
+
+extern "C" int sm3_conv_wgrad_cat(const sm3_conv_desc* d, const void* x, const void* dy, float* dw, const void* dy1,
+                                  int Co1, float* dw1, int views, int64_t dw_view_stride, int64_t dw1_view_stride,
+                                  void* stream) {
+    if (Co1 > 0 && d && d->Co % 128) return SM3_EALIGN;  // tiles of 64 or 128 channels never straddle the two tensors
+    return wgrad_impl(d, x, dy, dw, dy1, Co1, dw1, views, (long)dw_view_stride, (long)dw1_view_stride, stream);
 }

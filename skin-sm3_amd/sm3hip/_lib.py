@@ -32,6 +32,11 @@ class BnBwdFuse(C.Structure):
                 ("partial_row_offset_view1", C.c_int32), ("addend_sp_h", C.c_int32), ("addend_sp_w", C.c_int32)]
 
 
+class ConvSeg(C.Structure):
+    _fields_ = [("x1", C.c_void_p), ("w1", C.c_void_p), ("Ci1", C.c_int32), ("w_view_stride", C.c_int64),
+                ("w1_view_stride", C.c_int64), ("col_bias", C.c_void_p)]
+
+
 class BnApplySide(C.Structure):
     _fields_ = [("x", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("gamma", C.c_void_p),
                 ("global_sums", C.c_void_p), ("local_sums", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
@@ -53,6 +58,13 @@ SIGNATURES = {
     "sm3_conv_partial_rows": [_DESC],
     "sm3_conv_gather_gemm": [_DESC, _P, _P, _P, _P, _P, _P],
     "sm3_conv_dgrad_bnfuse": [_DESC, _P, _P, _P, _P, _P, _P],
+    "sm3_conv_dgrad_seg_bnfuse": [_DESC, _P, _P, _P, _P, _P, _P, _P],
+    "sm3_conv_wgrad_cat": [_DESC, _P, _P, _P, _P, _I, _P, _I, _L, _L, _P],
+    "sm3_bn_act_colsum_rows": [_L, _I, _I, _I],
+    "sm3_bn_act_colsum": [_I, _P, _P, _P, _P, _I, _P, _P, _P, _L, _I, _I, _P],
+    "sm3_linbn_stats": [_I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P],
+    "sm3_linbn_coeffs": [_I, _P, _P, _P, _P, _P, _D, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "sm3_linbn_wgrad_finish": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "sm3_conv_bn_act_eval": [_DESC, _P, _P, _P, _P, _P, _I, _P, _P],
     "sm3_conv_bn_eval": [_DESC, _P, _P, _P, _P, _P, _P, _F, _P, _I, _P, _P],
     "sm3_conv_wgrad": [_DESC, _P, _P, _P, _P],

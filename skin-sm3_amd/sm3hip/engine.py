@@ -163,7 +163,7 @@ class BNUnit:
 class Rec:
     """What one conv+BN(+act) application saves for backward."""
     __slots__ = ("cu", "bu", "N", "H", "W", "Ho", "Wo", "x_in", "xo", "mean", "invstd", "y", "relu", "mask", "V",
-                 "frozen_stats", "scale", "shift")
+                 "frozen_stats", "scale", "shift", "colsum", "colsum_rows", "linbn")
 
 
 class EncoderPlan:
@@ -286,6 +286,9 @@ class SM3Engine:
         # 7x7 stem straight from the NCHW images (csrc/stem.hip): no im2col matrix, BN-backward apply fused into the
         # stem weight gradient.  bf16 only; the exact-f32 parity mode keeps im2col + gather-GEMM.
         self.direct_stem = self.dtype in (SM3_BF16, SM3_F16) and _os.environ.get("SM3_DIRECT_STEM", "1") != "0"
+        # BatchNorm backward by linearity for conv3 -> bn3 of every Bottleneck (csrc/linbn.hip): no bn3 backward-apply
+        # pass and no backward read of conv3's output.  16-bit modes only; the exact-f32 parity mode keeps two passes.
+        self.linbn = self.dtype in (SM3_BF16, SM3_F16) and _os.environ.get("SM3_LINBN", "1") != "0"
 
     # ---- setup ---------------------------------------------------------------------------
     def _all_conv_units(self):
@@ -431,7 +434,7 @@ class SM3Engine:
 
     # ---- conv + BN (+residual) (+ReLU) ---------------------------------------------------
     def conv_bn(self, cu, bu, x, N, H, W, relu, residual=None, train=True, save=None, out_f32=False, y_out=None,
-                apply=True, scale_shift=None, res_affine=None, pending=None):
+                apply=True, scale_shift=None, res_affine=None, pending=None, colsum=False):
         """One conv + BatchNorm (+residual) (+ReLU) unit on N images.  With self._V == 2 the batch is two views back
         to back (N = 2B): one convolution launch, BatchNorm statistics / running-statistics updates per view.
         apply=False: stop after the statistics -- returns the pre-BatchNorm tensor, scale/shift are left in
@@ -544,12 +547,17 @@ class SM3Engine:
                 y_out = torch.empty(rows, C, dtype=torch.float32 if out_f32 else self.tdt, device=dev)
             if save is not None and relu:  # 1 bit per element of (y > 0): what backward needs instead of re-reading y
                 mask = torch.empty(rows * C // (16 // ops._sz(self.dtype)), dtype=torch.uint8, device=dev)
+            cs = cs_rows = None
             if res_affine is not None:
                 ops.bn_add_bn_act(self.dtype, xo, scale, shift, residual, res_affine[0], res_affine[1], relu, y_out,
                                   rows_v, C, mask=mask, views=V)
             else:
+                if colsum and save is not None and train and not out_f32:
+                    # column sums of this unit's output = first moment of the next convolution's input (linbn)
+                    cs_rows = ops.bn_act_colsum_rows(self.dtype, rows_v, C, V)
+                    cs = torch.empty(V * cs_rows * C, dtype=torch.float32, device=dev)
                 ops.bn_act(self.dtype, xo, scale, shift, residual, relu, y_out, rows_v, C, out_f32=out_f32, mask=mask,
-                           views=V)
+                           views=V, colsum=cs)
         if save is not None:
             r = Rec()
             r.cu, r.bu, r.N, r.H, r.W, r.Ho, r.Wo = cu, bu, N, H, W, Ho, Wo
@@ -557,6 +565,8 @@ class SM3Engine:
             r.V = V
             r.frozen_stats = not train
             r.scale = r.shift = None
+            r.colsum, r.colsum_rows = (cs, cs_rows) if apply else (None, None)
+            r.linbn = False
             save.append(r)
         return (y_out if apply else xo), Ho, Wo
 
@@ -642,6 +652,87 @@ class SM3Engine:
                           side(rd, gsums[n: 2 * n], lsums[n: 2 * n], dy), rows, C, views=V)
         return dx3, dy
 
+    def _lin_desc(self, dtype, M, K, N):
+        """Descriptor of a plain [M, K] x [N, K]^T product through the gather-GEMM."""
+        cache = self.__dict__.setdefault("_lin_descs", {})
+        key = (dtype, M, K, N)
+        if key not in cache:
+            cache[key] = ops.fwd_desc(dtype, M, 1, 1, K, N, 1, 1, 0)
+        return cache[key]
+
+    def conv3_backward_linbn(self, r3, r2, dz, bpart, prow, rd=None):
+        """Backward of conv3 -> bn3 BY LINEARITY (csrc/linbn.hip; reference: the autograd backward of
+        src/models/resnet.py:162-163).  dz: the masked gradient of the block output [M, C]; bpart: its partial rows
+        [V][prow][2][C] (only sum(dz) is used) as left by the producing data-gradient launch.  No pass over bn3's input or
+        output: the weight gradient runs on dz itself (plus a [p, p] Gram block of conv3's input y2), the data gradient
+        is one GEMM over the two K segments [dz | y2].  Accumulates d(conv3.weight), d(bn3.weight/bias).
+        rd: the downsample unit of the block, whose BatchNorm received the same dz (resnet.py:164-172): its two-pass
+        backward runs alongside -- statistics in the SAME SyncBN exchange as bn3's, apply pass in place over dz once the
+        GEMMs above have read it.
+        Returns (dz2 = masked gradient of bn2's output, bn2's phase-1 partial rows per view, d(downsample conv output))."""
+        cu, bu = r3.cu, r3.bu
+        C, p, V = cu.Co, cu.Ci, r3.V
+        M = r3.xo.shape[0]
+        rows = M // V
+        y2 = r3.x_in
+        # 1. P = dz^T y2 [V][C][p] and G = y2^T y2 [V][p][p]: the weight-gradient kernel, dz read once
+        PG = self._work("linbn_PG", V * (C + p) * p)
+        PG.zero_()
+        P, G = PG[: V * C * p], PG[V * C * p: V * (C + p) * p]
+        ops.conv_wgrad_cat(cu.wgrad_desc(self.dtype, r3.N, r3.H, r3.W), y2, dz, P, y2, G, views=V)
+        # 2. local sums [bn3 | downsample][V][2C]: sum(dz) from the fused partial rows, sum(dz * xhat) from P
+        n = V * 2 * C
+        tot = n * (2 if rd is not None else 1)
+        s = self._work("linbn_s", V * p)
+        lsums = self._work("lsums2", 2 * 2 * 2 * 2048, torch.float64)
+        ops.bn_stats_reduce(bpart, prow, C, lsums, views=V)
+        ops.linbn_stats(self.dtype, P, cu.w_fwd, r3.mean, r3.invstd, lsums, r2.colsum, r2.colsum_rows, s, C, p, V)
+        if rd is not None:
+            prow_d = ops.bn_bwd_partial_rows(rows, C)
+            dpart = self._work("partials_d", V * prow_d * 2 * C)
+            ops.bn_bwd_reduce(self.dtype, dz, None, rd.xo, rd.mean, rd.invstd, None, rows, C, dpart, views=V)
+            ops.bn_stats_reduce(dpart, prow_d, C, lsums[n:], views=V)
+        gsums, count = lsums, rows
+        if self.stat_sync is not None:
+            gsums = self._work("gsums2", 2 * 2 * 2 * 2048, torch.float64)
+            gsums[:tot].copy_(lsums[:tot])
+            self.stat_sync(gsums[:tot])  # one all-reduce for the two BatchNorms (and both views)
+            count = rows * self.world_size
+        # 3. a, b per channel; diag(a) W and -diag(b) W in data-gradient order; the constant term; d(gamma), d(beta)
+        wa = self._work("linbn_wa", V * p * C, self.tdt)
+        wbn = self._work("linbn_wbn", V * p * C, self.tdt)
+        cconst = self._work("linbn_const", V * p)
+        coef = self._work("linbn_coef", V * 4 * C)
+        aff = bu.affine
+        ops.linbn_coeffs(self.dtype, cu.w_dgrad, self._p(bu.name + ".weight") if aff else None, r3.mean, r3.invstd,
+                         gsums[:n], count, lsums[:n], self._g(bu.name + ".weight") if aff else None,
+                         self._g(bu.name + ".bias") if aff else None, wa, wbn, cconst, coef, C, p, V)
+        # 4. -H_v = (-diag(b_v) W)^T W  [V p, p]   and   5. Tm = W G  [C, V p] (exact f32)
+        Hn = self._work("linbn_H", V * p * p, self.tdt)
+        ops.conv_gemm(self._lin_desc(self.dtype, V * p, C, p), wbn[: V * p * C], cu.w_dgrad, Hn[: V * p * p])
+        Tm = self._work("linbn_T", C * V * p)
+        ops.conv_gemm(self._lin_desc(SM3_F32, C, p, V * p), self._p(cu.name + ".weight"), G, Tm[: C * V * p])
+        # 6. data gradient [dz | y2] x [diag(a) W ; -H]^T + const, with bn2's ReLU mask and phase 1 in the epilogue
+        descs, full = cu.dgrad_descs(self.dtype, r3.N, r3.H, r3.W)
+        dd = descs[0]
+        dz2 = torch.empty(M, p, dtype=self.tdt, device=dz.device)
+        total = ops.conv_partial_rows(dd)
+        part = self._work("fz_partials", total * 2 * p)
+        nrows = ops.conv_dgrad_seg_bnfuse(dd, dz, wa[: V * p * C], y2, Hn[: V * p * p], cconst[: V * p], dz2,
+                                          r2.mask if r2.relu else None, None if r2.linbn else r2.xo, r2.mean, r2.invstd,
+                                          part, 0, views=V, row_offset_view1=total // V, w_view_stride=p * C,
+                                          w1_view_stride=p * p)
+        # 7. d(conv3.weight) += diag(a)(P - m1 s^T) - diag(b)(W G - mu s^T)
+        ops.linbn_wgrad_finish(P, Tm[: C * V * p], s[: V * p], coef[: V * 4 * C], self._g(cu.name + ".weight"), C, p, V)
+        dxd = None
+        if rd is not None:  # the downsample BatchNorm's apply pass, in place over dz (its last reader was launch 6)
+            affd = rd.bu.affine
+            ops.bn_bwd_apply(self.dtype, dz, rd.xo, rd.mean, rd.invstd, self._p(rd.bu.name + ".weight") if affd else None,
+                             gsums[n: 2 * n], count, lsums[n: 2 * n], self._g(rd.bu.name + ".weight") if affd else None,
+                             self._g(rd.bu.name + ".bias") if affd else None, dz, rows, C, views=V)
+            dxd = dz
+        return dz2, nrows // V, dxd
+
     def _wgrad(self, cu, r, dxo):
         """Weight gradient on the lane's side stream: nothing on the critical path (data gradient -> BN backward ->
         ...) depends on it, so it overlaps with those HBM-bound kernels and fills their tails."""
@@ -697,8 +788,10 @@ class SM3Engine:
                 per_view = total // V
                 off = 0
                 for dd in descs:
+                    # a unit whose backward goes by linearity (Rec.linbn) needs no sum(dz * xhat) from here: its
+                    # pre-BatchNorm tensor is not read
                     n = ops.conv_dgrad_bnfuse(dd, dxo, cu.w_dgrad, dx, addend, fuse.mask if fuse.relu else None,
-                                              fuse.xo, fuse.mean, fuse.invstd, part, off, views=V,
+                                              None if fuse.linbn else fuse.xo, fuse.mean, fuse.invstd, part, off, views=V,
                                               row_offset_view1=per_view + off, addend_sparse=addend_sparse)
                     off += n // V
                 return dx, off
@@ -775,7 +868,8 @@ class SM3Engine:
         for blk in plan.blocks:
             br = [] if save is not None else None
             y1, h1, w1 = self.conv_bn(blk["c1"], blk["b1"], cur, N, h, w, True, None, train, br)
-            y2, h2, w2 = self.conv_bn(blk["c2"], blk["b2"], y1, N, h1, w1, True, None, train, br)
+            lin = self.linbn and train and br is not None and blk["c3"].Co % 128 == 0 and blk["c3"].Ci % 64 == 0
+            y2, h2, w2 = self.conv_bn(blk["c2"], blk["b2"], y1, N, h1, w1, True, None, train, br, colsum=lin)
             ra = None
             pend = None
             if "cd" in blk and lazy:
@@ -791,6 +885,8 @@ class SM3Engine:
                 idn = cur
             y3, h3, w3 = self.conv_bn(blk["c3"], blk["b3"], y2, N, h2, w2, True, idn, train, br, res_affine=ra,
                                       pending=pend)
+            if lin and br[1].colsum is not None:
+                br[-1].linbn = True  # backward of conv3 -> bn3 by linearity; needs br[1].colsum (sum of y2)
             block_recs.append(br)
             cur, h, w = y3, h3, w3
         ops.avgpool_fwd(self.dtype, cur, feat_f32, feat_t, N, h * w, plan.out_dim)
@@ -813,13 +909,27 @@ class SM3Engine:
                 r1, r2, rd, r3 = br
             else:
                 (r1, r2, r3), rd = br, None
-            if rd is not None:
-                dx3, dxd = self.bn_backward_join(r3, rd, dcur, fused_rows=fr)
-                dz = None
+            if r3.linbn:
+                # conv3 -> bn3 by linearity: dz (dcur, masked) feeds the weight- and data-gradient GEMMs as it is
+                if fr is None:  # last block: dcur is the un-masked gradient from the pooling layer
+                    C3, V3 = r3.cu.Co, r3.V
+                    rows3 = r3.xo.shape[0] // V3
+                    prow = ops.bn_bwd_partial_rows(rows3, C3)
+                    bpart = self._work("partials", V3 * prow * 2 * C3)
+                    ops.bn_bwd_reduce(self.dtype, dcur, None, r3.xo, r3.mean, r3.invstd, dcur, rows3, C3, bpart,
+                                      mask=r3.mask, views=V3)
+                else:
+                    prow, bpart = fr, self._ws[(self._lane, "fz_partials")]
+                dy2, fr2, dxd = self.conv3_backward_linbn(r3, r2, dcur, bpart, prow, rd=rd)
+                dz = None if rd is not None else dcur
             else:
-                dx3, dz = self.bn_backward(r3, dcur, keep_dz=True, fused_rows=fr)
-            dy2, fr2 = self.conv_backward(r3, dx3, fuse=r2)
-            del dx3
+                if rd is not None:
+                    dx3, dxd = self.bn_backward_join(r3, rd, dcur, fused_rows=fr)
+                    dz = None
+                else:
+                    dx3, dz = self.bn_backward(r3, dcur, keep_dz=True, fused_rows=fr)
+                dy2, fr2 = self.conv_backward(r3, dx3, fuse=r2)
+                del dx3
             dx2, _ = self.bn_backward(r2, dy2, keep_dz=False, fused_rows=fr2)
             dy1, fr1 = self.conv_backward(r2, dx2, fuse=r1)
             del dx2, dy2

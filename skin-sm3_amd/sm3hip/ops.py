@@ -213,7 +213,7 @@ def conv_dgrad_bnfuse(desc, dy_in, w_dgrad, dz_out, addend, mask, bn_x, mean, in
     if dy_in.numel() != desc.N * desc.Hi * desc.Wi * desc.Ci:
         raise ValueError("dy_in size does not match descriptor")
     n_out = desc.N * desc.Hout * desc.Wout * desc.Co
-    if dz_out.numel() != n_out or bn_x.numel() != n_out:
+    if dz_out.numel() != n_out or (bn_x is not None and bn_x.numel() != n_out):
         raise ValueError("dz_out / bn_x size does not match descriptor")
     if addend_sparse is not None:  # compact [N, Hs, Ws, Co] addend for the even output positions
         hs, ws = addend_sparse
@@ -224,7 +224,30 @@ def conv_dgrad_bnfuse(desc, dy_in, w_dgrad, dz_out, addend, mask, bn_x, mean, in
         raise ValueError("addend size does not match descriptor")
     if mask is not None and mask.numel() != n_out // (16 // _sz(desc.dtype)):
         raise ValueError("mask size mismatch")
-    if mean.numel() < views * desc.Co or invstd.numel() < views * desc.Co:
+    f = _bn_fuse_struct(desc, mask, bn_x, mean, invstd, partials, row_offset, views, row_offset_view1, addend_sparse)
+    prow = conv_partial_rows(desc)
+    if desc.Ci % K_CHUNK[desc.dtype]:
+        raise ValueError(f"Ci={desc.Ci} is not a multiple of {K_CHUNK[desc.dtype]}")
+    M = desc.N * desc.Ho * desc.Wo
+    sz = _sz(desc.dtype)
+    tag = _conv_tag(desc)
+    if _PROFILER is not None and getattr(_PROFILER, "detail", False):
+        tag += f"|M{M}_K{desc.ntaps}x{desc.Ci}_N{desc.Co}_s{desc.osy}_fz"
+    with _prof(tag, 2.0 * M * desc.Co * desc.ntaps * desc.Ci,
+               sz * (min(dy_in.numel(), M * desc.ntaps * desc.Ci)
+                     + M * desc.Co * (1 + (addend is not None) + (bn_x is not None)))):
+        check(_lib.load().sm3_conv_dgrad_bnfuse(C.byref(desc), _ptr(dy_in), _ptr(w_dgrad), _ptr(dz_out), _ptr(addend),
+                                                C.byref(f), _stream()), "sm3_conv_dgrad_bnfuse")
+    return prow
+
+
+def _bn_fuse_struct(desc, mask, bn_x, mean, invstd, partials, row_offset, views, row_offset_view1, addend_sparse=None):
+    """sm3_bn_bwd_fuse for a data-gradient launch over `desc` (sizes checked).  bn_x None: mask + sum(dz) only."""
+    n_out = desc.N * desc.Hout * desc.Wout * desc.Co
+    if mask is not None and mask.numel() != n_out // (16 // _sz(desc.dtype)):
+        raise ValueError("mask size mismatch")
+    if bn_x is not None and (mean is None or invstd is None or mean.numel() < views * desc.Co
+                             or invstd.numel() < views * desc.Co):
         raise ValueError("mean/invstd too small")
     prow = conv_partial_rows(desc)
     if views == 1:
@@ -235,24 +258,61 @@ def conv_dgrad_bnfuse(desc, dy_in, w_dgrad, dz_out, addend, mask, bn_x, mean, in
             raise ValueError("two views need a multiple of 128 rows each")
         if partials.numel() < (max(row_offset, row_offset_view1) + prow // 2) * 2 * desc.Co:
             raise ValueError("partials workspace too small")
-    if desc.Ci % K_CHUNK[desc.dtype]:
-        raise ValueError(f"Ci={desc.Ci} is not a multiple of {K_CHUNK[desc.dtype]}")
     f = _lib.BnBwdFuse()
     f.relu_mask = mask.data_ptr() if mask is not None else None
-    f.x, f.mean, f.invstd, f.partials = bn_x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), partials.data_ptr()
+    f.x = bn_x.data_ptr() if bn_x is not None else None
+    f.mean = mean.data_ptr() if bn_x is not None else None
+    f.invstd = invstd.data_ptr() if bn_x is not None else None
+    f.partials = partials.data_ptr()
     f.partial_row_offset = row_offset
     f.views, f.partial_row_offset_view1 = views, row_offset_view1
     f.addend_sp_h, f.addend_sp_w = addend_sparse if addend_sparse is not None else (0, 0)
+    return f
+
+
+def conv_dgrad_seg_bnfuse(desc, x0, w0, x1, w1, col_bias, dz_out, mask, bn_x, mean, invstd, partials, row_offset,
+                          views=1, row_offset_view1=0, w_view_stride=0, w1_view_stride=0):
+    """dz_out = mask(x0 w0^T + x1 w1^T + col_bias) with the producer BatchNorm's backward phase 1 in the epilogue
+    (sm3_conv_dgrad_seg_bnfuse): the data gradient of conv -> BatchNorm by linearity.  desc: the 1x1 data-gradient
+    descriptor of x0 ([pixels][desc.Ci]); x1: [pixels][Ci1]; w0: [views][Co][Ci], w1: [views][Co][Ci1]; col_bias:
+    fp32 [views][Co].  Returns the number of partial rows written."""
+    tdt = TORCH_DTYPE[desc.dtype]
+    for t, n in ((x0, "x0"), (w0, "w0"), (x1, "x1"), (w1, "w1"), (dz_out, "dz_out"), (bn_x, "bn_x")):
+        _chk(t, tdt, n)
+    _chk(col_bias, torch.float32, "col_bias"); _chk(mask, torch.uint8, "mask"); _chk(partials, torch.float32, "partials")
+    _chk(mean, torch.float32); _chk(invstd, torch.float32)
+    if desc.dtype == SM3_F32:
+        raise ValueError("conv_dgrad_seg_bnfuse: 16-bit activation types only")
     M = desc.N * desc.Ho * desc.Wo
+    if desc.ntaps != 1 or desc.Hout != desc.Ho or desc.Wout != desc.Wo or desc.Hi != desc.Ho or desc.Wi != desc.Wo:
+        raise ValueError("conv_dgrad_seg_bnfuse: 1x1 / stride-1 descriptor expected")
+    if x0.numel() != M * desc.Ci or x1.numel() % M or dz_out.numel() != M * desc.Co:
+        raise ValueError("conv_dgrad_seg_bnfuse: operand size does not match descriptor")
+    Ci1 = x1.numel() // M
+    if Ci1 % K_CHUNK[desc.dtype] or desc.Ci % K_CHUNK[desc.dtype]:
+        raise ValueError("conv_dgrad_seg_bnfuse: channel counts must be multiples of the K chunk")
+    if w0.numel() < (views - 1) * w_view_stride + desc.Co * desc.w_row_stride or \
+            w1.numel() < (views - 1) * w1_view_stride + desc.Co * Ci1:
+        raise ValueError("conv_dgrad_seg_bnfuse: weight bank too small")
+    if col_bias is not None and col_bias.numel() < views * desc.Co:
+        raise ValueError("conv_dgrad_seg_bnfuse: col_bias too small")
+    if bn_x is not None and bn_x.numel() != dz_out.numel():
+        raise ValueError("conv_dgrad_seg_bnfuse: bn_x size mismatch")
+    f = _bn_fuse_struct(desc, mask, bn_x, mean, invstd, partials, row_offset, views, row_offset_view1)
+    sg = _lib.ConvSeg()
+    sg.x1, sg.w1, sg.Ci1 = x1.data_ptr(), w1.data_ptr(), Ci1
+    sg.w_view_stride, sg.w1_view_stride = w_view_stride, w1_view_stride
+    sg.col_bias = col_bias.data_ptr() if col_bias is not None else None
     sz = _sz(desc.dtype)
     tag = _conv_tag(desc)
     if _PROFILER is not None and getattr(_PROFILER, "detail", False):
-        tag += f"|M{M}_K{desc.ntaps}x{desc.Ci}_N{desc.Co}_s{desc.osy}_fz"
-    with _prof(tag, 2.0 * M * desc.Co * desc.ntaps * desc.Ci,
-               sz * (min(dy_in.numel(), M * desc.ntaps * desc.Ci) + M * desc.Co * (3 if addend is not None else 2))):
-        check(_lib.load().sm3_conv_dgrad_bnfuse(C.byref(desc), _ptr(dy_in), _ptr(w_dgrad), _ptr(dz_out), _ptr(addend),
-                                                C.byref(f), _stream()), "sm3_conv_dgrad_bnfuse")
-    return prow
+        tag += f"|M{M}_K{desc.Ci}+{Ci1}_N{desc.Co}_seg_fz"
+    # algorithmic work = the convolution's data gradient (K = desc.Ci); the second segment is this implementation's cost
+    with _prof(tag, 2.0 * M * desc.Co * desc.Ci,
+               sz * (x0.numel() + x1.numel() + M * desc.Co * (1 + (bn_x is not None)))):
+        check(_lib.load().sm3_conv_dgrad_seg_bnfuse(C.byref(desc), _ptr(x0), _ptr(w0), C.byref(sg), _ptr(dz_out), None,
+                                                    C.byref(f), _stream()), "sm3_conv_dgrad_seg_bnfuse")
+    return conv_partial_rows(desc)
 
 
 def conv_bn_act_eval(desc, x, w, scale, shift, residual, relu, y):
@@ -322,6 +382,68 @@ def conv_wgrad(desc, x, dy, dw):
         check(_lib.load().sm3_conv_wgrad(C.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _stream()), "sm3_conv_wgrad")
 
 
+def conv_wgrad_cat(desc, x, dy, dw, dy1, dw1, views=1):
+    """P[v] = dy_v^T x_v -> dw [views][Co][Ci] and G[v] = dy1_v^T x_v -> dw1 [views][Co1][Ci] in one launch
+    (sm3_conv_wgrad_cat), accumulated into fp32 buffers the caller zeroed."""
+    tdt = TORCH_DTYPE[desc.dtype]
+    _chk(x, tdt, "x"); _chk(dy, tdt, "dy"); _chk(dy1, tdt, "dy1"); _chk(dw, torch.float32, "dw"); _chk(dw1, torch.float32, "dw1")
+    M = desc.N * desc.Ho * desc.Wo
+    if x.numel() != desc.N * desc.Hi * desc.Wi * desc.Ci or dy.numel() != M * desc.Co or dy1.numel() % M or M % views:
+        raise ValueError("conv_wgrad_cat: operand size does not match descriptor")
+    Co1 = dy1.numel() // M
+    if desc.Co % 128 or dw.numel() < views * desc.Co * desc.w_row_stride or dw1.numel() < views * Co1 * desc.w_row_stride:
+        raise ValueError("conv_wgrad_cat: Co must be a multiple of 128; dw / dw1 sized [views][rows][w_row_stride]")
+    sz = _sz(desc.dtype)
+    tag = "conv_wgrad"
+    if _PROFILER is not None and getattr(_PROFILER, "detail", False):
+        tag += f"|M{M}_K{desc.ntaps}x{desc.Ci}_N{desc.Co}+{Co1}_cat"
+    with _prof(tag, 2.0 * M * desc.Co * desc.ntaps * desc.Ci,
+               sz * (x.numel() + dy.numel()) + 4 * views * (desc.Co + Co1) * desc.w_row_stride):
+        check(_lib.load().sm3_conv_wgrad_cat(C.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _ptr(dy1), Co1, _ptr(dw1), views,
+                                             desc.Co * desc.w_row_stride, Co1 * desc.w_row_stride, _stream()),
+              "sm3_conv_wgrad_cat")
+
+
+def linbn_stats(dtype, P, w_fwd, mean, invstd, lsums, colsum, colsum_rows, s_out, Cn, p, views=1):
+    """lsums[v][C:2C] = sum(dz * xhat) from P = dz^T y; s_out[v] = column sums of y (sm3_linbn_stats)."""
+    _chk(P, torch.float32, "P"); _chk(w_fwd, TORCH_DTYPE[dtype], "w_fwd"); _chk(mean, torch.float32); _chk(invstd, torch.float32)
+    _chk(lsums, torch.float64, "lsums"); _chk(colsum, torch.float32, "colsum"); _chk(s_out, torch.float32, "s_out")
+    if P.numel() < views * Cn * p or w_fwd.numel() != Cn * p or mean.numel() < views * Cn or invstd.numel() < views * Cn or \
+            lsums.numel() < views * 2 * Cn or colsum.numel() < views * colsum_rows * p or s_out.numel() < views * p:
+        raise ValueError("linbn_stats: size mismatch")
+    with _prof("linbn_small", 0.0, 4.0 * views * (Cn * p + colsum_rows * p)):
+        check(_lib.load().sm3_linbn_stats(dtype, _ptr(P), _ptr(w_fwd), _ptr(mean), _ptr(invstd), _ptr(lsums), _ptr(colsum),
+                                          colsum_rows, _ptr(s_out), Cn, p, views, _stream()), "sm3_linbn_stats")
+
+
+def linbn_coeffs(dtype, w_dgrad, gamma, mean, invstd, gsums, count, lsums, dgamma, dbeta, wa, wbn, col_const, coef, Cn, p,
+                 views=1):
+    tdt = TORCH_DTYPE[dtype]
+    _chk(w_dgrad, tdt, "w_dgrad"); _chk(wa, tdt, "wa"); _chk(wbn, tdt, "wbn")
+    for t in (gamma, mean, invstd, dgamma, dbeta, col_const, coef):
+        _chk(t, torch.float32)
+    _chk(gsums, torch.float64); _chk(lsums, torch.float64)
+    if w_dgrad.numel() != p * Cn or wa.numel() < views * p * Cn or wbn.numel() < views * p * Cn or \
+            col_const.numel() < views * p or coef.numel() < views * 4 * Cn or gsums.numel() < views * 2 * Cn or \
+            mean.numel() < views * Cn or invstd.numel() < views * Cn or (lsums is not None and lsums.numel() < views * 2 * Cn):
+        raise ValueError("linbn_coeffs: size mismatch")
+    with _prof("linbn_small", 0.0, _sz(dtype) * p * Cn * (1 + 2 * views)):
+        check(_lib.load().sm3_linbn_coeffs(dtype, _ptr(w_dgrad), _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(gsums),
+                                           float(count), _ptr(lsums), _ptr(dgamma), _ptr(dbeta), _ptr(wa), _ptr(wbn),
+                                           _ptr(col_const), _ptr(coef), Cn, p, views, _stream()), "sm3_linbn_coeffs")
+
+
+def linbn_wgrad_finish(P, Tm, s, coef, dw, Cn, p, views=1):
+    for t in (P, Tm, s, coef, dw):
+        _chk(t, torch.float32)
+    if P.numel() < views * Cn * p or Tm.numel() < Cn * views * p or s.numel() < views * p or coef.numel() < views * 4 * Cn \
+            or dw.numel() != Cn * p:
+        raise ValueError("linbn_wgrad_finish: size mismatch")
+    with _prof("linbn_small", 0.0, 4.0 * Cn * p * (2 + 2 * views)):
+        check(_lib.load().sm3_linbn_wgrad_finish(_ptr(P), _ptr(Tm), _ptr(s), _ptr(coef), _ptr(dw), Cn, p, views, _stream()),
+              "sm3_linbn_wgrad_finish")
+
+
 # ------------------------------------------------------------------------------------------
 # batch norm
 # ------------------------------------------------------------------------------------------
@@ -384,8 +506,13 @@ def bn_eval_scale_shift(gamma, beta, running_mean, running_var, eps, Cn, scale, 
                                               Cn, _ptr(scale), _ptr(shift), _stream()), "sm3_bn_eval_scale_shift")
 
 
-def bn_act(dtype, x, scale, shift, residual, relu, y, rows, Cn, out_f32=False, mask=None, views=1):
-    """rows: rows of ONE view; tensors hold `views` row ranges back to back, scale/shift are [views][C]."""
+def bn_act_colsum_rows(dtype, rows, Cn, views=1):
+    return _lib.load().sm3_bn_act_colsum_rows(rows, Cn, dtype, views)
+
+
+def bn_act(dtype, x, scale, shift, residual, relu, y, rows, Cn, out_f32=False, mask=None, views=1, colsum=None):
+    """rows: rows of ONE view; tensors hold `views` row ranges back to back, scale/shift are [views][C].
+    colsum: optional fp32 [views][bn_act_colsum_rows][C] -- per-block column sums of the stored outputs."""
     tdt = TORCH_DTYPE[dtype]
     _chk(x, tdt, "x"); _chk(residual, tdt, "residual"); _chk(scale, torch.float32); _chk(shift, torch.float32)
     _chk(y, torch.float32 if out_f32 else tdt, "y")
@@ -400,9 +527,17 @@ def bn_act(dtype, x, scale, shift, residual, relu, y, rows, Cn, out_f32=False, m
     tag = "bn_act"
     if _PROFILER is not None and getattr(_PROFILER, "detail", False):
         tag += f"|rows{views * rows}_C{Cn}_res{int(residual is not None)}"
+    _chk(colsum, torch.float32, "colsum")
+    if colsum is not None and (out_f32 or colsum.numel() < views * bn_act_colsum_rows(dtype, rows, Cn, views) * Cn):
+        raise ValueError("bn_act: colsum needs the storage dtype and [views][colsum_rows][C] floats")
     with _prof(tag, 0.0, _sz(dtype) * n * (2 if residual is None else 3)):
-        check(_lib.load().sm3_bn_act(dtype, _ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), int(relu),
-                                     int(out_f32), _ptr(y), _ptr(mask), rows, Cn, views, _stream()), "sm3_bn_act")
+        if colsum is not None:
+            check(_lib.load().sm3_bn_act_colsum(dtype, _ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), int(relu),
+                                                _ptr(y), _ptr(mask), _ptr(colsum), rows, Cn, views, _stream()),
+                  "sm3_bn_act_colsum")
+        else:
+            check(_lib.load().sm3_bn_act(dtype, _ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), int(relu),
+                                         int(out_f32), _ptr(y), _ptr(mask), rows, Cn, views, _stream()), "sm3_bn_act")
 
 
 def bn_add_bn_act(dtype, x, scale, shift, x2, scale2, shift2, relu, y, rows, Cn, mask=None, views=1):

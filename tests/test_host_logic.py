@@ -57,14 +57,17 @@ def test_param_store_views_are_channels_last_and_survive_load_state_dict(model):
     assert st.total == total and st.flat_p.numel() == total
 
 
-def test_engine_dry_run_sequences_and_bucket_schedule(model):
+@pytest.mark.parametrize("linbn", [True, False])
+def test_engine_dry_run_sequences_and_bucket_schedule(model, linbn):
     """One full trainer step on CPU tensors with the C ABI stubbed out: every ops wrapper's host-side size /
-    dtype validation runs, and the gradient-ready notifications must cover every parameter exactly once."""
+    dtype validation runs, and the gradient-ready notifications must cover every parameter exactly once.
+    linbn: conv3 -> bn3 backward by linearity (the 16-bit default, csrc/linbn.hip) or the two-pass form."""
     from sm3hip.trainer import SM3Trainer
     with installed() as fake:
         model.sm3_dtype = torch.bfloat16
         tr = SM3Trainer(model, lr=1e-3, data_parallel=False)
         eng = tr._engine()
+        eng.linbn = linbn
         x = [torch.randn(2, 3, 32, 32) for _ in range(4)]
         eng.prepare(torch.device("cpu"))
         ranges = []
@@ -76,17 +79,28 @@ def test_engine_dry_run_sequences_and_bucket_schedule(model):
             eng.grad_ready = None
 
         eng.backward = spy_backward
-        tr.step(x[:2], x[2:])
+        try:
+            tr.step(x[:2], x[2:])
+        finally:
+            del eng.backward  # the engine is cached on the (module-scoped) model
         calls = Counter(fake.calls)
     # 53 convs x 4 encoder passes + 3 linears x (2 in-modal + 4 cross) projector passes
     assert calls["sm3_bn_finalize"] == 53 * 4 + 3 * 6 == 230  # 212 BN2d + 18 BN1d per step
-    assert calls["sm3_conv_wgrad"] == 230 - 4 and calls["sm3_stem_wgrad_bn"] == 4  # bf16: direct stem (csrc/stem.hip)
-    # every BatchNorm gets its backward apply: the bn3 / downsample pair of a downsample block in one dual launch
-    # (the stem's is fused into its weight gradient)
-    assert calls["sm3_bn_bwd_apply2"] == 4 * 4 and calls["sm3_bn_bwd_apply"] == 230 - 2 * 16 - 4
+    nlin = 64 if linbn else 0  # 16 Bottlenecks x 4 encoder passes: conv3 -> bn3 units whose backward goes by linearity
+    assert calls["sm3_conv_wgrad"] == 230 - 4 - nlin and calls["sm3_stem_wgrad_bn"] == 4  # bf16: direct stem (csrc/stem.hip)
+    for name in ("sm3_conv_wgrad_cat", "sm3_linbn_stats", "sm3_linbn_coeffs", "sm3_linbn_wgrad_finish",
+                 "sm3_conv_dgrad_seg_bnfuse", "sm3_bn_act_colsum"):
+        assert calls[name] == nlin, name
+    if linbn:
+        # no backward-apply pass for bn3; the downsample BatchNorm of a block keeps its own (the stem's is fused into its
+        # weight gradient)
+        assert calls["sm3_bn_bwd_apply2"] == 0 and calls["sm3_bn_bwd_apply"] == 230 - 4 - 64
+    else:
+        # every BatchNorm gets its backward apply: the bn3 / downsample pair of a downsample block in one dual launch
+        assert calls["sm3_bn_bwd_apply2"] == 4 * 4 and calls["sm3_bn_bwd_apply"] == 230 - 2 * 16 - 4
     # ... and its forward apply, except where the consumer applies it: the 16 downsample BatchNorms inside their
     # block's join (sm3_bn_add_bn_act), the 4 stem BatchNorms inside the fused BN + ReLU + max-pool pass
-    assert calls["sm3_bn_add_bn_act"] == 16 and calls["sm3_bn_act"] == 230 - 16 - 16 - 4
+    assert calls["sm3_bn_add_bn_act"] == 16 and calls["sm3_bn_act"] + calls["sm3_bn_act_colsum"] == 230 - 16 - 16 - 4
     assert calls["sm3_ntxent_fused"] == 4 and calls["sm3_adamw"] == 1
     assert calls["sm3_stem_conv_fwd"] == 4 and calls["sm3_stem_im2col"] == 0
     assert calls["sm3_bn_relu_maxpool_fwd"] == 4 and calls["sm3_maxpool_bn_bwd"] == 4

@@ -1,0 +1,290 @@
+"""BatchNorm backward by linearity (csrc/linbn.hip) on the GPU: every new entry point against fp64 PyTorch of the same
+arithmetic, then the whole conv3 -> bn3 backward unit (the launch sequence of SM3Engine.conv3_backward_linbn) against the
+fp64 AUTOGRAD of the reference's modules (src/models/resnet.py:162-163: conv1x1 -> BatchNorm2d in train mode), and the
+encoder's gradients with the linear backward on and off."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DTS = [torch.bfloat16, torch.float16]
+IDS = ["bf16", "f16"]
+
+
+def _ops():
+    from sm3hip import ops
+    return ops
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def tol(dt):
+    return {torch.bfloat16: 1.2e-2, torch.float16: 2e-3}[dt]
+
+
+@pytest.mark.parametrize("dt", DTS, ids=IDS)
+@pytest.mark.parametrize("case", [(2, 1, 640, 256, 64), (2, 2, 1024, 256, 64), (1, 2, 768, 512, 128), (3, 1, 300, 128, 64)])
+def test_wgrad_cat_views(case, dt):
+    """P[v] = dz_v^T y_v and G[v] = y_v^T y_v from ONE launch over two views (sm3_conv_wgrad_cat)."""
+    ops = _ops()
+    N, V, HW, C, p = case
+    M = N * V * HW
+    g = torch.Generator().manual_seed(M + C)
+    dz = torch.randn(M, C, generator=g).to(dt)
+    y = torch.relu(torch.randn(M, p, generator=g)).to(dt)
+    code = ops.dtype_code(dt)
+    d = ops.fwd_desc(code, N * V, HW, 1, p, C, 1, 1, 0)
+    P = torch.zeros(V, C, p, device=dev())
+    G = torch.zeros(V, p, p, device=dev())
+    yd, dzd = y.to(dev()), dz.to(dev())
+    ops.conv_wgrad_cat(d, yd, dzd, P, yd, G, views=V)
+    torch.cuda.synchronize()
+    Mv = M // V
+    for v in range(V):
+        dzv, yv = dz[v * Mv:(v + 1) * Mv].double(), y[v * Mv:(v + 1) * Mv].double()
+        refP, refG = dzv.t() @ yv, yv.t() @ yv
+        assert (P[v].cpu().double() - refP).abs().max() < 2e-5 * refP.abs().max() + 1e-3
+        assert (G[v].cpu().double() - refG).abs().max() < 2e-5 * refG.abs().max() + 1e-3
+
+
+@pytest.mark.parametrize("dt", DTS + [torch.float32], ids=IDS + ["f32"])
+@pytest.mark.parametrize("case", [(1, 5000, 64), (2, 1664, 128), (2, 777, 512), (1, 40, 2048)])
+def test_bn_act_colsum(case, dt):
+    """sm3_bn_act_colsum: same output and mask as sm3_bn_act, plus per-block column sums of the STORED values."""
+    ops = _ops()
+    V, rows, C = case
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(V * rows, C, generator=g).to(dt).to(dev())
+    scale = (torch.rand(V * C, generator=g) + 0.5).to(dev())
+    shift = (torch.randn(V * C, generator=g) * 0.3).to(dev())
+    code = ops.dtype_code(dt)
+    E = 4 if dt == torch.float32 else 8
+    y0 = torch.empty_like(x)
+    m0 = torch.empty(V * rows * C // E, dtype=torch.uint8, device=dev())
+    ops.bn_act(code, x, scale, shift, None, True, y0, rows, C, mask=m0, views=V)
+    crow = ops.bn_act_colsum_rows(code, rows, C, V)
+    assert crow >= 1
+    cs = torch.full((V, crow, C), float("nan"), device=dev())
+    y1 = torch.empty_like(x)
+    m1 = torch.empty_like(m0)
+    ops.bn_act(code, x, scale, shift, None, True, y1, rows, C, mask=m1, views=V, colsum=cs)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and torch.equal(m0, m1)
+    got = cs.double().sum(1).cpu()
+    want = y1.double().reshape(V, rows, C).sum(1).cpu()
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("dt", DTS, ids=IDS)
+@pytest.mark.parametrize("with_x", [True, False])
+@pytest.mark.parametrize("case", [(1, 640, 256, 64), (2, 1024, 256, 64), (2, 512, 512, 128), (1, 333, 1024, 256),
+                                  (2, 128, 2048, 512)])
+def test_dgrad_two_segments_with_fused_bn_phase1(case, with_x, dt):
+    """sm3_conv_dgrad_seg_bnfuse: dz_out = mask(x0 w0^T + x1 w1^T + col_bias) with per-view banks, and the producer
+    BatchNorm's partial sums -- (sum dz, sum dz*xhat) with its x, (sum dz, 0) without."""
+    ops = _ops()
+    V, Mv, C, p = case
+    M = V * Mv
+    g = torch.Generator().manual_seed(M + C + p)
+    x0 = torch.randn(M, C, generator=g).to(dt)
+    x1 = torch.randn(M, p, generator=g).to(dt)
+    w0 = (torch.randn(V, p, C, generator=g) / math.sqrt(C)).to(dt)
+    w1 = (torch.randn(V, p, p, generator=g) / math.sqrt(p)).to(dt)
+    bias = torch.randn(V, p, generator=g)
+    bx = torch.randn(M, p, generator=g).to(dt)
+    mean, invstd = torch.randn(V, p, generator=g) * 0.2, torch.rand(V, p, generator=g) + 0.5
+    mask_bits = torch.rand(M, p, generator=g) > 0.4
+    code = ops.dtype_code(dt)
+    mb = mask_bits.reshape(M, p // 8, 8).to(torch.int32)
+    mask = (mb * (1 << torch.arange(8, dtype=torch.int32))).sum(-1).to(torch.uint8).reshape(-1)
+    d = ops.dgrad_descs(code, V, Mv, 1, p, C, 1, 1, 0)[0][0]
+    assert (d.Ci, d.Co) == (C, p)
+    prow = ops.conv_partial_rows(d)
+    part = torch.full((2 * prow + 3, 2, p), float("nan"), device=dev())
+    out = torch.empty(M, p, dtype=dt, device=dev())
+    off1 = prow // V + 3 if V == 2 else 0
+    n = ops.conv_dgrad_seg_bnfuse(d, x0.to(dev()), w0.to(dev()), x1.to(dev()), w1.to(dev()), bias.to(dev()), out,
+                                  mask.to(dev()), bx.to(dev()) if with_x else None, mean.reshape(-1).to(dev()),
+                                  invstd.reshape(-1).to(dev()), part, 0, views=V, row_offset_view1=off1,
+                                  w_view_stride=p * C, w1_view_stride=p * p)
+    torch.cuda.synchronize()
+    assert n == prow
+    for v in range(V):
+        sl = slice(v * Mv, (v + 1) * Mv)
+        ref = x0[sl].double() @ w0[v].double().t() + x1[sl].double() @ w1[v].double().t() + bias[v].double()
+        ref = ref * mask_bits[sl]
+        got = out[sl].double().cpu()
+        sc = ref.abs().max().item()
+        assert (got - ref).abs().max().item() < tol(dt) * sc
+        rows_v = prow // V
+        pr = part[(off1 if v else 0):(off1 if v else 0) + rows_v].double().cpu().sum(0)
+        assert torch.allclose(pr[0], got.sum(0), rtol=1e-4, atol=1e-3 * sc)
+        if with_x:
+            xh = (bx[sl].double() - mean[v].double()) * invstd[v].double()
+            want2 = (got * xh).sum(0)
+            assert torch.allclose(pr[1], want2, rtol=1e-4, atol=2e-3 * sc * xh.abs().max().item())
+        else:
+            assert torch.equal(pr[1], torch.zeros(p, dtype=torch.float64))
+
+
+def _unit_reference(y, W, gamma, beta, dz, eps=1e-5):
+    """fp64 autograd of conv1x1 -> BatchNorm (train) per view; returns dy, dW, dgamma, dbeta summed over views."""
+    V = y.shape[0]
+    Wt = W.double().clone().requires_grad_()
+    ga = gamma.double().clone().requires_grad_()
+    be = beta.double().clone().requires_grad_()
+    dys = []
+    for v in range(V):
+        yv = y[v].double().clone().requires_grad_()
+        x = yv @ Wt.t()
+        mu, var = x.mean(0), x.var(0, unbiased=False)
+        z = (x - mu) * (var + eps).rsqrt() * ga + be
+        z.backward(dz[v].double())
+        dys.append(yv.grad)
+    return torch.stack(dys), Wt.grad, ga.grad, be.grad
+
+
+@pytest.mark.parametrize("dt", DTS, ids=IDS)
+@pytest.mark.parametrize("case", [(1, 1280, 256, 64), (2, 1024, 256, 64), (2, 640, 512, 128), (2, 256, 1024, 256)])
+def test_conv_bn_backward_by_linearity_matches_fp64_autograd(case, dt):
+    """The launch sequence of SM3Engine.conv3_backward_linbn on one conv3 -> bn3 unit against the fp64 autograd of
+    conv1x1 -> BatchNorm2d(train) (src/models/resnet.py:162-163) on the same (rounded) operands: data gradient, weight
+    gradient, d(gamma), d(beta)."""
+    ops = _ops()
+    from sm3hip._lib import SM3_F32
+    V, Mv, C, p = case
+    M = V * Mv
+    g = torch.Generator().manual_seed(7 * M + C)
+    code = ops.dtype_code(dt)
+    y = torch.relu(torch.randn(V, Mv, p, generator=g) + 0.3).to(dt)
+    Wm = torch.randn(C, p, generator=g) / math.sqrt(p)            # fp32 master [C][p]
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    dz = (torch.randn(V, Mv, C, generator=g) * (torch.rand(V, Mv, C, generator=g) > 0.4)).to(dt)
+    Wr = Wm.to(dt)                                                # the bank the forward used
+    ref_dy, ref_dW, ref_dg, ref_db = _unit_reference(y.float(), Wr.float(), gamma, beta, dz.float())
+    # forward statistics as the engine has them: of the STORED convolution output
+    x = (y.float().double() @ Wr.float().double().t()).to(dt).double()   # [V][Mv][C]
+    mean = x.mean(1).float()
+    invstd = (x.var(1, unbiased=False) + 1e-5).rsqrt().float()
+
+    D = dev()
+    yd, dzd = y.reshape(M, p).to(D), dz.reshape(M, C).to(D)
+    w_master = Wm.to(D)
+    w_fwd = torch.empty(C, p, dtype=dt, device=D)
+    w_dg = torch.empty(p, 1, C, dtype=dt, device=D)
+    ops.weight_prep(code, w_master, C, 1, p, w_fwd, p, w_dg)
+    # column sums of y through the apply kernel (identity scale/shift reproduces y)
+    crow = ops.bn_act_colsum_rows(code, Mv, p, V)
+    cs = torch.empty(V * crow * p, device=D)
+    ytmp = torch.empty_like(yd)
+    ops.bn_act(code, yd, torch.ones(V * p, device=D), torch.zeros(V * p, device=D), None, False, ytmp, Mv, p, views=V,
+               colsum=cs)
+    assert torch.equal(ytmp, yd)
+    # sum(dz) partial rows as a producing data-gradient epilogue leaves them: here from the standalone reduce kernel
+    prow = ops.bn_bwd_partial_rows(Mv, C)
+    bpart = torch.empty(V * prow * 2 * C, device=D)
+    xd = x.reshape(M, C).to(dt).to(D)
+    ops.bn_bwd_reduce(code, dzd, None, xd, mean.reshape(-1).to(D), invstd.reshape(-1).to(D), None, Mv, C, bpart, views=V)
+    lsums = torch.empty(V * 2 * C, dtype=torch.float64, device=D)
+    ops.bn_stats_reduce(bpart, prow, C, lsums, views=V)
+    want_s2 = lsums.reshape(V, 2, C)[:, 1].clone()
+    lsums.reshape(V, 2, C)[:, 1] = float("nan")   # the linear path must produce this half itself
+
+    PG = torch.zeros(V * (C + p) * p, device=D)
+    P, G = PG[: V * C * p], PG[V * C * p:]
+    dw_desc = ops.fwd_desc(code, V, Mv, 1, p, C, 1, 1, 0)
+    ops.conv_wgrad_cat(dw_desc, yd, dzd, P, yd, G, views=V)
+    s = torch.empty(V * p, device=D)
+    mean_d, invstd_d = mean.reshape(-1).to(D), invstd.reshape(-1).to(D)
+    ops.linbn_stats(code, P, w_fwd, mean_d, invstd_d, lsums, cs, crow, s, C, p, V)
+    torch.cuda.synchronize()
+    got_s2 = lsums.reshape(V, 2, C)[:, 1]
+    assert torch.allclose(got_s2, want_s2, rtol=2e-2, atol=2e-2 * want_s2.abs().max().item())  # stored x vs y W^T
+    assert torch.allclose(s.reshape(V, p).cpu().double(), y.double().sum(1), rtol=1e-5)
+
+    wa = torch.empty(V * p * C, dtype=dt, device=D)
+    wbn = torch.empty(V * p * C, dtype=dt, device=D)
+    cconst = torch.empty(V * p, device=D)
+    coef = torch.empty(V * 4 * C, device=D)
+    dgamma, dbeta = torch.zeros(C, device=D), torch.zeros(C, device=D)
+    ops.linbn_coeffs(code, w_dg, gamma.to(D), mean_d, invstd_d, lsums, Mv, lsums, dgamma, dbeta, wa, wbn, cconst, coef, C, p, V)
+    Hn = torch.empty(V * p * p, dtype=dt, device=D)
+    ops.conv_gemm(ops.fwd_desc(code, V * p, 1, 1, C, p, 1, 1, 0), wbn, w_dg, Hn)
+    Tm = torch.empty(C * V * p, device=D)
+    ops.conv_gemm(ops.fwd_desc(SM3_F32, C, 1, 1, p, V * p, 1, 1, 0), w_master, G, Tm)
+    dd = ops.dgrad_descs(code, V, Mv, 1, p, C, 1, 1, 0)[0][0]
+    dy = torch.empty(M, p, dtype=dt, device=D)
+    part = torch.empty(ops.conv_partial_rows(dd) * 2 * p, device=D)
+    ops.conv_dgrad_seg_bnfuse(dd, dzd, wa, yd, Hn, cconst, dy, None, None, None, None, part, 0, views=V,
+                              row_offset_view1=ops.conv_partial_rows(dd) // V, w_view_stride=p * C, w1_view_stride=p * p)
+    dW = torch.zeros(C, p, device=D)
+    ops.linbn_wgrad_finish(P, Tm, s, coef, dW, C, p, V)
+    torch.cuda.synchronize()
+
+    t = tol(dt)
+    got_dy = dy.reshape(V, Mv, p).double().cpu()
+    assert (got_dy - ref_dy).abs().max().item() < 2 * t * ref_dy.abs().max().item()
+    assert ((got_dy - ref_dy).norm() / ref_dy.norm()).item() < t
+    assert ((dW.double().cpu() - ref_dW).norm() / ref_dW.norm()).item() < t
+    assert (dW.double().cpu() - ref_dW).abs().max().item() < 2 * t * ref_dW.abs().max().item()
+    assert torch.allclose(dbeta.double().cpu(), ref_db, rtol=1e-4, atol=1e-3 * ref_db.abs().max().item())
+    assert ((dgamma.double().cpu() - ref_dg).norm() / ref_dg.norm()).item() < t
+
+
+@pytest.mark.parametrize("dt", DTS, ids=IDS)
+@pytest.mark.parametrize("views", [1, 2])
+def test_encoder_gradients_linear_backward_on_and_off(dt, views):
+    """A whole ResNet-50 encoder backward with conv3 -> bn3 by linearity against the two-pass BatchNorm backward, same
+    weights and inputs, both measured against the exact-f32 mode of the same engine: the linear form is no further from
+    the f32 gradient than the two-pass form is (they differ only in where the 16-bit roundings fall; through 53 train-mode
+    BatchNorms either form is several per cent away from f32 in the earliest layers).  Features and running statistics
+    are bit-identical: the forward is the same code."""
+    from src.models import resnet
+    from sm3hip.engine import SM3Engine
+    torch.manual_seed(3)
+    N = 8 if views == 1 else 16
+    x = torch.randn(N, 3, 64, 64).to(dev())
+    res = {}
+    for mode, lin in (("f32", False), ("off", False), ("on", True)):
+        torch.manual_seed(5)
+        m = resnet.resnet50()
+        m.fc = torch.nn.Identity()
+        m.to(dev()).train()
+        eng = SM3Engine(m, dtype=torch.float32 if mode == "f32" else dt, kind="encoder")
+        eng.linbn = lin
+        eng.prepare(dev())
+        eng.refresh_weights()
+        plan = eng.branches["main"][0]
+        f32 = torch.empty(N, 2048, device=dev())
+        ctx = []
+        if views == 2 and not eng.pair_ok(N // 2, 64, 64):
+            pytest.skip("batch too small for two views in one pass")
+        eng.encoder_forward(plan, x, True, f32, None, ctx, views=views)
+        gen = torch.Generator().manual_seed(11)
+        dfeat = (torch.randn(N, 2048, generator=gen) * 1e-2).to(eng.tdt).to(dev())
+        eng.store.flat_g.zero_()
+        eng.encoder_backward(ctx[0], dfeat)
+        torch.cuda.synchronize()
+        res[mode] = (f32.clone(), eng.store.flat_g.clone(),
+                     {k: v.clone() for k, v in m.state_dict().items() if "running" in k}, eng.store)
+    assert torch.equal(res["off"][0], res["on"][0])
+    for k in res["off"][2]:
+        assert torch.equal(res["off"][2][k], res["on"][2][k]), k
+    st = res["on"][3]
+    ref = res["f32"][1].double()
+    e_off = ((res["off"][1].double() - ref).norm() / ref.norm()).item()
+    e_on = ((res["on"][1].double() - ref).norm() / ref.norm()).item()
+    print(f"whole-gradient relative error vs f32: two-pass {e_off:.4f}, linear {e_on:.4f}")
+    assert e_on < 1.25 * e_off + 1e-3
+    worse = []
+    for name in st.names:
+        r = st._view(ref, name)
+        a = ((st._view(res["off"][1], name).double() - r).norm() / (r.norm() + 1e-30)).item()
+        b = ((st._view(res["on"][1], name).double() - r).norm() / (r.norm() + 1e-30)).item()
+        if b > 2.0 * a + 2e-2:
+            worse.append((name, a, b))
+    assert not worse, worse[:8]
