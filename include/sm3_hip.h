@@ -134,10 +134,10 @@ int sm3_conv_bn_eval(const sm3_conv_desc* d, const void* x, const void* w, const
  * dy is dense [N*Ho*Wo, Co]; dw is fp32 and is accumulated into (float atomics, split over pixels).
  * Columns wtap[t]*Ci+ci >= w_row_stride are dropped (the zero-padded K tail of the stem im2col). */
 int sm3_conv_wgrad(const sm3_conv_desc* d, const void* x, const void* dy, float* dw, void* stream);
-/* The same product with dY the channel concatenation [dy (d->Co) | dy1 (Co1)] of two tensors over the same pixels (rows
- * of the second part accumulate into dw1, same row layout), over `views` equal pixel ranges that accumulate into
- * dw + v * dw_view_stride / dw1 + v * dw1_view_stride: with dy = dz, dy1 = x = the convolution's input this gives
- * P = dz^T x and the Gram matrix G = x^T x per view in ONE launch that reads dz once.  d->Co a multiple of 128. */
+/* The same product over `views` equal pixel ranges that accumulate into dw + v * dw_view_stride (per-view weight-gradient
+ * products: P_v = dz_v^T x_v, or with dy = x the Gram matrix G_v = x_v^T x_v), and optionally with dY the channel
+ * concatenation [dy (d->Co) | dy1 (Co1)] of two tensors over the same pixels (rows of the second part accumulate into
+ * dw1 + v * dw1_view_stride; d->Co then a multiple of 128).  Co1 = 0: dy1 / dw1 unused. */
 int sm3_conv_wgrad_cat(const sm3_conv_desc* d, const void* x, const void* dy, float* dw, const void* dy1, int Co1,
                        float* dw1, int views, int64_t dw_view_stride, int64_t dw1_view_stride, void* stream);
 
@@ -225,26 +225,28 @@ int sm3_bn_bwd_apply2(int dtype, const void* dz, double count, const sm3_bn_appl
  * W: [C, p]) and dx = a (dz - m1) - b (x - mu) [a = gamma invstd, b = a invstd mean(dz xhat), m1 = mean(dz)]:
  *   P = dz^T y, G = y^T y (sm3_conv_wgrad_cat), s = sum_m y (sm3_bn_act_colsum)
  *   sum_m dz xhat = invstd (rowdot(W, P) - mu sum_m dz)                                  (sm3_linbn_stats)
- *   dy = dz (diag(a) W) - y H + const, H = W^T diag(b) W          (sm3_linbn_coeffs, sm3_conv_gather_gemm for H,
+ *   dy = dz (diag(a) W) - y H + const, H = W^T diag(b) W          (sm3_linbn_coeffs, sm3_linbn_post for H,
  *                                                                   sm3_conv_dgrad_seg_bnfuse)
- *   dW += diag(a)(P - m1 s^T) - diag(b)(W G - mu s^T)             (sm3_conv_gather_gemm in SM3_F32 for W G,
- *                                                                   sm3_linbn_wgrad_finish)
+ *   dW += diag(a)(P - m1 s^T) - diag(b)(W G - mu s^T)             (sm3_linbn_post, W G on the exact-f32 MFMA)
  * so sm3_bn_bwd_apply's pass over dz / x / dx (and every backward read of x) is never made.  All per-channel vectors
  * are [views][C].
  * ------------------------------------------------------------------------------------------ */
-/* lsums: [views][2C] fp64 with sum(dz) in [0, C) on entry; [C, 2C) is written.  P: [views][C][p] fp32; w_fwd: dtype
- * [C][p]; colsum_partials: [views][colsum_rows][p]; s_out: [views][p] fp32. */
-int sm3_linbn_stats(int dtype, const float* P, const void* w_fwd, const float* mean, const float* invstd, double* lsums,
-                    const float* colsum_partials, int colsum_rows, float* s_out, int C, int p, int views, void* stream);
+/* reduce_ws / groups: what sm3_bn_stats_reduce(partials of (dz, .), sums = NULL) left -- its stage B runs here.
+ * lsums: [views][2C] fp64, both halves written (sum dz | sum dz xhat).  P: [views][C][p] fp32; w_fwd: dtype [C][p];
+ * colsum_partials: [views][colsum_rows][p]; s_out: [views][p] fp32. */
+int sm3_linbn_stats(int dtype, const float* P, const void* w_fwd, const float* mean, const float* invstd,
+                    const double* reduce_ws, int groups, double* lsums, const float* colsum_partials, int colsum_rows,
+                    float* s_out, int C, int p, int views, void* stream);
 /* From the (all-reduced) sums: wa = diag(a) W and wbn = -diag(b) W in data-gradient order (dtype [views][p][C], from
  * w_dgrad [p][C]), col_const [views][p] = (b mu - a m1) W, coef [views][4][C] = (a, b, m1, mu);
  * dgamma += local sum(dz xhat), dbeta += local sum(dz) (NULL to skip).  count: elements per channel of one view. */
 int sm3_linbn_coeffs(int dtype, const void* w_dgrad, const float* gamma, const float* mean, const float* invstd,
                      const double* global_sums, double count, const double* local_sums, float* dgamma, float* dbeta,
                      void* wa, void* wbn, float* col_const, float* coef, int C, int p, int views, void* stream);
-/* dw[C][p] += sum_v diag(a_v)(P_v - m1_v s_v^T) - diag(b_v)(Tm[:, v p : (v+1) p] - mu_v s_v^T), Tm = W G: [C][views p] */
-int sm3_linbn_wgrad_finish(const float* P, const float* Tm, const float* s, const float* coef, float* dw, int C, int p,
-                           int views, void* stream);
+/* The two small products, one launch of 32 x 32 MFMA tiles:  hn [views][p][p] (dtype) = wbn_v w_dgrad^T = -H_v, and
+ * dw[C][p] += sum_v diag(a_v)(P_v - m1_v s_v^T) - diag(b_v)(w_fwd G_v - mu_v s_v^T).  C % 128 == 0, p % 32 == 0. */
+int sm3_linbn_post(int dtype, const void* wbn, const void* w_dgrad, void* hn, const float* P, const float* G,
+                   const void* w_fwd, const float* s, const float* coef, float* dw, int C, int p, int views, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Stem, pooling.  replaces resnet.py:208-213,224,294-305.

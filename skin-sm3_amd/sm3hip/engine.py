@@ -163,7 +163,7 @@ class BNUnit:
 class Rec:
     """What one conv+BN(+act) application saves for backward."""
     __slots__ = ("cu", "bu", "N", "H", "W", "Ho", "Wo", "x_in", "xo", "mean", "invstd", "y", "relu", "mask", "V",
-                 "frozen_stats", "scale", "shift", "colsum", "colsum_rows", "linbn")
+                 "frozen_stats", "scale", "shift", "colsum", "colsum_rows", "linbn", "gram")
 
 
 class EncoderPlan:
@@ -567,6 +567,7 @@ class SM3Engine:
             r.scale = r.shift = None
             r.colsum, r.colsum_rows = (cs, cs_rows) if apply else (None, None)
             r.linbn = False
+            r.gram = None
             save.append(r)
         return (y_out if apply else xo), Ho, Wo
 
@@ -660,12 +661,21 @@ class SM3Engine:
             cache[key] = ops.fwd_desc(dtype, M, 1, 1, K, N, 1, 1, 0)
         return cache[key]
 
-    def conv3_backward_linbn(self, r3, r2, dz, bpart, prow, rd=None):
+    def _lin_conv_desc(self, dtype, N, H, W, Ci, Co):
+        """Descriptor of a 1x1 / stride-1 convolution Ci -> Co over an [N, H, W] map (weight-gradient-kernel launches
+        that are not tied to a ConvUnit: the Gram matrix of an activation)."""
+        cache = self.__dict__.setdefault("_lin_descs", {})
+        key = ("conv", dtype, N, H, W, Ci, Co)
+        if key not in cache:
+            cache[key] = ops.fwd_desc(dtype, N, H, W, Ci, Co, 1, 1, 0)
+        return cache[key]
+
+    def conv3_backward_linbn(self, r3, r2, dz, bpart, prow, P, rd=None):
         """Backward of conv3 -> bn3 BY LINEARITY (csrc/linbn.hip; reference: the autograd backward of
         src/models/resnet.py:162-163).  dz: the masked gradient of the block output [M, C]; bpart: its partial rows
-        [V][prow][2][C] (only sum(dz) is used) as left by the producing data-gradient launch.  No pass over bn3's input or
-        output: the weight gradient runs on dz itself (plus a [p, p] Gram block of conv3's input y2), the data gradient
-        is one GEMM over the two K segments [dz | y2].  Accumulates d(conv3.weight), d(bn3.weight/bias).
+        [V][prow][2][C] (only sum(dz) is used) as left by the producing data-gradient launch; P: zeroed fp32 [V][C][p].
+        No pass over bn3's input or output: the weight gradient runs on dz itself (the [p, p] Gram matrix of conv3's input
+        y2 came with the forward pass), the data gradient is one GEMM over the two K segments [dz | y2].  Accumulates d(conv3.weight), d(bn3.weight/bias).
         rd: the downsample unit of the block, whose BatchNorm received the same dz (resnet.py:164-172): its two-pass
         backward runs alongside -- statistics in the SAME SyncBN exchange as bn3's, apply pass in place over dz once the
         GEMMs above have read it.
@@ -675,18 +685,16 @@ class SM3Engine:
         M = r3.xo.shape[0]
         rows = M // V
         y2 = r3.x_in
-        # 1. P = dz^T y2 [V][C][p] and G = y2^T y2 [V][p][p]: the weight-gradient kernel, dz read once
-        PG = self._work("linbn_PG", V * (C + p) * p)
-        PG.zero_()
-        P, G = PG[: V * C * p], PG[V * C * p: V * (C + p) * p]
-        ops.conv_wgrad_cat(cu.wgrad_desc(self.dtype, r3.N, r3.H, r3.W), y2, dz, P, y2, G, views=V)
+        # 1. P = dz^T y2 [V][C][p]: the weight-gradient kernel on dz itself
+        G = r2.gram
+        ops.conv_wgrad_cat(cu.wgrad_desc(self.dtype, r3.N, r3.H, r3.W), y2, dz, P, views=V)
         # 2. local sums [bn3 | downsample][V][2C]: sum(dz) from the fused partial rows, sum(dz * xhat) from P
         n = V * 2 * C
         tot = n * (2 if rd is not None else 1)
         s = self._work("linbn_s", V * p)
         lsums = self._work("lsums2", 2 * 2 * 2 * 2048, torch.float64)
-        ops.bn_stats_reduce(bpart, prow, C, lsums, views=V)
-        ops.linbn_stats(self.dtype, P, cu.w_fwd, r3.mean, r3.invstd, lsums, r2.colsum, r2.colsum_rows, s, C, p, V)
+        ws, groups = ops.bn_stats_reduce(bpart, prow, C, None, views=V)  # stage A; stage B runs inside linbn_stats
+        ops.linbn_stats(self.dtype, P, cu.w_fwd, r3.mean, r3.invstd, ws, groups, lsums, r2.colsum, r2.colsum_rows, s, C, p, V)
         if rd is not None:
             prow_d = ops.bn_bwd_partial_rows(rows, C)
             dpart = self._work("partials_d", V * prow_d * 2 * C)
@@ -707,12 +715,11 @@ class SM3Engine:
         ops.linbn_coeffs(self.dtype, cu.w_dgrad, self._p(bu.name + ".weight") if aff else None, r3.mean, r3.invstd,
                          gsums[:n], count, lsums[:n], self._g(bu.name + ".weight") if aff else None,
                          self._g(bu.name + ".bias") if aff else None, wa, wbn, cconst, coef, C, p, V)
-        # 4. -H_v = (-diag(b_v) W)^T W  [V p, p]   and   5. Tm = W G  [C, V p] (exact f32)
+        # 4. -H_v = (-diag(b_v) W)^T W [V][p][p], and d(conv3.weight) += diag(a)(P - m1 s^T) - diag(b)(W G - mu s^T):
+        #    32 x 32 MFMA tiles of one launch
         Hn = self._work("linbn_H", V * p * p, self.tdt)
-        ops.conv_gemm(self._lin_desc(self.dtype, V * p, C, p), wbn[: V * p * C], cu.w_dgrad, Hn[: V * p * p])
-        Tm = self._work("linbn_T", C * V * p)
-        ops.conv_gemm(self._lin_desc(SM3_F32, C, p, V * p), self._p(cu.name + ".weight"), G, Tm[: C * V * p])
-        # 6. data gradient [dz | y2] x [diag(a) W ; -H]^T + const, with bn2's ReLU mask and phase 1 in the epilogue
+        ops.linbn_post(self.dtype, wbn, cu.w_dgrad, Hn, P, G, cu.w_fwd, s, coef, self._g(cu.name + ".weight"), C, p, V)
+        # 5. data gradient [dz | y2] x [diag(a) W ; -H]^T + const, with bn2's ReLU mask and phase 1 in the epilogue
         descs, full = cu.dgrad_descs(self.dtype, r3.N, r3.H, r3.W)
         dd = descs[0]
         dz2 = torch.empty(M, p, dtype=self.tdt, device=dz.device)
@@ -722,10 +729,8 @@ class SM3Engine:
                                           r2.mask if r2.relu else None, None if r2.linbn else r2.xo, r2.mean, r2.invstd,
                                           part, 0, views=V, row_offset_view1=total // V, w_view_stride=p * C,
                                           w1_view_stride=p * p)
-        # 7. d(conv3.weight) += diag(a)(P - m1 s^T) - diag(b)(W G - mu s^T)
-        ops.linbn_wgrad_finish(P, Tm[: C * V * p], s[: V * p], coef[: V * 4 * C], self._g(cu.name + ".weight"), C, p, V)
         dxd = None
-        if rd is not None:  # the downsample BatchNorm's apply pass, in place over dz (its last reader was launch 6)
+        if rd is not None:  # the downsample BatchNorm's apply pass, in place over dz (its last reader was launch 5)
             affd = rd.bu.affine
             ops.bn_bwd_apply(self.dtype, dz, rd.xo, rd.mean, rd.invstd, self._p(rd.bu.name + ".weight") if affd else None,
                              gsums[n: 2 * n], count, lsums[n: 2 * n], self._g(rd.bu.name + ".weight") if affd else None,
@@ -865,11 +870,24 @@ class SM3Engine:
         del stem_in
         cur, h, w = p, Hp, Wp
         block_recs = []
-        for blk in plan.blocks:
+        # conv3 -> bn3 backward by linearity needs sum(y2) and the Gram matrix y2^T y2 of conv3's input per view: the first
+        # from bn2's apply pass, the second from one launch of the weight-gradient kernel on y2 alone.  All blocks' Gram
+        # matrices live in one buffer, zeroed once (the kernel accumulates with atomics).
+        Vt = self._V if train else 1
+        lin_ok = [self.linbn and train and save is not None and b["c3"].Co % 128 == 0 and b["c3"].Ci % 64 == 0
+                  for b in plan.blocks]
+        gram_all = torch.zeros(sum(Vt * b["c3"].Ci ** 2 for b, ok in zip(plan.blocks, lin_ok) if ok), dtype=torch.float32,
+                               device=x.device) if any(lin_ok) else None
+        gram_off = 0
+        for blk, lin in zip(plan.blocks, lin_ok):
             br = [] if save is not None else None
             y1, h1, w1 = self.conv_bn(blk["c1"], blk["b1"], cur, N, h, w, True, None, train, br)
-            lin = self.linbn and train and br is not None and blk["c3"].Co % 128 == 0 and blk["c3"].Ci % 64 == 0
             y2, h2, w2 = self.conv_bn(blk["c2"], blk["b2"], y1, N, h1, w1, True, None, train, br, colsum=lin)
+            if lin and br[1].colsum is not None:
+                pp = blk["c3"].Ci
+                br[1].gram = gram_all[gram_off: gram_off + Vt * pp * pp]
+                gram_off += Vt * pp * pp
+                ops.conv_wgrad_cat(self._lin_conv_desc(self.dtype, N, h2, w2, pp, pp), y2, y2, br[1].gram, views=Vt)
             ra = None
             pend = None
             if "cd" in blk and lazy:
@@ -885,8 +903,8 @@ class SM3Engine:
                 idn = cur
             y3, h3, w3 = self.conv_bn(blk["c3"], blk["b3"], y2, N, h2, w2, True, idn, train, br, res_affine=ra,
                                       pending=pend)
-            if lin and br[1].colsum is not None:
-                br[-1].linbn = True  # backward of conv3 -> bn3 by linearity; needs br[1].colsum (sum of y2)
+            if lin and br[1].gram is not None:
+                br[-1].linbn = True  # backward of conv3 -> bn3 by linearity; needs br[1].colsum / .gram (moments of y2)
             block_recs.append(br)
             cur, h, w = y3, h3, w3
         ops.avgpool_fwd(self.dtype, cur, feat_f32, feat_t, N, h * w, plan.out_dim)
@@ -903,6 +921,10 @@ class SM3Engine:
         dcur = torch.empty(N * h * w, plan.out_dim, dtype=self.tdt, device=dfeat.device)
         ops.avgpool_bwd(self.dtype, dfeat, dcur, N, h * w, plan.out_dim)
         fr = None  # rows of fused BN-backward partials that came with dcur
+        # the weight-gradient products dz^T y2 of the blocks that go by linearity: one zeroed buffer for all of them
+        lin_sz = {bi: br[-1].V * br[-1].cu.Co * br[-1].cu.Ci for bi, br in enumerate(ctx["blocks"]) if br[-1].linbn}
+        lin_P = torch.zeros(sum(lin_sz.values()), dtype=torch.float32, device=dfeat.device) if lin_sz else None
+        lin_off = 0
         for bi in range(len(plan.blocks) - 1, -1, -1):
             blk, br = plan.blocks[bi], ctx["blocks"][bi]
             if "cd" in blk:
@@ -920,7 +942,9 @@ class SM3Engine:
                                       mask=r3.mask, views=V3)
                 else:
                     prow, bpart = fr, self._ws[(self._lane, "fz_partials")]
-                dy2, fr2, dxd = self.conv3_backward_linbn(r3, r2, dcur, bpart, prow, rd=rd)
+                dy2, fr2, dxd = self.conv3_backward_linbn(r3, r2, dcur, bpart, prow,
+                                                          lin_P[lin_off: lin_off + lin_sz[bi]], rd=rd)
+                lin_off += lin_sz[bi]
                 dz = None if rd is not None else dcur
             else:
                 if rd is not None:

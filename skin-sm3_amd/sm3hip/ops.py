@@ -382,21 +382,24 @@ def conv_wgrad(desc, x, dy, dw):
         check(_lib.load().sm3_conv_wgrad(C.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _stream()), "sm3_conv_wgrad")
 
 
-def conv_wgrad_cat(desc, x, dy, dw, dy1, dw1, views=1):
-    """P[v] = dy_v^T x_v -> dw [views][Co][Ci] and G[v] = dy1_v^T x_v -> dw1 [views][Co1][Ci] in one launch
+def conv_wgrad_cat(desc, x, dy, dw, dy1=None, dw1=None, views=1):
+    """P[v] = dy_v^T x_v -> dw [views][Co][Ci] (and, with dy1, G[v] = dy1_v^T x_v -> dw1 [views][Co1][Ci]) in one launch
     (sm3_conv_wgrad_cat), accumulated into fp32 buffers the caller zeroed."""
     tdt = TORCH_DTYPE[desc.dtype]
     _chk(x, tdt, "x"); _chk(dy, tdt, "dy"); _chk(dy1, tdt, "dy1"); _chk(dw, torch.float32, "dw"); _chk(dw1, torch.float32, "dw1")
     M = desc.N * desc.Ho * desc.Wo
-    if x.numel() != desc.N * desc.Hi * desc.Wi * desc.Ci or dy.numel() != M * desc.Co or dy1.numel() % M or M % views:
+    if x.numel() != desc.N * desc.Hi * desc.Wi * desc.Ci or dy.numel() != M * desc.Co or M % views:
         raise ValueError("conv_wgrad_cat: operand size does not match descriptor")
-    Co1 = dy1.numel() // M
-    if desc.Co % 128 or dw.numel() < views * desc.Co * desc.w_row_stride or dw1.numel() < views * Co1 * desc.w_row_stride:
+    if (dy1 is None) != (dw1 is None) or (dy1 is not None and dy1.numel() % M):
+        raise ValueError("conv_wgrad_cat: dy1 and dw1 go together, dy1 over the same pixels")
+    Co1 = dy1.numel() // M if dy1 is not None else 0
+    if (Co1 and desc.Co % 128) or dw.numel() < views * desc.Co * desc.w_row_stride or \
+            (Co1 and dw1.numel() < views * Co1 * desc.w_row_stride):
         raise ValueError("conv_wgrad_cat: Co must be a multiple of 128; dw / dw1 sized [views][rows][w_row_stride]")
     sz = _sz(desc.dtype)
     tag = "conv_wgrad"
     if _PROFILER is not None and getattr(_PROFILER, "detail", False):
-        tag += f"|M{M}_K{desc.ntaps}x{desc.Ci}_N{desc.Co}+{Co1}_cat"
+        tag += f"|M{M}_K{desc.ntaps}x{desc.Ci}_N{desc.Co}+{Co1}_v{views}"
     with _prof(tag, 2.0 * M * desc.Co * desc.ntaps * desc.Ci,
                sz * (x.numel() + dy.numel()) + 4 * views * (desc.Co + Co1) * desc.w_row_stride):
         check(_lib.load().sm3_conv_wgrad_cat(C.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _ptr(dy1), Co1, _ptr(dw1), views,
@@ -404,16 +407,20 @@ def conv_wgrad_cat(desc, x, dy, dw, dy1, dw1, views=1):
               "sm3_conv_wgrad_cat")
 
 
-def linbn_stats(dtype, P, w_fwd, mean, invstd, lsums, colsum, colsum_rows, s_out, Cn, p, views=1):
-    """lsums[v][C:2C] = sum(dz * xhat) from P = dz^T y; s_out[v] = column sums of y (sm3_linbn_stats)."""
+def linbn_stats(dtype, P, w_fwd, mean, invstd, reduce_ws, groups, lsums, colsum, colsum_rows, s_out, Cn, p, views=1):
+    """lsums[v] = (sum dz | sum dz * xhat): the first from stage A of bn_stats_reduce (reduce_ws, groups), the second from
+    P = dz^T y; s_out[v] = column sums of y (sm3_linbn_stats)."""
     _chk(P, torch.float32, "P"); _chk(w_fwd, TORCH_DTYPE[dtype], "w_fwd"); _chk(mean, torch.float32); _chk(invstd, torch.float32)
     _chk(lsums, torch.float64, "lsums"); _chk(colsum, torch.float32, "colsum"); _chk(s_out, torch.float32, "s_out")
+    _chk(reduce_ws, torch.float64, "reduce_ws")
     if P.numel() < views * Cn * p or w_fwd.numel() != Cn * p or mean.numel() < views * Cn or invstd.numel() < views * Cn or \
-            lsums.numel() < views * 2 * Cn or colsum.numel() < views * colsum_rows * p or s_out.numel() < views * p:
+            lsums.numel() < views * 2 * Cn or colsum.numel() < views * colsum_rows * p or s_out.numel() < views * p or \
+            reduce_ws.numel() < views * groups * 2 * Cn:
         raise ValueError("linbn_stats: size mismatch")
     with _prof("linbn_small", 0.0, 4.0 * views * (Cn * p + colsum_rows * p)):
-        check(_lib.load().sm3_linbn_stats(dtype, _ptr(P), _ptr(w_fwd), _ptr(mean), _ptr(invstd), _ptr(lsums), _ptr(colsum),
-                                          colsum_rows, _ptr(s_out), Cn, p, views, _stream()), "sm3_linbn_stats")
+        check(_lib.load().sm3_linbn_stats(dtype, _ptr(P), _ptr(w_fwd), _ptr(mean), _ptr(invstd), _ptr(reduce_ws), groups,
+                                          _ptr(lsums), _ptr(colsum), colsum_rows, _ptr(s_out), Cn, p, views, _stream()),
+              "sm3_linbn_stats")
 
 
 def linbn_coeffs(dtype, w_dgrad, gamma, mean, invstd, gsums, count, lsums, dgamma, dbeta, wa, wbn, col_const, coef, Cn, p,
@@ -433,15 +440,22 @@ def linbn_coeffs(dtype, w_dgrad, gamma, mean, invstd, gsums, count, lsums, dgamm
                                            _ptr(col_const), _ptr(coef), Cn, p, views, _stream()), "sm3_linbn_coeffs")
 
 
-def linbn_wgrad_finish(P, Tm, s, coef, dw, Cn, p, views=1):
-    for t in (P, Tm, s, coef, dw):
+def linbn_post(dtype, wbn, w_dgrad, hn, P, G, w_fwd, s, coef, dw, Cn, p, views=1):
+    """hn[v] = wbn_v w_dgrad^T (= -H_v, dtype [views][p][p]);  dw += sum_v diag(a)(P_v - m1 s^T) - diag(b)(w_fwd G_v - mu s^T)
+    (sm3_linbn_post)."""
+    tdt = TORCH_DTYPE[dtype]
+    for t, n in ((wbn, "wbn"), (w_dgrad, "w_dgrad"), (hn, "hn"), (w_fwd, "w_fwd")):
+        _chk(t, tdt, n)
+    for t in (P, G, s, coef, dw):
         _chk(t, torch.float32)
-    if P.numel() < views * Cn * p or Tm.numel() < Cn * views * p or s.numel() < views * p or coef.numel() < views * 4 * Cn \
-            or dw.numel() != Cn * p:
-        raise ValueError("linbn_wgrad_finish: size mismatch")
-    with _prof("linbn_small", 0.0, 4.0 * Cn * p * (2 + 2 * views)):
-        check(_lib.load().sm3_linbn_wgrad_finish(_ptr(P), _ptr(Tm), _ptr(s), _ptr(coef), _ptr(dw), Cn, p, views, _stream()),
-              "sm3_linbn_wgrad_finish")
+    if wbn.numel() < views * p * Cn or w_dgrad.numel() != p * Cn or hn.numel() < views * p * p or w_fwd.numel() != Cn * p or \
+            P.numel() < views * Cn * p or G.numel() < views * p * p or s.numel() < views * p or \
+            coef.numel() < views * 4 * Cn or dw.numel() != Cn * p or Cn % 128 or p % 32:
+        raise ValueError("linbn_post: size mismatch")
+    flops = 2.0 * views * (p * p * Cn + Cn * p * p)
+    with _prof("linbn_small", flops, 4.0 * Cn * p * (2 + views) + _sz(dtype) * p * Cn * (1 + views)):
+        check(_lib.load().sm3_linbn_post(dtype, _ptr(wbn), _ptr(w_dgrad), _ptr(hn), _ptr(P), _ptr(G), _ptr(w_fwd), _ptr(s),
+                                         _ptr(coef), _ptr(dw), Cn, p, views, _stream()), "sm3_linbn_post")
 
 
 # ------------------------------------------------------------------------------------------

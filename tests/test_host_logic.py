@@ -88,9 +88,9 @@ def test_engine_dry_run_sequences_and_bucket_schedule(model, linbn):
     assert calls["sm3_bn_finalize"] == 53 * 4 + 3 * 6 == 230  # 212 BN2d + 18 BN1d per step
     nlin = 64 if linbn else 0  # 16 Bottlenecks x 4 encoder passes: conv3 -> bn3 units whose backward goes by linearity
     assert calls["sm3_conv_wgrad"] == 230 - 4 - nlin and calls["sm3_stem_wgrad_bn"] == 4  # bf16: direct stem (csrc/stem.hip)
-    for name in ("sm3_conv_wgrad_cat", "sm3_linbn_stats", "sm3_linbn_coeffs", "sm3_linbn_wgrad_finish",
-                 "sm3_conv_dgrad_seg_bnfuse", "sm3_bn_act_colsum"):
+    for name in ("sm3_linbn_stats", "sm3_linbn_coeffs", "sm3_linbn_post", "sm3_conv_dgrad_seg_bnfuse", "sm3_bn_act_colsum"):
         assert calls[name] == nlin, name
+    assert calls["sm3_conv_wgrad_cat"] == 2 * nlin  # forward: Gram matrix of conv3's input; backward: dz^T y2 per view
     if linbn:
         # no backward-apply pass for bn3; the downsample BatchNorm of a block keeps its own (the stem's is fused into its
         # weight gradient)
