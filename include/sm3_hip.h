@@ -121,6 +121,12 @@ int sm3_conv_dgrad_seg_bnfuse(const sm3_conv_desc* d, const void* x0, const void
  * tools/backbone_eval.py --finetune fc, inference.py) never writes or re-reads a pre-BN tensor. */
 int sm3_conv_bn_act_eval(const sm3_conv_desc* d, const void* x, const void* w, const float* scale,
                          const float* shift, const void* residual, int relu, void* y, void* stream);
+/* The train-mode form: scale / shift are [views][Co] (a launch over two views back to back, each a multiple of 128 rows,
+ * uses view v's vectors for view v's rows) and relu_mask (nullable, with relu) receives the ReLU bits of y as sm3_bn_act
+ * writes them.  With scale / shift from sm3_linbn_fwd_stats + sm3_bn_finalize this is conv3 -> bn3 -> (+identity) -> ReLU
+ * of a Bottleneck (resnet.py:162-172) in ONE launch: the pre-BatchNorm tensor is never written.  Dense outputs only. */
+int sm3_conv_bn_act_fused(const sm3_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
+                          const void* residual, int relu, void* y, uint8_t* relu_mask, int views, void* stream);
 /* Same launch with scale/shift derived in the epilogue from the BatchNorm's own tensors,
  *   scale = gamma / sqrt(running_var + eps),  shift = beta - running_mean * scale      (gamma/beta NULL: 1 / 0),
  * bit-identical to sm3_bn_eval_scale_shift followed by sm3_conv_bn_act_eval, without the 53 small launches per encoder
@@ -140,6 +146,13 @@ int sm3_conv_wgrad(const sm3_conv_desc* d, const void* x, const void* dy, float*
  * dw1 + v * dw1_view_stride; d->Co then a multiple of 128).  Co1 = 0: dy1 / dw1 unused. */
 int sm3_conv_wgrad_cat(const sm3_conv_desc* d, const void* x, const void* dy, float* dw, const void* dy1, int Co1,
                        float* dw1, int views, int64_t dw_view_stride, int64_t dw1_view_stride, void* stream);
+/* The same product WITHOUT atomics (plain-store split-K): slice j of view v of the pixel axis stores its whole
+ * [Co][taps * Ci] partial product into slabs + (v * *slabs_used + j) * Co * taps * Ci; the caller adds the slabs up in a
+ * fixed order (sm3_linbn_moments, sm3_linbn_stats / sm3_linbn_post): deterministic, and at these sizes faster than
+ * ~1.3 TB/s of float atomics.  *slabs_used <= slab_capacity slabs per view (host int, written before return); a view is cut
+ * the same way whether the launch holds one view or two. */
+int sm3_conv_wgrad_slabs(const sm3_conv_desc* d, const void* x, const void* dy, float* slabs, int slab_capacity, int views,
+                         int* slabs_used, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm (2d and 1d: rows x C), train and eval.  replaces nn.BatchNorm2d/1d (+SyncBatchNorm,
@@ -176,10 +189,11 @@ int sm3_bn_eval_scale_shift(const float* gamma, const float* beta, const float* 
  * replaces the bn->relu / bn->add->relu chains of Bottleneck.forward (resnet.py:154-174). */
 int sm3_bn_act(int dtype, const void* x, const float* scale, const float* shift, const void* residual,
                int relu, int out_f32, void* y, uint8_t* relu_mask, int64_t rows, int C, int views, void* stream);
-/* sm3_bn_act (16-bit or f32 storage, no fp32 output) that also leaves per-block column sums of the stored outputs:
- * colsum_partials [views][sm3_bn_act_colsum_rows(rows, C, dtype, views)][C] fp32 -- the first moment of a convolution
- * input, summed by sm3_linbn_stats. */
-int sm3_bn_act_colsum_rows(int64_t rows, int C, int dtype, int views);
+/* sm3_bn_act (storage dtype output) that also leaves per-block column sums of the STORED outputs:
+ * colsum_partials [views][sm3_bn_act_colsum_rows(rows, C, dtype)][C] fp32 -- the first moment of a convolution input, for
+ * the BatchNorm by linearity below (sm3_linbn_moments sums the rows in a fixed order).  A view's rows are cut the same way
+ * whether the launch holds one view or two, so its sums do not depend on that. */
+int sm3_bn_act_colsum_rows(int64_t rows, int C, int dtype);
 int sm3_bn_act_colsum(int dtype, const void* x, const float* scale, const float* shift, const void* residual, int relu,
                       void* y, uint8_t* relu_mask, float* colsum_partials, int64_t rows, int C, int views, void* stream);
 /* The join of a Bottleneck with a downsample branch in ONE pass (resnet.py:164-172: out = bn3(conv3); identity =
@@ -191,7 +205,8 @@ int sm3_bn_add_bn_act(int dtype, const void* x, const float* scale, const float*
                       int64_t rows, int C, int views, void* stream);
 /* Backward, phase 1: dz = dy * (y > 0), the mask taken from relu_mask if given, else from y if given, else all
  * ones; writes dz (may alias dy; NULL to skip) and
- * per-block partial sums [bwd_partial_rows][2][C] of (dz, dz * xhat), xhat = (x-mean)*invstd. */
+ * per-block partial sums [bwd_partial_rows][2][C] of (dz, dz * xhat), xhat = (x-mean)*invstd.  x == NULL (mean / invstd
+ * then unused): mask and sum(dz) only, the second slot is written as 0 (BatchNorm by linearity, below). */
 int sm3_bn_bwd_partial_rows(int64_t rows, int C);
 int sm3_bn_bwd_reduce(int dtype, const void* dy, const void* y, const uint8_t* relu_mask, const void* x,
                       const float* mean, const float* invstd, void* dz, int64_t rows, int C,
@@ -220,33 +235,47 @@ int sm3_bn_bwd_apply2(int dtype, const void* dz, double count, const sm3_bn_appl
                       const sm3_bn_apply_side* b, int64_t rows, int C, int views, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * BatchNorm backward by linearity, for an expanding 1x1 convolution followed by train-mode BatchNorm (Bottleneck
- * conv3 -> bn3: resnet.py:162-163 and their autograd backward; 16-bit dtypes).  With x = y W^T (y: [M, p] conv input,
- * W: [C, p]) and dx = a (dz - m1) - b (x - mu) [a = gamma invstd, b = a invstd mean(dz xhat), m1 = mean(dz)]:
- *   P = dz^T y, G = y^T y (sm3_conv_wgrad_cat), s = sum_m y (sm3_bn_act_colsum)
- *   sum_m dz xhat = invstd (rowdot(W, P) - mu sum_m dz)                                  (sm3_linbn_stats)
- *   dy = dz (diag(a) W) - y H + const, H = W^T diag(b) W          (sm3_linbn_coeffs, sm3_linbn_post for H,
- *                                                                   sm3_conv_dgrad_seg_bnfuse)
- *   dW += diag(a)(P - m1 s^T) - diag(b)(W G - mu s^T)             (sm3_linbn_post, W G on the exact-f32 MFMA)
- * so sm3_bn_bwd_apply's pass over dz / x / dx (and every backward read of x) is never made.  All per-channel vectors
- * are [views][C].
+ * BatchNorm BY LINEARITY, for an expanding 1x1 convolution followed by train-mode BatchNorm (Bottleneck conv3 -> bn3:
+ * resnet.py:162-163 and their autograd backward; 16-bit dtypes).  With x = y W^T (y: [M, p] conv input, W: [C, p]),
+ * s = sum_m y (sm3_bn_act_colsum) and G = y^T y (sm3_conv_wgrad_cat on y alone):
+ *   forward   sum_m x = W s,  sum_m x^2 = rowdot(W G, W)  -> sm3_bn_finalize -> sm3_conv_bn_act_fused: x is never stored
+ *   backward  dx = a (dz - m1) - b (x - mu)   [a = gamma invstd, b = a invstd mean(dz xhat), m1 = mean(dz)], so with
+ *             P = dz^T y (sm3_conv_wgrad_cat):
+ *               sum_m dz xhat = invstd (rowdot(W, P) - mu sum_m dz)                                (sm3_linbn_stats)
+ *               dy = dz (diag(a) W) - y H + const,  H = W^T diag(b) W   (sm3_linbn_banks, sm3_linbn_post for H,
+ *                                                                        sm3_conv_dgrad_seg_bnfuse)
+ *               dW += diag(a)(P - m1 s^T) - diag(b)(W G - mu s^T)                                  (sm3_linbn_post)
+ * so neither sm3_bn_bwd_apply's pass over dz / x / dx nor any other read of x is made.  All per-channel vectors are
+ * [views][C]; coef is [views][C][4] fp32 = (a, b, m1, mu).
  * ------------------------------------------------------------------------------------------ */
+/* out [views][n] fp32 = the sum of the nslabs slabs per view sm3_conv_wgrad_slabs left (n = p * p for G = y^T y, C * p for
+ * P = dz^T y), and -- colsum_partials given -- s_out [views][p] fp64 = the sum of the colsum_rows partial rows of
+ * sm3_bn_act_colsum; both in a fixed order. */
+int sm3_linbn_moments(const float* slabs, int nslabs, int64_t n, float* out, const float* colsum_partials, int colsum_rows,
+                      double* s_out, int p, int views, void* stream);
+/* Tm [views][C][p] fp32 = W G_v (exact-f32 MFMA), and the batch sums of x as sums_ws [views][p/32][2C] fp64 -- pass it to
+ * sm3_bn_finalize with groups = p/32 (data parallel: all-reduce it first).  G: [views][p][p] fp32; s: [views][p] fp64;
+ * w_dgrad: dtype [p][C]; w_fwd: dtype [C][p].  C, p multiples of 32. */
+int sm3_linbn_fwd_stats(int dtype, const float* G, const void* w_dgrad, const void* w_fwd, const double* s, float* Tm,
+                        double* sums_ws, int C, int p, int views, void* stream);
 /* reduce_ws / groups: what sm3_bn_stats_reduce(partials of (dz, .), sums = NULL) left -- its stage B runs here.
- * lsums: [views][2C] fp64, both halves written (sum dz | sum dz xhat).  P: [views][C][p] fp32; w_fwd: dtype [C][p];
- * colsum_partials: [views][colsum_rows][p]; s_out: [views][p] fp32. */
-int sm3_linbn_stats(int dtype, const float* P, const void* w_fwd, const float* mean, const float* invstd,
-                    const double* reduce_ws, int groups, double* lsums, const float* colsum_partials, int colsum_rows,
-                    float* s_out, int C, int p, int views, void* stream);
-/* From the (all-reduced) sums: wa = diag(a) W and wbn = -diag(b) W in data-gradient order (dtype [views][p][C], from
- * w_dgrad [p][C]), col_const [views][p] = (b mu - a m1) W, coef [views][4][C] = (a, b, m1, mu);
- * dgamma += local sum(dz xhat), dbeta += local sum(dz) (NULL to skip).  count: elements per channel of one view. */
-int sm3_linbn_coeffs(int dtype, const void* w_dgrad, const float* gamma, const float* mean, const float* invstd,
-                     const double* global_sums, double count, const double* local_sums, float* dgamma, float* dbeta,
-                     void* wa, void* wbn, float* col_const, float* coef, int C, int p, int views, void* stream);
-/* The two small products, one launch of 32 x 32 MFMA tiles:  hn [views][p][p] (dtype) = wbn_v w_dgrad^T = -H_v, and
- * dw[C][p] += sum_v diag(a_v)(P_v - m1_v s_v^T) - diag(b_v)(w_fwd G_v - mu_v s_v^T).  C % 128 == 0, p % 32 == 0. */
+ * lsums: [views][2C] fp64, both halves written (sum dz | sum dz xhat); dgamma += sum dz xhat, dbeta += sum dz (NULL to
+ * skip).  count > 0 (single rank: the local sums are the global ones): coef is written too; count <= 0: the caller
+ * all-reduces lsums and calls sm3_linbn_coef.  P: [views][C][p] fp32; w_fwd: dtype [C][p]. */
+int sm3_linbn_stats(int dtype, const float* P, const void* w_fwd, const float* mean, const float* invstd, const float* gamma,
+                    const double* reduce_ws, int groups, double* lsums, float* dgamma, float* dbeta, double count,
+                    float* coef, int C, int p, int views, void* stream);
+int sm3_linbn_coef(const double* global_sums, double count, const float* gamma, const float* mean, const float* invstd,
+                   float* coef, int C, int views, void* stream);
+/* wa = diag(a) W and wbn = -diag(b) W in data-gradient order (dtype [views][p][C], from w_dgrad [p][C]);
+ * col_const [views][p] = (b mu - a m1) W, summed over the rounded products. */
+int sm3_linbn_banks(int dtype, const void* w_dgrad, const float* coef, void* wa, void* wbn, float* col_const, int C, int p,
+                    int views, void* stream);
+/* One launch of 32 x 32 MFMA tiles:  hn [views][p][p] (dtype) = wbn_v w_dgrad^T = -H_v, and
+ * dw[C][p] += sum_v diag(a_v)(P_v - m1_v s_v^T) - diag(b_v)(W G_v - mu_v s_v^T), W G_v from Tm (sm3_linbn_fwd_stats) or,
+ * Tm NULL, recomputed from G.  C % 128 == 0, p % 32 == 0. */
 int sm3_linbn_post(int dtype, const void* wbn, const void* w_dgrad, void* hn, const float* P, const float* G,
-                   const void* w_fwd, const float* s, const float* coef, float* dw, int C, int p, int views, void* stream);
+                   const float* Tm, const double* s, const float* coef, float* dw, int C, int p, int views, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Stem, pooling.  replaces resnet.py:208-213,224,294-305.

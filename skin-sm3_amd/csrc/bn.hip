@@ -180,8 +180,8 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x, co
     const int cv = blockIdx.x * tbx + tx;
     const bool active = !(cv * E >= C || ty >= tby);
     if (!active && !colsum) return;
-    // colsum (nullable): [views][gridDim.y][C] f32, the block's column sums of the STORED (rounded) outputs -- the
-    // first moment of a convolution input that the linear BatchNorm backward needs (linbn.hip)
+    // colsum (nullable): [views][gridDim.y][C] f32, the block's column sums of the STORED (rounded) outputs -- the first
+    // moment of a convolution input that BatchNorm by linearity needs (linbn.hip sums the rows in a fixed order)
     float cs[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) cs[e] = 0.f;
@@ -302,23 +302,27 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     {  // view blockIdx.z
         const int64_t vo = (int64_t)blockIdx.z * rows * C;
         dy += vo;
-        x += vo;
+        if (x) {
+            x += vo;
+            mean += (int64_t)blockIdx.z * C;
+            invstd += (int64_t)blockIdx.z * C;
+        }
         if (y) y += vo;
         if (dz) dz += vo;
         if (mask) mask += (int64_t)blockIdx.z * rows * (C / E);
-        mean += (int64_t)blockIdx.z * C;
-        invstd += (int64_t)blockIdx.z * C;
         partials += (int64_t)blockIdx.z * gridDim.y * 2 * C;
     }
     float s1[E], s2[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) s1[e] = s2[e] = 0.f;
     if (active) {
+        // x == nullptr: mask and sum(dz) only, the sum(dz * xhat) slot stays 0 (a BatchNorm whose backward goes by
+        // linearity never reads its input: linbn.hip)
         float mu[E], is[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            mu[e] = mean[cv * E + e];
-            is[e] = invstd[cv * E + e];
+            mu[e] = x ? mean[cv * E + e] : 0.f;
+            is[e] = x ? invstd[cv * E + e] : 0.f;
         }
         const int64_t rstep = (int64_t)gridDim.y * tby;
         auto finish = [&](int64_t r, const uint4& gu, const uint4& xu, const uint4& yu, unsigned m) {
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             for (int u = 0; u < U; ++u) {
                 const int64_t rr = r + u * rstep, off = rr * C + (int64_t)cv * E;
                 gu[u] = ldg16<NT>(dy + off);
-                xu[u] = ldg16<NT>(x + off);
+                xu[u] = x ? ldg16<NT>(x + off) : make_uint4(0, 0, 0, 0);
                 m[u] = mask ? mask[rr * (C / E) + cv] : 0u;
                 yu[u] = (!mask && y) ? ldg16<NT>(y + off) : make_uint4(0, 0, 0, 0);
             }
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         }
         for (; r < rows; r += rstep) {
             const int64_t off = r * C + (int64_t)cv * E;
-            finish(r, ldg16<false>(dy + off), ldg16<false>(x + off),
+            finish(r, ldg16<false>(dy + off), x ? ldg16<false>(x + off) : make_uint4(0, 0, 0, 0),
                    (!mask && y) ? ldg16<false>(y + off) : make_uint4(0, 0, 0, 0), mask ? mask[r * (C / E) + cv] : 0u);
         }
     }
@@ -624,7 +628,9 @@ static int bn_act_impl(int dtype, const void* x, const float* scale, const float
     const int E = dtype == SM3_F32 ? 4 : 8;
     if (C % E) return SM3_EALIGN;
     if (colsum && out_f32) return SM3_EINVAL;
-    const RowWalk w = make_walk(rows, C / E, 8192, views);
+    // with column sums the row walk of a view is cut as if the launch always held two views: a view's partial rows -- and
+    // so the bits of their sum -- are the same whether the two views of a branch share a launch or not
+    const RowWalk w = make_walk(rows, C / E, 8192, (colsum && views < 2) ? 2 : views);
     dim3 grid(w.gx, w.gy, views), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define SM3_ACT_T(T, U, NT)                                                                                          \
@@ -653,11 +659,11 @@ extern "C" int sm3_bn_act(int dtype, const void* x, const float* scale, const fl
                        stream);
 }
 
-extern "C" int sm3_bn_act_colsum_rows(int64_t rows, int C, int dtype, int views) {
-    if (rows <= 0 || C <= 0 || views < 1 || !SM3_DTYPE_OK(dtype)) return SM3_EINVAL;
+extern "C" int sm3_bn_act_colsum_rows(int64_t rows, int C, int dtype) {
+    if (rows <= 0 || C <= 0 || !SM3_DTYPE_OK(dtype)) return SM3_EINVAL;
     const int E = dtype == SM3_F32 ? 4 : 8;
     if (C % E) return SM3_EALIGN;
-    return make_walk(rows, C / E, 8192, views).gy;
+    return make_walk(rows, C / E, 8192, 2).gy;
 }
 
 extern "C" int sm3_bn_act_colsum(int dtype, const void* x, const float* scale, const float* shift, const void* residual,
@@ -690,7 +696,7 @@ extern "C" int sm3_bn_bwd_partial_rows(int64_t rows, int C) {
 extern "C" int sm3_bn_bwd_reduce(int dtype, const void* dy, const void* y, const uint8_t* relu_mask, const void* x,
                                  const float* mean, const float* invstd, void* dz, int64_t rows, int C,
                                  float* partials, int views, void* stream) {
-    if (!dy || !x || !mean || !invstd || !partials || rows <= 0 || C <= 0 || views < 1) return SM3_EINVAL;
+    if (!dy || (x && (!mean || !invstd)) || !partials || rows <= 0 || C <= 0 || views < 1) return SM3_EINVAL;
     if (!SM3_DTYPE_OK(dtype)) return SM3_EDTYPE;
     const int E = dtype == SM3_F32 ? 4 : 8;
     if (C % E) return SM3_EALIGN;

@@ -43,6 +43,9 @@ struct ConvParams {
     const float* ep_rm;
     const float* ep_rv;
     float ep_eps;
+    // train-mode form of the same epilogue (sm3_conv_bn_act_fused): ep_scale / ep_shift are [views][Co] (a tile's view as
+    // for the fused BN-backward: fz_view_tiles), and the ReLU bits of the output go to ep_mask (1 byte per 16-byte vector)
+    uint8_t* ep_mask;
     // ---- second K segment (SEG kernels, "BatchNorm backward by linearity": csrc/linbn.hip) ----------------------------
     // taps with tap_src[t] = 1 take their A rows from x1 ([pixels][Ci1], same pixel geometry) and their B rows from w1
     // ([Co][w1_row_stride]); nsteps_seg = sum over taps of that tap's K-steps.  Two views in one launch (fz_view_tiles > 0)

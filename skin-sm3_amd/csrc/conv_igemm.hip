@@ -368,7 +368,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
                 f_mu[e] = p.fz_mean[fz_view * p.Co + ncol + e];
                 f_is[e] = p.fz_invstd[fz_view * p.Co + ncol + e];
             } else if (ep) {
-                ep_affine(p, ncol + e, f_is[e], f_mu[e]);
+                if (p.ep_rv) {
+                    ep_affine(p, ncol + e, f_is[e], f_mu[e]);
+                } else {  // per-view vectors (train-mode fused form); view 0 = the only one at inference
+                    f_is[e] = p.ep_scale[tile_view * p.Co + ncol + e];
+                    f_mu[e] = p.ep_shift[tile_view * p.Co + ncol + e];
+                }
             }
         }
     }
@@ -469,6 +474,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
                 for (int e = 0; e < EPC; ++e) v[e] += a[e];
             }
             if (ep && p.ep_relu) {
+                if (p.ep_mask) {  // what the backward pass needs of the output: one bit per element
+                    unsigned m = 0;
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) m |= (v[e] > 0.f ? 1u : 0u) << e;
+                    p.ep_mask[e_off[k] / EPC] = (uint8_t)m;
+                }
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) v[e] = fmaxf(v[e], 0.f);
             }
@@ -558,7 +569,9 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         const char* lv = getenv("SM3_CONV_LEAN");
         const bool dense = p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.HWout == p.HoWo;
-        if (!(lv && atoi(lv) == 0) && dense && !p.addend && !p.fz_partials) {  // train-mode forward, and conv+evalBN(+ReLU)
+        // (the lean epilogue knows neither per-view scale / shift nor the ReLU-bit output of the train-mode fused form)
+        if (!(lv && atoi(lv) == 0) && dense && !p.addend && !p.fz_partials && !p.ep_mask &&
+            !(p.ep_scale && p.fz_view_tiles)) {  // train-mode forward, and conv+evalBN(+ReLU)
             if (deep) return launch_conv_st<T, BM, BN, WM, WN, 4, true>(p, st);
             return single ? launch_conv_st<T, BM, BN, WM, WN, 1, true>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, true>(p, st);
         }
@@ -610,10 +623,12 @@ extern "C" int sm3_conv_partial_rows(const sm3_conv_desc* d) {
     return (int)((M + kBM - 1) / kBM);
 }
 
-struct EvalBn {  // eval-mode BatchNorm folded into the epilogue: precomputed vectors, or the BatchNorm's tensors
+struct EvalBn {  // BatchNorm folded into the epilogue: precomputed vectors ([views][Co]), or an eval BatchNorm's tensors
     const float *scale, *shift, *gamma, *beta, *rm, *rv;
     float eps;
     int relu;
+    uint8_t* mask = nullptr;  // train-mode fused form: ReLU bits of the output
+    int views = 1;
 };
 
 static int conv_gather_gemm_impl(const sm3_conv_desc* d, const void* x, const void* w, void* y, const void* addend,
@@ -658,6 +673,11 @@ static int conv_gather_gemm_impl(const sm3_conv_desc* d, const void* x, const vo
     p.ep_rv = ebn ? ebn->rv : nullptr;
     p.ep_eps = ebn ? ebn->eps : 0.f;
     p.ep_relu = ebn ? ebn->relu : 0;
+    p.ep_mask = ebn ? ebn->mask : nullptr;
+    if (ebn && ebn->views > 1) {
+        if (ebn->views != 2 || fuse || (p.M % 2) || ((p.M / 2) % kBM)) return SM3_EALIGN;
+        p.fz_view_tiles = p.M / 2 / kBM;
+    }
     p.x1 = p.w1 = nullptr;
     p.col_bias = nullptr;
     p.x1_bytes = p.w1_bytes = p.w_view_bytes = p.w1_view_bytes = 0;
@@ -725,6 +745,18 @@ extern "C" int sm3_conv_bn_act_eval(const sm3_conv_desc* d, const void* x, const
                                     const float* shift, const void* residual, int relu, void* y, void* stream) {
     if (!scale || !shift) return SM3_EINVAL;
     const EvalBn e{scale, shift, nullptr, nullptr, nullptr, nullptr, 0.f, relu};
+    return conv_gather_gemm_impl(d, x, w, y, residual, nullptr, nullptr, stream, &e);
+}
+
+extern "C" int sm3_conv_bn_act_fused(const sm3_conv_desc* d, const void* x, const void* w, const float* scale,
+                                     const float* shift, const void* residual, int relu, void* y, uint8_t* relu_mask,
+                                     int views, void* stream) {
+    if (!scale || !shift || views < 1 || (relu_mask && !relu)) return SM3_EINVAL;
+    if (d && !(d->osy == 1 && d->osx == 1 && d->ooy == 0 && d->oox == 0 && d->Hout == d->Ho && d->Wout == d->Wo))
+        return SM3_EINVAL;  // the mask is indexed like a dense output
+    EvalBn e{scale, shift, nullptr, nullptr, nullptr, nullptr, 0.f, relu};
+    e.mask = relu_mask;
+    e.views = views;
     return conv_gather_gemm_impl(d, x, w, y, residual, nullptr, nullptr, stream, &e);
 }
 

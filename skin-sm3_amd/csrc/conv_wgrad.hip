@@ -41,6 +41,10 @@ struct WgradParams {
     float* dw1;
     int Co1, views, Mv, splits_view;
     long dw_view_stride, dw1_view_stride;
+    // sm3_conv_wgrad_slabs: no atomics -- slice j of view v STORES its tiles into dw + (v * splits_view + j) * slab_stride
+    // (every slab a full [Co][w_row_stride] matrix); the caller sums the slabs in a fixed order (deterministic results)
+    long slab_stride;  // 0: accumulate with float atomics
+    int slab_cap;      // slabs available per view
 };
 
 using sm3conv::dma16;       // LDS-DMA from inline asm, zero-fill by the buffer range check: see conv_common.h
@@ -307,7 +311,9 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const WgradParams 
                 for (int r = 0; r < 16; ++r) acc[i][j][r] += xch[((wave * TM * TN + i * TN + j) * 16 + r) * 64 + lane];
     }
     const int frow = lane & 31, fh = lane >> 5;
-    float* const dw_out = second ? p.dw1 + (long)view * p.dw1_view_stride : p.dw + (long)view * p.dw_view_stride;
+    float* const dw_out = p.slab_stride ? p.dw + (long)slice * p.slab_stride
+                          : second    ? p.dw1 + (long)view * p.dw1_view_stride
+                                      : p.dw + (long)view * p.dw_view_stride;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -317,10 +323,14 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const WgradParams 
                 const int co = co0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 const int ci = ci0 + wn * WTN + j * 32 + frow;
                 const long kcol = (long)p.wtap[tap] * p.Ci + ci;  // column inside the dw row
-                if (co < dyC && ci < p.Ci && kcol < p.w_row_stride)
-                    atomicAdd(dw_out + (long)co * p.w_row_stride + kcol, acc[i][j][r]);
+                if (co < dyC && ci < p.Ci && kcol < p.w_row_stride) {
+                    if (p.slab_stride) dw_out[(long)co * p.w_row_stride + kcol] = acc[i][j][r];
+                    else atomicAdd(dw_out + (long)co * p.w_row_stride + kcol, acc[i][j][r]);
+                }
             }
 }
+
+static int g_last_slabs = 0;  // slabs per view of the most recent launch (sm3_conv_wgrad_slabs returns it)
 
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
@@ -375,7 +385,10 @@ int launch_wgrad_kp(WgradParams p, hipStream_t st) {
     if (target > 0) splits = (target + gx - 1) / gx;
     else if (gx <= slots_xcd) splits = 8 * (slots_xcd / gx);
     else splits = 8 * slots_xcd / gx;  // < 8 slices: tiles go round-robin over the XCDs (see the kernel)
-    splits = (splits + p.views - 1) / p.views;  // per view from here on
+    // per view from here on.  Slab mode: as if the launch always held two views, so that a view's pixels are cut into the
+    // same slices -- and its slabs add up to the same bits -- whether the two views of a branch share a launch or not
+    splits = p.slab_stride ? (splits + 1) / 2 : (splits + p.views - 1) / p.views;
+    if (p.slab_stride && splits > p.slab_cap) splits = p.slab_cap;
     const long max_splits = (p.Mv + KP * 8 * KG - 1) / (KP * 8 * KG);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -385,6 +398,7 @@ int launch_wgrad_kp(WgradParams p, hipStream_t st) {
     p.k_per_split = (int)kps;
     p.gx = (int)gx;
     p.splits_view = (int)splits;
+    g_last_slabs = (int)splits;
     splits *= p.views;
     p.splits = (int)splits;
     const long nblocks = gx * (splits >= 8 ? (splits + 7) / 8 * 8 : splits);
@@ -413,7 +427,7 @@ int launch_wgrad(WgradParams p, hipStream_t st) {
 }  // namespace
 
 static int wgrad_impl(const sm3_conv_desc* d, const void* x, const void* dy, float* dw, const void* dy1, int Co1,
-                      float* dw1, int views, long dw_view_stride, long dw1_view_stride, void* stream) {
+                      float* dw1, int views, long dw_view_stride, long dw1_view_stride, void* stream, int slab_cap = 0) {
     if (!d || !x || !dy || !dw) return SM3_EINVAL;
     if (!SM3_DTYPE_OK(d->dtype)) return SM3_EDTYPE;
     const int sz = d->dtype == SM3_F32 ? 4 : 2;
@@ -430,6 +444,8 @@ static int wgrad_impl(const sm3_conv_desc* d, const void* x, const void* dy, flo
     p.dy1 = (const char*)dy1; p.dw1 = dw1; p.Co1 = Co1;
     p.views = views; p.Mv = (int)(M / views);
     p.dw_view_stride = dw_view_stride; p.dw1_view_stride = dw1_view_stride;
+    p.slab_cap = slab_cap;
+    p.slab_stride = slab_cap > 0 ? (long)d->Co * d->w_row_stride : 0;
     p.M = (int)M; p.Hi = d->Hi; p.Wi = d->Wi; p.Ci = d->Ci; p.Co = d->Co;
     p.sy = d->sy; p.sx = d->sx; p.ntaps = d->ntaps;
     for (int t = 0; t < SM3_MAX_TAPS; ++t) { p.dyt[t] = d->dy[t]; p.dxt[t] = d->dx[t]; p.wtap[t] = d->wtap[t]; }
@@ -462,6 +478,15 @@ static int wgrad_impl(const sm3_conv_desc* d, const void* x, const void* dy, flo
 
 extern "C" int sm3_conv_wgrad(const sm3_conv_desc* d, const void* x, const void* dy, float* dw, void* stream) {
     return wgrad_impl(d, x, dy, dw, nullptr, 0, nullptr, 1, 0, 0, stream);
+}
+
+extern "C" int sm3_conv_wgrad_slabs(const sm3_conv_desc* d, const void* x, const void* dy, float* slabs, int slab_capacity,
+                                    int views, int* slabs_used, void* stream) {
+    if (!slabs_used || slab_capacity < 1) return SM3_EINVAL;
+    if (d && d->ntaps * d->Ci != d->w_row_stride) return SM3_EINVAL;  // every slab a dense [Co][taps * Ci] matrix
+    const int rc = wgrad_impl(d, x, dy, slabs, nullptr, 0, nullptr, views, 0, 0, stream, slab_capacity);
+    if (rc == 0) *slabs_used = g_last_slabs;
+    return rc;
 }
 
 extern "C" int sm3_conv_wgrad_cat(const sm3_conv_desc* d, const void* x, const void* dy, float* dw, const void* dy1,

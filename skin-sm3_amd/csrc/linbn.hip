@@ -1,62 +1,91 @@
-// BatchNorm backward BY LINEARITY for an expanding 1x1 convolution followed by train-mode BatchNorm
-// (Bottleneck conv3 -> bn3, reference src/models/resnet.py:162-163 and their autograd backward):
+// BatchNorm BY LINEARITY for an expanding 1x1 convolution followed by train-mode BatchNorm
+// (Bottleneck conv3 -> bn3, reference src/models/resnet.py:162-163, and their autograd backward):
 //
 //   forward   x = y W^T          y: [M, p] (conv input),  W: [C, p],  C = 4p;   z = gamma * (x - mu) * invstd + beta
 //   backward  dx = a (dz - m1) - b (x - mu),   a = gamma invstd,  b = a invstd m2,  m1 = mean(dz),  m2 = mean(dz xhat)
 //
-// Every consumer of dx is linear in it, and x is linear in y, so neither dx nor x has to be read (or written):
-//   P  = dz^T y  [C, p]  (the weight-gradient GEMM on dz itself),  G = y^T y [p, p],  s = sum_m y [p]
-//   sum_m dz x        = rowdot(W, P)                               -> m2 without a pass over x
-//   dy = dx W         = dz (diag(a) W) - y H + const,   H = W^T diag(b) W [p, p],  const = (b mu - a m1) W
-//   dW = dx^T y       = diag(a) (P - m1 s^T) - diag(b) (W G - mu s^T)
-// The data gradient is then one gather-GEMM over two K segments [dz | y] (sm3_conv_dgrad_seg_bnfuse), the weight
-// gradient the same kernel as ever on dz (sm3_conv_wgrad_cat; the [p, p] Gram block is one more launch of it on y alone,
-// made in the forward pass), and the BatchNorm-backward apply
-// pass over the widest tensors of the network (read dz, read x, write dx: 12 of the 80 activation-sized transfers a
-// Bottleneck costs per step) disappears together with every backward read of x.  Per view: all per-channel vectors are
-// [views][C].  The kernels here are the small pieces between those GEMMs; 16-bit activation types only (the exact-f32
-// parity mode keeps the two-pass BatchNorm backward).
+// x is linear in y and every consumer of dx is linear in it, so the widest tensor of the block -- x, 4x the size of y --
+// is needed by nobody as long as two small moments of y are at hand:  s = sum_m y [p]  and  G = y^T y [p, p]
+// (sm3_bn_act_colsum; one launch of the weight-gradient kernel on y alone):
+//   batch statistics   sum_m x = W s,   sum_m x^2 = rowdot(W G, W)          -> mu, invstd WITHOUT x (sm3_linbn_fwd_stats),
+//                      so conv3 can apply bn3 + residual + ReLU in its own epilogue (sm3_conv_bn_act_fused): x never
+//                      reaches HBM in the forward pass either
+//   P = dz^T y [C, p]  the weight-gradient GEMM on dz itself (sm3_conv_wgrad_cat)
+//   sum_m dz x         = rowdot(W, P)                                       -> m2 (sm3_linbn_stats)
+//   dy = dx W          = dz (diag(a) W) - y H + const,  H = W^T diag(b) W [p, p],  const = (b mu - a m1) W
+//                      (sm3_linbn_banks, sm3_linbn_post, then ONE gather-GEMM over the K segments [dz | y]:
+//                      sm3_conv_dgrad_seg_bnfuse)
+//   dW = dx^T y        = diag(a) (P - m1 s^T) - diag(b) (W G - mu s^T)      (sm3_linbn_post)
+// Per Bottleneck and step this removes the write and three reads of x and the BatchNorm-backward apply pass (read dz,
+// read x, write dx) -- 22 of the 80 activation-sized transfers.  All per-channel vectors are [views][C] (the two views of
+// a branch share a launch but not their statistics).  16-bit activation types only: the exact-f32 parity mode keeps the
+// two-pass BatchNorm.  The kernels here are the small pieces between the GEMMs.
 #include "common.h"
 
 namespace {
 
-// ---- sm3_linbn_stats ------------------------------------------------------------------------------------------------
-// blocks [0, views * C / 4): one wave per output channel: S1 = sum over the `groups` rows sm3_bn_stats_reduce's stage A left
-// in ws (that kernel's stage B, folded in here), lsums[v][co] = S1, lsums[v][C + co] = invstd * (rowdot(W[co], P_v[co]) - mu S1)
-// blocks beyond: s[v][ci] = sum over the colsum partial rows
+// 32 x 32 tile of W G on the exact-f32 MFMA, operands straight from L2 (a few hundred KB): lane (i = l & 31, kk = l >> 5)
+// feeds A[i][k] = wd[k][co0 + i] (the data-gradient bank [p][C]: contiguous over i) and B[k][j] = G[k][ci0 + j] for
+// k = 2 t + kk; the loads of 8 steps are issued before the first MFMA of the batch.  acc[r] = (W G)[co0 + row(r)][ci0 + i],
+// row(r) = (r & 3) + 8 (r >> 2) + 4 kk.
 template <typename T>
-__global__ __launch_bounds__(256) void linbn_stats_kernel(const float* __restrict__ P, const T* __restrict__ w,
-                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                          const double* __restrict__ ws, int groups,
-                                                          double* __restrict__ lsums, const float* __restrict__ colsum,
-                                                          int crow, float* __restrict__ s_out, int C, int p, int views,
-                                                          int row_blocks) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if ((int)blockIdx.x < row_blocks) {
-        const int row = blockIdx.x * 4 + wave;  // (view, co)
-        if (row >= views * C) return;
-        const int v = row / C, co = row - v * C;
-        const float* pr = P + ((long)v * C + co) * p;
-        const T* wr = w + (long)co * p;
-        double acc = 0.0, s1 = 0.0;
-        for (int k = lane; k < p; k += 64) acc += (double)pr[k] * (double)ElemTraits<T>::load(wr + k);
-        for (int g = lane; g < groups; g += 64) s1 += ws[((long)v * groups + g) * 2 * C + co];
+__device__ __forceinline__ void tile_wg(const T* __restrict__ wd, int C, const float* __restrict__ G, int p, int co0, int ci0,
+                                        int lane, f32x16& acc) {
+    const int i = lane & 31, kk = lane >> 5;
+    const T* ap = wd + (long)kk * C + co0 + i;
+    const float* bp = G + (long)kk * p + ci0 + i;
+    constexpr int U = 8;
+    for (int t = 0; t < p / 2; t += U) {
+        float a[U], b[U];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            acc += __shfl_xor(acc, o, 64);
-            s1 += __shfl_xor(s1, o, 64);
+        for (int u = 0; u < U; ++u) {
+            a[u] = ElemTraits<T>::load(ap + (long)(2 * (t + u)) * C);
+            b[u] = bp[(long)(2 * (t + u)) * p];
         }
-        if (lane == 0) {
-            double* ls = lsums + (long)v * 2 * C;
-            ls[co] = s1;
-            ls[C + co] = (double)invstd[(long)v * C + co] * (acc - (double)mean[(long)v * C + co] * s1);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ double half_sum(double v) {  // over the 32 lanes of a wave half
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- sm3_linbn_moments ----------------------------------------------------------------------------------------------
+// The two moments of y in their final form, summed in a FIXED order (no atomics anywhere on the forward path: a step's
+// forward is bit-reproducible, and a view's moments do not depend on whether its sibling view shared the launches):
+//   blocks [0, gblocks):  G[v][e] = sum_j slabs[v][j][e]            (the slabs sm3_conv_wgrad_slabs left for y^T y; the
+//                         same sum gives P = dz^T y from its slabs: n elements per view, no column sums)
+//   blocks beyond:        s[v][ci] = sum_r colsum_partials[v][r][ci] (sm3_bn_act_colsum), 32 columns x 8 row lanes per block
+__global__ __launch_bounds__(256) void linbn_moments_kernel(const float* __restrict__ slabs, int nslabs, long pp,
+                                                            const float* __restrict__ colsum, int crow,
+                                                            float* __restrict__ G, double* __restrict__ s_out, int p,
+                                                            int views, int gblocks) {
+    if ((int)blockIdx.x < gblocks) {
+        const long e4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;  // four consecutive elements of one view's matrix
+        if (e4 >= (long)views * pp) return;
+        const int v = (int)(e4 / pp);
+        const float* src = slabs + (long)v * nslabs * pp + (e4 - (long)v * pp);
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+        auto add = [](float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+        int j = 0;
+        for (; j + 3 < nslabs; j += 4) {
+            add(a0, *reinterpret_cast<const float4*>(src + (long)j * pp));
+            add(a1, *reinterpret_cast<const float4*>(src + (long)(j + 1) * pp));
+            add(a2, *reinterpret_cast<const float4*>(src + (long)(j + 2) * pp));
+            add(a3, *reinterpret_cast<const float4*>(src + (long)(j + 3) * pp));
         }
+        for (; j < nslabs; ++j) add(a0, *reinterpret_cast<const float4*>(src + (long)j * pp));
+        add(a0, a1);
+        add(a2, a3);
+        add(a0, a2);
+        *reinterpret_cast<float4*>(G + e4) = a0;
         return;
     }
-    // column sums: a block takes 32 columns of one view, 8 row lanes x 4 independent chains each (the partial rows are a few
-    // hundred: one thread per column would walk them as one chain of dependent L2 loads)
     __shared__ double red[8][32];
-    const int cb = blockIdx.x - row_blocks, pb = (p + 31) / 32;
+    const int cb = blockIdx.x - gblocks, pb = (p + 31) / 32;
     const int v = cb / pb, ci = (cb - v * pb) * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     if (ci < p) {
@@ -76,50 +105,122 @@ __global__ __launch_bounds__(256) void linbn_stats_kernel(const float* __restric
         double t = 0.0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) t += red[j][threadIdx.x];
-        s_out[(long)v * p + ci] = (float)t;
+        s_out[(long)v * p + ci] = t;
     }
 }
 
-// ---- sm3_linbn_coeffs -----------------------------------------------------------------------------------------------
+// ---- sm3_linbn_fwd_stats --------------------------------------------------------------------------------------------
+// one wave per (view, 32 channels co, 32 columns ci): Tm[v][co][ci] = (W G_v)[co][ci], and the tile's share of the batch
+// sums of x = y W^T:  ws[v][cit][co] = sum_{ci in tile} W[co][ci] s_v[ci],  ws[v][cit][C + co] = sum_{ci} Tm W[co][ci]
+// -- the [views][groups = p/32][2C] fp64 layout sm3_bn_finalize sums over.
+template <typename T>
+__global__ __launch_bounds__(256) void linbn_fwd_stats_kernel(const float* __restrict__ G, const T* __restrict__ wd,
+                                                              const T* __restrict__ w, const double* __restrict__ s,
+                                                              float* __restrict__ Tm, double* __restrict__ ws, int C,
+                                                              int p, int views) {
+    const int lane = threadIdx.x & 63, i = lane & 31, kk = lane >> 5;
+    const int pt = p / 32, ct = C / 32;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= views * ct * pt) return;
+    const int v = tile / (ct * pt), rem = tile - v * ct * pt;
+    const int co0 = (rem / pt) * 32, cit = rem % pt, ci0 = cit * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    tile_wg<T>(wd, C, G + (long)v * p * p, p, co0, ci0, lane, acc);
+    const double sv = s[(long)v * p + ci0 + i];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        Tm[((long)v * C + co) * p + ci0 + i] = acc[r];
+        const double wv = (double)ElemTraits<T>::load(w + (long)co * p + ci0 + i);
+        const double s1 = half_sum(wv * sv), s2 = half_sum(wv * (double)acc[r]);
+        if (i == 0) {
+            double* o = ws + ((long)v * pt + cit) * 2 * C;
+            o[co] = s1;
+            o[C + co] = s2;
+        }
+    }
+}
+
+// ---- sm3_linbn_stats ------------------------------------------------------------------------------------------------
+// one wave per (view, channel): S1 = sum over the `groups` rows stage A of sm3_bn_stats_reduce left in ws (its stage B,
+// folded in here), S2 = invstd (rowdot(W[co], P_v[co]) - mu S1); lsums[v] = (S1 | S2); dgamma += S2, dbeta += S1.
+// inv_count > 0 (no exchange of the sums between ranks to wait for): also coef[v][co] = (a, b, m1, mu).
+template <typename T>
+__global__ __launch_bounds__(256) void linbn_stats_kernel(const float* __restrict__ P, const T* __restrict__ w,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma, const double* __restrict__ ws,
+                                                          int groups, double* __restrict__ lsums, float* dgamma,
+                                                          float* dbeta, double inv_count, float4* __restrict__ coef, int C,
+                                                          int p, int views) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);  // (view, co)
+    if (row >= views * C) return;
+    const int v = row / C, co = row - v * C;
+    const float* pr = P + ((long)v * C + co) * p;
+    const T* wr = w + (long)co * p;
+    double acc = 0.0, s1 = 0.0;
+    for (int k = lane; k < p; k += 64) acc += (double)pr[k] * (double)ElemTraits<T>::load(wr + k);
+    for (int g = lane; g < groups; g += 64) s1 += ws[((long)v * groups + g) * 2 * C + co];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        acc += __shfl_xor(acc, o, 64);
+        s1 += __shfl_xor(s1, o, 64);
+    }
+    if (lane == 0) {
+        const float is = invstd[(long)v * C + co], mu = mean[(long)v * C + co];
+        const double s2 = (double)is * (acc - (double)mu * s1);
+        double* ls = lsums + (long)v * 2 * C;
+        ls[co] = s1;
+        ls[C + co] = s2;
+        if (dbeta) atomicAdd(&dbeta[co], (float)s1);   // atomics: both views (and both lanes of a shared projector) add
+        if (dgamma) atomicAdd(&dgamma[co], (float)s2);
+        if (inv_count > 0) {
+            const float a = (gamma ? gamma[co] : 1.f) * is;
+            coef[(long)v * C + co] = make_float4(a, a * is * (float)(s2 * inv_count), (float)(s1 * inv_count), mu);
+        }
+    }
+}
+
+// data parallel: the same coefficients from the all-reduced sums
+__global__ void linbn_coef_kernel(const double* __restrict__ gsums, double inv_count, const float* __restrict__ gamma,
+                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                  float4* __restrict__ coef, int C, int views) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= views * C) return;
+    const int v = t / C, co = t - v * C;
+    const float is = invstd[t], a = (gamma ? gamma[co] : 1.f) * is;
+    const double* gs = gsums + (long)v * 2 * C;
+    coef[t] = make_float4(a, a * is * (float)(gs[C + co] * inv_count), (float)(gs[co] * inv_count), mean[t]);
+}
+
+// ---- sm3_linbn_banks ------------------------------------------------------------------------------------------------
 // grid (p, views): block (ci, v) walks row ci of the data-gradient bank wd [p][C]:
 //   wa[v][ci][co] = T(a wd),  wbn[v][ci][co] = T(-b wd),  col_const[v][ci] = sum_co -(mu f(wbn) + m1 f(wa))
-// (the constant uses the ROUNDED products, so that what the GEMM adds up is centred exactly).  Block ci = 0 also leaves
-// coef[v][{a, b, m1, mu}][C] for the weight-gradient finish and adds the BatchNorm's own parameter gradients.
+// (the constant uses the ROUNDED products, so that what the GEMM adds up is centred exactly).
 template <typename T>
-__global__ __launch_bounds__(256) void linbn_coeffs_kernel(const T* __restrict__ wd, const float* __restrict__ gamma,
-                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           const double* __restrict__ gsums, double inv_count,
-                                                           const double* __restrict__ lsums, float* dgamma, float* dbeta,
-                                                           T* __restrict__ wa, T* __restrict__ wbn,
-                                                           float* __restrict__ col_const, float* __restrict__ coef, int C,
-                                                           int p) {
+__global__ __launch_bounds__(256) void linbn_banks_kernel(const T* __restrict__ wd, const float4* __restrict__ coef,
+                                                          T* __restrict__ wa, T* __restrict__ wbn,
+                                                          float* __restrict__ col_const, int C, int p) {
     constexpr int E = 8;
     __shared__ float red[4];
     const int ci = blockIdx.x, v = blockIdx.y;
     const T* src = wd + (long)ci * C;
     T* oa = wa + ((long)v * p + ci) * C;
     T* ob = wbn + ((long)v * p + ci) * C;
-    const float* mu_v = mean + (long)v * C;
-    const float* is_v = invstd + (long)v * C;
-    const double* gs = gsums + (long)v * 2 * C;
+    const float4* cf = coef + (long)v * C;
     float part = 0.f;
     for (int c0 = threadIdx.x * E; c0 < C; c0 += 256 * E) {
-        float a[E], b[E], m1[E], mu[E];
+        float4 q[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int c = c0 + e;
-            const float is = is_v[c];
-            a[e] = (gamma ? gamma[c] : 1.f) * is;
-            m1[e] = (float)(gs[c] * inv_count);
-            b[e] = a[e] * is * (float)(gs[C + c] * inv_count);
-            mu[e] = mu_v[c];
-        }
+        for (int e = 0; e < E; ++e) q[e] = cf[c0 + e];
         float w[E], fa[E], fb[E];
         unpack16<T>(*reinterpret_cast<const uint4*>(src + c0), w);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            fa[e] = a[e] * w[e];
-            fb[e] = -b[e] * w[e];
+            fa[e] = q[e].x * w[e];
+            fb[e] = -q[e].y * w[e];
         }
         const uint4 pa = pack16<T>(fa), pb = pack16<T>(fb);
         *reinterpret_cast<uint4*>(oa + c0) = pa;
@@ -127,23 +228,7 @@ __global__ __launch_bounds__(256) void linbn_coeffs_kernel(const T* __restrict__
         unpack16<T>(pa, fa);
         unpack16<T>(pb, fb);
 #pragma unroll
-        for (int e = 0; e < E; ++e) part -= mu[e] * fb[e] + m1[e] * fa[e];
-        if (ci == 0) {
-            float* cf = coef + (long)v * 4 * C;
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const int c = c0 + e;
-                cf[c] = a[e];
-                cf[C + c] = b[e];
-                cf[2 * C + c] = m1[e];
-                cf[3 * C + c] = mu[e];
-                if (lsums) {  // parameter gradients from the LOCAL sums (atomics: views / lanes may add concurrently)
-                    const double* ls = lsums + (long)v * 2 * C;
-                    if (dbeta) atomicAdd(&dbeta[c], (float)ls[c]);
-                    if (dgamma) atomicAdd(&dgamma[c], (float)ls[C + c]);
-                }
-            }
-        }
+        for (int e = 0; e < E; ++e) part -= q[e].w * fb[e] + q[e].z * fa[e];
     }
     part = wave_sum(part);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
@@ -152,21 +237,21 @@ __global__ __launch_bounds__(256) void linbn_coeffs_kernel(const T* __restrict__
 }
 
 // ---- sm3_linbn_post -------------------------------------------------------------------------------------------------
-// The two small matrix products of the scheme, as 32 x 32 output tiles, one wave each, operands straight from L2 (they are
-// a few hundred KB): no LDS, no barriers; loads of step t + 1 are issued before the MFMAs of step t.
-//   tiles [0, views * (p/32)^2):  -H_v[k][ci] = sum_co wbn_v[k][co] * wd[ci][co]           (16-bit MFMA, K = C)
-//   tiles beyond:  dw[co][ci] += sum_v a (P_v - m1 s_v^T) - b (W G_v - mu s_v^T)           (exact-f32 MFMA for W G, K = p)
-// f32 tile: lane (i = l & 31, kk = l >> 5) walks k = kk * p/2 + j, j = 0 .. p/2: both operands are read along their rows.
+// 32 x 32 output tiles, one wave each, no LDS:
+//   tiles [0, views (p/32)^2):  hn[v][k][ci] = sum_co wbn_v[k][co] wd[ci][co] = -H_v          (16-bit MFMA, K = C)
+//   tiles beyond:  dw[co][ci] += sum_v a (P_v - m1 s_v^T) - b (W G_v - mu s_v^T),  W G_v read from Tm (saved by
+//                  sm3_linbn_fwd_stats) or, Tm == nullptr, recomputed here on the exact-f32 MFMA
 template <typename T>
 __global__ __launch_bounds__(256) void linbn_post_kernel(const T* __restrict__ wbn, const T* __restrict__ wd,
                                                          T* __restrict__ hn, const float* __restrict__ P,
-                                                         const float* __restrict__ G, const T* __restrict__ w,
-                                                         const float* __restrict__ s, const float* __restrict__ coef,
+                                                         const float* __restrict__ G, const float* __restrict__ Tm,
+                                                         const double* __restrict__ s, const float4* __restrict__ coef,
                                                          float* __restrict__ dw, int C, int p, int views, int h_tiles) {
     const int lane = threadIdx.x & 63, i = lane & 31, kk = lane >> 5;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int pt = p / 32;
     if (tile < h_tiles) {
+        if (tile >= views * pt * pt) return;  // padding of the last H block
         const int v = tile / (pt * pt), rem = tile - v * pt * pt;
         const int k0 = (rem / pt) * 32, c0 = (rem % pt) * 32;
         const T* ap = wbn + ((long)v * p + k0 + i) * C + 8 * kk;
@@ -174,85 +259,57 @@ __global__ __launch_bounds__(256) void linbn_post_kernel(const T* __restrict__ w
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        constexpr int U = 4;  // K-steps of 16 channels per batch of loads (C is a multiple of 128)
-        uint4 fa[U], fb[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            fa[u] = *reinterpret_cast<const uint4*>(ap + 16 * u);
-            fb[u] = *reinterpret_cast<const uint4*>(bp + 16 * u);
-        }
+        constexpr int U = 8;  // K-steps of 16 channels per batch of loads (C is a multiple of 128)
         for (int c = 0; c < C; c += 16 * U) {
-            uint4 na[U], nb[U];
-            const int cn = c + 16 * U < C ? c + 16 * U : c;  // last batch: harmless re-load
+            uint4 fa[U], fb[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                na[u] = *reinterpret_cast<const uint4*>(ap + cn + 16 * u);
-                nb[u] = *reinterpret_cast<const uint4*>(bp + cn + 16 * u);
+                fa[u] = *reinterpret_cast<const uint4*>(ap + c + 16 * u);
+                fb[u] = *reinterpret_cast<const uint4*>(bp + c + 16 * u);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if constexpr (sizeof(T) == 2 && __is_same(T, bf16_t))
+                if constexpr (__is_same(T, bf16_t))
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[u]),
                                                                   __builtin_bit_cast(bf16x8, fb[u]), acc, 0, 0, 0);
                 else
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[u]),
                                                                  __builtin_bit_cast(f16x8, fb[u]), acc, 0, 0, 0);
             }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                fa[u] = na[u];
-                fb[u] = nb[u];
-            }
         }
         T* out = hn + ((long)v * p + k0) * p + c0 + i;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
-            const float q = acc[r];
-            if constexpr (__is_same(T, bf16_t)) out[(long)row * p].v = f32_to_bf16(q);
-            else out[(long)row * p].v = f32_to_f16(q);
+            if constexpr (__is_same(T, bf16_t)) out[(long)row * p].v = f32_to_bf16(acc[r]);
+            else out[(long)row * p].v = f32_to_f16(acc[r]);
         }
         return;
     }
     const int ft = tile - h_tiles;
     if (ft >= (C / 32) * pt) return;
     const int co0 = (ft / pt) * 32, ci0 = (ft % pt) * 32;
-    const int half = p / 2;
     float tot[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) tot[r] = 0.f;
-    const T* ap = w + (long)(co0 + i) * p + kk * half;
     for (int v = 0; v < views; ++v) {
-        const float* bp = G + ((long)v * p + ci0 + i) * p + kk * half;
         f32x16 acc;
+        if (Tm) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        float a4[4];
-        float4 b4 = *reinterpret_cast<const float4*>(bp);
+            for (int r = 0; r < 16; ++r)
+                acc[r] = Tm[((long)v * C + co0 + (r & 3) + 8 * (r >> 2) + 4 * kk) * p + ci0 + i];
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a4[e] = ElemTraits<T>::load(ap + e);
-        for (int j = 0; j < half; j += 4) {
-            const int jn = j + 4 < half ? j + 4 : j;
-            float n4[4];
-            const float4 nb = *reinterpret_cast<const float4*>(bp + jn);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) n4[e] = ElemTraits<T>::load(ap + jn + e);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], b4.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1], b4.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], b4.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], b4.w, acc, 0, 0, 0);
-            b4 = nb;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a4[e] = n4[e];
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            tile_wg<T>(wd, C, G + (long)v * p * p, p, co0, ci0, lane, acc);
         }
-        const float* cf = coef + (long)v * 4 * C;
-        const float sv = s[(long)v * p + ci0 + i];
+        const float sv = (float)s[(long)v * p + ci0 + i];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-            const float a = cf[co], b = cf[C + co], m1 = cf[2 * C + co], mu = cf[3 * C + co];
+            const float4 q = coef[(long)v * C + co];  // (a, b, m1, mu)
             const float pv = P[((long)v * C + co) * p + ci0 + i];
-            tot[r] += a * (pv - m1 * sv) - b * (acc[r] - mu * sv);
+            tot[r] += q.x * (pv - q.z * sv) - q.y * (acc[r] - q.w * sv);
         }
     }
 #pragma unroll
@@ -262,65 +319,100 @@ __global__ __launch_bounds__(256) void linbn_post_kernel(const T* __restrict__ w
     }
 }
 
+inline bool lin16(int dtype) { return dtype == SM3_BF16 || dtype == SM3_F16; }
+
 }  // namespace
 
-extern "C" int sm3_linbn_stats(int dtype, const float* P, const void* w_fwd, const float* mean, const float* invstd,
-                               const double* reduce_ws, int groups, double* lsums, const float* colsum_partials,
-                               int colsum_rows, float* s_out, int C, int p, int views, void* stream) {
-    if (!P || !w_fwd || !mean || !invstd || !reduce_ws || !lsums || !colsum_partials || !s_out) return SM3_EINVAL;
-    if (C <= 0 || p <= 0 || views < 1 || colsum_rows < 1 || groups < 1) return SM3_EINVAL;
-    if (dtype != SM3_BF16 && dtype != SM3_F16) return SM3_EDTYPE;
-    const int row_blocks = (views * C + 3) / 4, col_blocks = views * ((p + 31) / 32);
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == SM3_BF16)
-        hipLaunchKernelGGL(linbn_stats_kernel<bf16_t>, dim3(row_blocks + col_blocks), dim3(256), 0, st, P, (const bf16_t*)w_fwd,
-                           mean, invstd, reduce_ws, groups, lsums, colsum_partials, colsum_rows, s_out, C, p, views,
-                           row_blocks);
-    else
-        hipLaunchKernelGGL(linbn_stats_kernel<f16_t>, dim3(row_blocks + col_blocks), dim3(256), 0, st, P, (const f16_t*)w_fwd,
-                           mean, invstd, reduce_ws, groups, lsums, colsum_partials, colsum_rows, s_out, C, p, views,
-                           row_blocks);
+extern "C" int sm3_linbn_moments(const float* slabs, int nslabs, int64_t n, float* out, const float* colsum_partials,
+                                 int colsum_rows, double* s_out, int p, int views, void* stream) {
+    if (!slabs || !out || nslabs < 1 || n <= 0 || views < 1) return SM3_EINVAL;
+    if (colsum_partials && (!s_out || colsum_rows < 1 || p <= 0)) return SM3_EINVAL;
+    if (n % 4) return SM3_EALIGN;
+    const int gblocks = (int)(((long)views * n / 4 + 255) / 256), cblocks = colsum_partials ? views * ((p + 31) / 32) : 0;
+    hipLaunchKernelGGL(linbn_moments_kernel, dim3(gblocks + cblocks), dim3(256), 0, (hipStream_t)stream, slabs, nslabs, (long)n,
+                       colsum_partials, colsum_rows, out, s_out, p, views, gblocks);
     SM3_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int sm3_linbn_coeffs(int dtype, const void* w_dgrad, const float* gamma, const float* mean, const float* invstd,
-                                const double* global_sums, double count, const double* local_sums, float* dgamma,
-                                float* dbeta, void* wa, void* wbn, float* col_const, float* coef, int C, int p, int views,
-                                void* stream) {
-    if (!w_dgrad || !mean || !invstd || !global_sums || !wa || !wbn || !col_const || !coef) return SM3_EINVAL;
-    if (C <= 0 || p <= 0 || views < 1 || !(count > 0)) return SM3_EINVAL;
-    if (dtype != SM3_BF16 && dtype != SM3_F16) return SM3_EDTYPE;
+extern "C" int sm3_linbn_fwd_stats(int dtype, const float* G, const void* w_dgrad, const void* w_fwd, const double* s,
+                                   float* Tm, double* sums_ws, int C, int p, int views, void* stream) {
+    if (!G || !w_dgrad || !w_fwd || !s || !Tm || !sums_ws || C <= 0 || p <= 0 || views < 1) return SM3_EINVAL;
+    if (!lin16(dtype)) return SM3_EDTYPE;
+    if (C % 32 || p % 32) return SM3_EALIGN;
+    const unsigned blocks = (unsigned)((views * (C / 32) * (p / 32) + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SM3_BF16)
+        hipLaunchKernelGGL(linbn_fwd_stats_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, G, (const bf16_t*)w_dgrad,
+                           (const bf16_t*)w_fwd, s, Tm, sums_ws, C, p, views);
+    else
+        hipLaunchKernelGGL(linbn_fwd_stats_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, G, (const f16_t*)w_dgrad,
+                           (const f16_t*)w_fwd, s, Tm, sums_ws, C, p, views);
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_linbn_stats(int dtype, const float* P, const void* w_fwd, const float* mean, const float* invstd,
+                               const float* gamma, const double* reduce_ws, int groups, double* lsums, float* dgamma,
+                               float* dbeta, double count, float* coef, int C, int p, int views, void* stream) {
+    if (!P || !w_fwd || !mean || !invstd || !reduce_ws || !lsums) return SM3_EINVAL;
+    if (C <= 0 || p <= 0 || views < 1 || groups < 1 || (count > 0 && !coef)) return SM3_EINVAL;
+    if (!lin16(dtype)) return SM3_EDTYPE;
+    const unsigned blocks = (unsigned)((views * C + 3) / 4);
+    const double inv = count > 0 ? 1.0 / count : 0.0;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SM3_BF16)
+        hipLaunchKernelGGL(linbn_stats_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, P, (const bf16_t*)w_fwd, mean, invstd,
+                           gamma, reduce_ws, groups, lsums, dgamma, dbeta, inv, (float4*)coef, C, p, views);
+    else
+        hipLaunchKernelGGL(linbn_stats_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, P, (const f16_t*)w_fwd, mean, invstd,
+                           gamma, reduce_ws, groups, lsums, dgamma, dbeta, inv, (float4*)coef, C, p, views);
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_linbn_coef(const double* global_sums, double count, const float* gamma, const float* mean,
+                              const float* invstd, float* coef, int C, int views, void* stream) {
+    if (!global_sums || !mean || !invstd || !coef || C <= 0 || views < 1 || !(count > 0)) return SM3_EINVAL;
+    hipLaunchKernelGGL(linbn_coef_kernel, dim3((views * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, global_sums,
+                       1.0 / count, gamma, mean, invstd, (float4*)coef, C, views);
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_linbn_banks(int dtype, const void* w_dgrad, const float* coef, void* wa, void* wbn, float* col_const,
+                               int C, int p, int views, void* stream) {
+    if (!w_dgrad || !coef || !wa || !wbn || !col_const || C <= 0 || p <= 0 || views < 1) return SM3_EINVAL;
+    if (!lin16(dtype)) return SM3_EDTYPE;
     if (C % 8) return SM3_EALIGN;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SM3_BF16)
-        hipLaunchKernelGGL(linbn_coeffs_kernel<bf16_t>, dim3(p, views), dim3(256), 0, st, (const bf16_t*)w_dgrad, gamma, mean,
-                           invstd, global_sums, 1.0 / count, local_sums, dgamma, dbeta, (bf16_t*)wa, (bf16_t*)wbn, col_const,
-                           coef, C, p);
+        hipLaunchKernelGGL(linbn_banks_kernel<bf16_t>, dim3(p, views), dim3(256), 0, st, (const bf16_t*)w_dgrad,
+                           (const float4*)coef, (bf16_t*)wa, (bf16_t*)wbn, col_const, C, p);
     else
-        hipLaunchKernelGGL(linbn_coeffs_kernel<f16_t>, dim3(p, views), dim3(256), 0, st, (const f16_t*)w_dgrad, gamma, mean,
-                           invstd, global_sums, 1.0 / count, local_sums, dgamma, dbeta, (f16_t*)wa, (f16_t*)wbn, col_const,
-                           coef, C, p);
+        hipLaunchKernelGGL(linbn_banks_kernel<f16_t>, dim3(p, views), dim3(256), 0, st, (const f16_t*)w_dgrad,
+                           (const float4*)coef, (f16_t*)wa, (f16_t*)wbn, col_const, C, p);
     SM3_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int sm3_linbn_post(int dtype, const void* wbn, const void* w_dgrad, void* hn, const float* P, const float* G,
-                              const void* w_fwd, const float* s, const float* coef, float* dw, int C, int p, int views,
+                              const float* Tm, const double* s, const float* coef, float* dw, int C, int p, int views,
                               void* stream) {
-    if (!wbn || !w_dgrad || !hn || !P || !G || !w_fwd || !s || !coef || !dw) return SM3_EINVAL;
+    if (!wbn || !w_dgrad || !hn || !P || (!G && !Tm) || !s || !coef || !dw) return SM3_EINVAL;
     if (C <= 0 || p <= 0 || views < 1) return SM3_EINVAL;
-    if (dtype != SM3_BF16 && dtype != SM3_F16) return SM3_EDTYPE;
+    if (!lin16(dtype)) return SM3_EDTYPE;
     if (C % 128 || p % 32) return SM3_EALIGN;
     const int pt = p / 32, h_tiles = views * pt * pt, f_tiles = (C / 32) * pt;
-    const unsigned blocks = (unsigned)((h_tiles + f_tiles + 3) / 4);
+    const int h_pad = (h_tiles + 3) / 4 * 4;  // a block is all-H or all-finish
+    const unsigned blocks = (unsigned)(h_pad / 4 + (f_tiles + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SM3_BF16)
         hipLaunchKernelGGL(linbn_post_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)wbn, (const bf16_t*)w_dgrad,
-                           (bf16_t*)hn, P, G, (const bf16_t*)w_fwd, s, coef, dw, C, p, views, h_tiles);
+                           (bf16_t*)hn, P, G, Tm, s, (const float4*)coef, dw, C, p, views, h_pad);
     else
         hipLaunchKernelGGL(linbn_post_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, (const f16_t*)wbn, (const f16_t*)w_dgrad,
-                           (f16_t*)hn, P, G, (const f16_t*)w_fwd, s, coef, dw, C, p, views, h_tiles);
+                           (f16_t*)hn, P, G, Tm, s, (const float4*)coef, dw, C, p, views, h_pad);
     SM3_CHECK_LAUNCH();
     return 0;
 }

@@ -60,10 +60,15 @@ SIGNATURES = {
     "sm3_conv_dgrad_bnfuse": [_DESC, _P, _P, _P, _P, _P, _P],
     "sm3_conv_dgrad_seg_bnfuse": [_DESC, _P, _P, _P, _P, _P, _P, _P],
     "sm3_conv_wgrad_cat": [_DESC, _P, _P, _P, _P, _I, _P, _I, _L, _L, _P],
-    "sm3_bn_act_colsum_rows": [_L, _I, _I, _I],
+    "sm3_bn_act_colsum_rows": [_L, _I, _I],
+    "sm3_conv_wgrad_slabs": [_DESC, _P, _P, _P, _I, _I, _P, _P],
+    "sm3_linbn_moments": [_P, _I, _L, _P, _P, _I, _P, _I, _I, _P],
     "sm3_bn_act_colsum": [_I, _P, _P, _P, _P, _I, _P, _P, _P, _L, _I, _I, _P],
-    "sm3_linbn_stats": [_I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _P],
-    "sm3_linbn_coeffs": [_I, _P, _P, _P, _P, _P, _D, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "sm3_conv_bn_act_fused": [_DESC, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P],
+    "sm3_linbn_fwd_stats": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "sm3_linbn_stats": [_I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _D, _P, _I, _I, _I, _P],
+    "sm3_linbn_coef": [_P, _D, _P, _P, _P, _P, _I, _I, _P],
+    "sm3_linbn_banks": [_I, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "sm3_linbn_post": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "sm3_conv_bn_act_eval": [_DESC, _P, _P, _P, _P, _P, _I, _P, _P],
     "sm3_conv_bn_eval": [_DESC, _P, _P, _P, _P, _P, _P, _F, _P, _I, _P, _P],

@@ -163,7 +163,7 @@ class BNUnit:
 class Rec:
     """What one conv+BN(+act) application saves for backward."""
     __slots__ = ("cu", "bu", "N", "H", "W", "Ho", "Wo", "x_in", "xo", "mean", "invstd", "y", "relu", "mask", "V",
-                 "frozen_stats", "scale", "shift", "colsum", "colsum_rows", "linbn", "gram")
+                 "frozen_stats", "scale", "shift", "colsum", "linbn", "gram", "Tm")
 
 
 class EncoderPlan:
@@ -289,6 +289,9 @@ class SM3Engine:
         # BatchNorm backward by linearity for conv3 -> bn3 of every Bottleneck (csrc/linbn.hip): no bn3 backward-apply
         # pass and no backward read of conv3's output.  16-bit modes only; the exact-f32 parity mode keeps two passes.
         self.linbn = self.dtype in (SM3_BF16, SM3_F16) and _os.environ.get("SM3_LINBN", "1") != "0"
+        # ... and, for the blocks without a downsample branch, the forward half of it: bn3's batch statistics from the
+        # moments of conv3's input, bn3 + residual + ReLU inside conv3's epilogue -- conv3's output never reaches HBM
+        self.linbn_fwd = _os.environ.get("SM3_LINBN_FWD", "1") != "0"
 
     # ---- setup ---------------------------------------------------------------------------
     def _all_conv_units(self):
@@ -434,7 +437,7 @@ class SM3Engine:
 
     # ---- conv + BN (+residual) (+ReLU) ---------------------------------------------------
     def conv_bn(self, cu, bu, x, N, H, W, relu, residual=None, train=True, save=None, out_f32=False, y_out=None,
-                apply=True, scale_shift=None, res_affine=None, pending=None, colsum=False):
+                apply=True, scale_shift=None, res_affine=None, pending=None, colsum=None):
         """One conv + BatchNorm (+residual) (+ReLU) unit on N images.  With self._V == 2 the batch is two views back
         to back (N = 2B): one convolution launch, BatchNorm statistics / running-statistics updates per view.
         apply=False: stop after the statistics -- returns the pre-BatchNorm tensor, scale/shift are left in
@@ -547,15 +550,13 @@ class SM3Engine:
                 y_out = torch.empty(rows, C, dtype=torch.float32 if out_f32 else self.tdt, device=dev)
             if save is not None and relu:  # 1 bit per element of (y > 0): what backward needs instead of re-reading y
                 mask = torch.empty(rows * C // (16 // ops._sz(self.dtype)), dtype=torch.uint8, device=dev)
-            cs = cs_rows = None
+            cs = None
             if res_affine is not None:
                 ops.bn_add_bn_act(self.dtype, xo, scale, shift, residual, res_affine[0], res_affine[1], relu, y_out,
                                   rows_v, C, mask=mask, views=V)
             else:
-                if colsum and save is not None and train and not out_f32:
-                    # column sums of this unit's output = first moment of the next convolution's input (linbn)
-                    cs_rows = ops.bn_act_colsum_rows(self.dtype, rows_v, C, V)
-                    cs = torch.empty(V * cs_rows * C, dtype=torch.float32, device=dev)
+                if colsum is not None and save is not None and train and not out_f32:
+                    cs = colsum  # += column sums of this unit's output: first moment of the next convolution's input (linbn)
                 ops.bn_act(self.dtype, xo, scale, shift, residual, relu, y_out, rows_v, C, out_f32=out_f32, mask=mask,
                            views=V, colsum=cs)
         if save is not None:
@@ -565,9 +566,9 @@ class SM3Engine:
             r.V = V
             r.frozen_stats = not train
             r.scale = r.shift = None
-            r.colsum, r.colsum_rows = (cs, cs_rows) if apply else (None, None)
+            r.colsum = cs if apply else None
             r.linbn = False
-            r.gram = None
+            r.gram = r.Tm = None
             save.append(r)
         return (y_out if apply else xo), Ho, Wo
 
@@ -661,6 +662,12 @@ class SM3Engine:
             cache[key] = ops.fwd_desc(dtype, M, 1, 1, K, N, 1, 1, 0)
         return cache[key]
 
+    def _slab_buf(self, n, V):
+        """Workspace for a plain-store split-K launch (ops.conv_wgrad_slabs): up to SLAB_CAP slabs of n floats per view,
+        at most 64 MB per view."""
+        cap = max(1, min(ops.SLAB_CAP, (1 << 24) // n))
+        return self._work("linbn_slabs", V * cap * n)
+
     def _lin_conv_desc(self, dtype, N, H, W, Ci, Co):
         """Descriptor of a 1x1 / stride-1 convolution Ci -> Co over an [N, H, W] map (weight-gradient-kernel launches
         that are not tied to a ConvUnit: the Gram matrix of an activation)."""
@@ -670,31 +677,85 @@ class SM3Engine:
             cache[key] = ops.fwd_desc(dtype, N, H, W, Ci, Co, 1, 1, 0)
         return cache[key]
 
-    def conv3_backward_linbn(self, r3, r2, dz, bpart, prow, P, rd=None):
+    def conv3_bn3_fused(self, cu, bu, r2, y2, idn, N, H, W, save):
+        """conv3 -> bn3 (train mode) -> + identity -> ReLU of a Bottleneck (resnet.py:162-172) without its pre-BatchNorm
+        tensor: bn3's batch sums are linear / quadratic forms of the moments of y2 (r2.colsum = sum y2, r2.gram =
+        y2^T y2; sm3_linbn_fwd_stats), so its scale / shift are known BEFORE conv3 runs and conv3 applies them, the residual
+        and the ReLU in its own epilogue (sm3_conv_bn_act_fused)."""
+        dev = y2.device
+        C, p, V = cu.Co, cu.Ci, self._V
+        d = cu.fwd_desc(self.dtype, N, H, W)
+        rows = N * d.Ho * d.Wo
+        rows_v = rows // V
+        if V > 1 and rows_v % 128:
+            raise ValueError("two views in one batch need a multiple of 128 rows per view")
+        Tm = torch.empty(V * C * p, dtype=torch.float32, device=dev)
+        groups = p // 32
+        ws = self._work("linbn_fws", V * groups * 2 * C, torch.float64)
+        ops.linbn_fwd_stats(self.dtype, r2.gram, cu.w_dgrad, cu.w_fwd, r2.colsum, Tm, ws, C, p, V)
+        count = rows_v
+        if self.stat_sync is not None:
+            self.stat_sync(ws[: V * groups * 2 * C])  # SyncBatchNorm: the partial rows add up over ranks like the sums
+            count = rows_v * self.world_size
+        scale, shift = self._work("scale", 2 * 2048), self._work("shift", 2 * 2048)
+        mean = torch.empty(V * C, dtype=torch.float32, device=dev)
+        invstd = torch.empty(V * C, dtype=torch.float32, device=dev)
+        track = not self.__dict__.get("_no_stat_update", False)
+        ops.bn_finalize(ws, count, C, self._p(bu.name + ".weight") if bu.affine else None,
+                        self._p(bu.name + ".bias") if bu.affine else None, BN_EPS, BN_MOMENTUM,
+                        self.buffers[bu.name + ".running_mean"] if track else None,
+                        self.buffers[bu.name + ".running_var"] if track else None,
+                        self.buffers[bu.name + ".num_batches_tracked"] if track else None,
+                        scale, shift, mean, invstd, groups=groups, views=V)
+        y3 = torch.empty(rows, C, dtype=self.tdt, device=dev)
+        mask = torch.empty(rows * C // (16 // ops._sz(self.dtype)), dtype=torch.uint8, device=dev)
+        ops.conv_bn_act_fused(d, y2, cu.w_fwd, scale, shift, idn, True, y3, mask, views=V)
+        r = Rec()
+        r.cu, r.bu, r.N, r.H, r.W, r.Ho, r.Wo = cu, bu, N, H, W, d.Ho, d.Wo
+        r.x_in, r.xo, r.mean, r.invstd, r.y, r.relu, r.mask = y2, None, mean, invstd, y3, True, mask
+        r.V = V
+        r.frozen_stats = False
+        r.scale = r.shift = None
+        r.colsum = r.gram = None
+        r.linbn = True
+        r.Tm = Tm
+        save.append(r)
+        return y3, d.Ho, d.Wo
+
+    def conv3_backward_linbn(self, r3, r2, dz, bpart, prow, rd=None):
         """Backward of conv3 -> bn3 BY LINEARITY (csrc/linbn.hip; reference: the autograd backward of
         src/models/resnet.py:162-163).  dz: the masked gradient of the block output [M, C]; bpart: its partial rows
-        [V][prow][2][C] (only sum(dz) is used) as left by the producing data-gradient launch; P: zeroed fp32 [V][C][p].
-        No pass over bn3's input or output: the weight gradient runs on dz itself (the [p, p] Gram matrix of conv3's input
-        y2 came with the forward pass), the data gradient is one GEMM over the two K segments [dz | y2].  Accumulates d(conv3.weight), d(bn3.weight/bias).
+        [V][prow][2][C] (only sum(dz) is used) as left by the producing data-gradient launch.
+        No pass over bn3's input or output: the weight gradient runs on dz itself, the data gradient is one GEMM over the
+        two K segments [dz | y2]; the moments of y2 (r2.colsum, r2.gram) and W G (r3.Tm) came with the forward pass.
+        Accumulates d(conv3.weight), d(bn3.weight/bias).
         rd: the downsample unit of the block, whose BatchNorm received the same dz (resnet.py:164-172): its two-pass
         backward runs alongside -- statistics in the SAME SyncBN exchange as bn3's, apply pass in place over dz once the
         GEMMs above have read it.
         Returns (dz2 = masked gradient of bn2's output, bn2's phase-1 partial rows per view, d(downsample conv output))."""
         cu, bu = r3.cu, r3.bu
         C, p, V = cu.Co, cu.Ci, r3.V
-        M = r3.xo.shape[0]
+        M = r3.N * r3.Ho * r3.Wo
         rows = M // V
         y2 = r3.x_in
-        # 1. P = dz^T y2 [V][C][p]: the weight-gradient kernel on dz itself
-        G = r2.gram
-        ops.conv_wgrad_cat(cu.wgrad_desc(self.dtype, r3.N, r3.H, r3.W), y2, dz, P, views=V)
-        # 2. local sums [bn3 | downsample][V][2C]: sum(dz) from the fused partial rows, sum(dz * xhat) from P
+        G, s = r2.gram, r2.colsum
+        aff = bu.affine
+        gamma = self._p(bu.name + ".weight") if aff else None
+        # 1. P = dz^T y2 [V][C][p]: the weight-gradient kernel on dz itself, plain-store split-K slabs summed in order
+        slabs = self._slab_buf(C * p, V)
+        ns = ops.conv_wgrad_slabs(cu.wgrad_desc(self.dtype, r3.N, r3.H, r3.W), y2, dz, slabs, views=V)
+        P = self._work("linbn_P", V * C * p)
+        ops.linbn_moments(slabs, ns, C * p, P, views=V)
+        # 2. local sums [bn3 | downsample][V][2C]: sum(dz) from the fused partial rows, sum(dz * xhat) from P; d(gamma),
+        #    d(beta); single rank: the coefficients (a, b, m1, mu) too
         n = V * 2 * C
         tot = n * (2 if rd is not None else 1)
-        s = self._work("linbn_s", V * p)
         lsums = self._work("lsums2", 2 * 2 * 2 * 2048, torch.float64)
+        coef = self._work("linbn_coef", V * 4 * C)
         ws, groups = ops.bn_stats_reduce(bpart, prow, C, None, views=V)  # stage A; stage B runs inside linbn_stats
-        ops.linbn_stats(self.dtype, P, cu.w_fwd, r3.mean, r3.invstd, ws, groups, lsums, r2.colsum, r2.colsum_rows, s, C, p, V)
+        ops.linbn_stats(self.dtype, P, cu.w_fwd, r3.mean, r3.invstd, gamma, ws, groups, lsums,
+                        self._g(bu.name + ".weight") if aff else None, self._g(bu.name + ".bias") if aff else None,
+                        rows if self.stat_sync is None else 0, coef, C, p, V)
         if rd is not None:
             prow_d = ops.bn_bwd_partial_rows(rows, C)
             dpart = self._work("partials_d", V * prow_d * 2 * C)
@@ -706,19 +767,15 @@ class SM3Engine:
             gsums[:tot].copy_(lsums[:tot])
             self.stat_sync(gsums[:tot])  # one all-reduce for the two BatchNorms (and both views)
             count = rows * self.world_size
-        # 3. a, b per channel; diag(a) W and -diag(b) W in data-gradient order; the constant term; d(gamma), d(beta)
+            ops.linbn_coef(gsums[:n], count, gamma, r3.mean, r3.invstd, coef, C, V)
+        # 3. diag(a) W and -diag(b) W in data-gradient order, the constant term
         wa = self._work("linbn_wa", V * p * C, self.tdt)
         wbn = self._work("linbn_wbn", V * p * C, self.tdt)
         cconst = self._work("linbn_const", V * p)
-        coef = self._work("linbn_coef", V * 4 * C)
-        aff = bu.affine
-        ops.linbn_coeffs(self.dtype, cu.w_dgrad, self._p(bu.name + ".weight") if aff else None, r3.mean, r3.invstd,
-                         gsums[:n], count, lsums[:n], self._g(bu.name + ".weight") if aff else None,
-                         self._g(bu.name + ".bias") if aff else None, wa, wbn, cconst, coef, C, p, V)
-        # 4. -H_v = (-diag(b_v) W)^T W [V][p][p], and d(conv3.weight) += diag(a)(P - m1 s^T) - diag(b)(W G - mu s^T):
-        #    32 x 32 MFMA tiles of one launch
+        ops.linbn_banks(self.dtype, cu.w_dgrad, coef, wa, wbn, cconst, C, p, V)
+        # 4. -H_v = (-diag(b_v) W)^T W [V][p][p], and d(conv3.weight) += diag(a)(P - m1 s^T) - diag(b)(W G - mu s^T)
         Hn = self._work("linbn_H", V * p * p, self.tdt)
-        ops.linbn_post(self.dtype, wbn, cu.w_dgrad, Hn, P, G, cu.w_fwd, s, coef, self._g(cu.name + ".weight"), C, p, V)
+        ops.linbn_post(self.dtype, wbn, cu.w_dgrad, Hn, P, G, r3.Tm, s, coef, self._g(cu.name + ".weight"), C, p, V)
         # 5. data gradient [dz | y2] x [diag(a) W ; -H]^T + const, with bn2's ReLU mask and phase 1 in the epilogue
         descs, full = cu.dgrad_descs(self.dtype, r3.N, r3.H, r3.W)
         dd = descs[0]
@@ -870,24 +927,30 @@ class SM3Engine:
         del stem_in
         cur, h, w = p, Hp, Wp
         block_recs = []
-        # conv3 -> bn3 backward by linearity needs sum(y2) and the Gram matrix y2^T y2 of conv3's input per view: the first
-        # from bn2's apply pass, the second from one launch of the weight-gradient kernel on y2 alone.  All blocks' Gram
-        # matrices live in one buffer, zeroed once (the kernel accumulates with atomics).
+        # BatchNorm by linearity for conv3 -> bn3 (csrc/linbn.hip) needs two moments of conv3's input y2 per view: sum(y2),
+        # which bn2's apply pass adds up on the side (per-block partial rows), and the Gram matrix y2^T y2, one launch of the
+        # weight-gradient kernel on y2 alone (plain-store split-K slabs); sm3_linbn_moments adds both up in a fixed order,
+        # so the forward pass stays bit-reproducible.
         Vt = self._V if train else 1
         lin_ok = [self.linbn and train and save is not None and b["c3"].Co % 128 == 0 and b["c3"].Ci % 64 == 0
                   for b in plan.blocks]
-        gram_all = torch.zeros(sum(Vt * b["c3"].Ci ** 2 for b, ok in zip(plan.blocks, lin_ok) if ok), dtype=torch.float32,
-                               device=x.device) if any(lin_ok) else None
-        gram_off = 0
         for blk, lin in zip(plan.blocks, lin_ok):
             br = [] if save is not None else None
             y1, h1, w1 = self.conv_bn(blk["c1"], blk["b1"], cur, N, h, w, True, None, train, br)
-            y2, h2, w2 = self.conv_bn(blk["c2"], blk["b2"], y1, N, h1, w1, True, None, train, br, colsum=lin)
-            if lin and br[1].colsum is not None:
-                pp = blk["c3"].Ci
-                br[1].gram = gram_all[gram_off: gram_off + Vt * pp * pp]
-                gram_off += Vt * pp * pp
-                ops.conv_wgrad_cat(self._lin_conv_desc(self.dtype, N, h2, w2, pp, pp), y2, y2, br[1].gram, views=Vt)
+            pp = blk["c3"].Ci
+            cs = crow = None
+            if lin:
+                d2 = blk["c2"].fwd_desc(self.dtype, N, h1, w1)
+                crow = ops.bn_act_colsum_rows(self.dtype, N * d2.Ho * d2.Wo // Vt, pp)
+                cs = self._work("linbn_cs", Vt * crow * pp)
+            y2, h2, w2 = self.conv_bn(blk["c2"], blk["b2"], y1, N, h1, w1, True, None, train, br, colsum=cs)
+            if lin:
+                slabs = self._slab_buf(pp * pp, Vt)
+                ns = ops.conv_wgrad_slabs(self._lin_conv_desc(self.dtype, N, h2, w2, pp, pp), y2, y2, slabs, views=Vt)
+                br[1].gram = torch.empty(Vt * pp * pp, dtype=torch.float32, device=x.device)
+                br[1].colsum = torch.empty(Vt * pp, dtype=torch.float64, device=x.device)
+                ops.linbn_moments(slabs, ns, pp * pp, br[1].gram, views=Vt, colsum=cs, colsum_rows=crow,
+                                  s_out=br[1].colsum, p=pp)
             ra = None
             pend = None
             if "cd" in blk and lazy:
@@ -901,10 +964,14 @@ class SM3Engine:
                 idn, _, _ = self.conv_bn(blk["cd"], blk["bd"], cur, N, h, w, False, None, train, br)
             else:
                 idn = cur
-            y3, h3, w3 = self.conv_bn(blk["c3"], blk["b3"], y2, N, h2, w2, True, idn, train, br, res_affine=ra,
-                                      pending=pend)
-            if lin and br[1].gram is not None:
-                br[-1].linbn = True  # backward of conv3 -> bn3 by linearity; needs br[1].colsum / .gram (moments of y2)
+            if lin and "cd" not in blk and self.linbn_fwd and not self._ordered_bn:
+                # conv3 -> bn3 -> (+identity) -> ReLU in ONE launch: bn3's batch statistics come from the moments of y2
+                y3, h3, w3 = self.conv3_bn3_fused(blk["c3"], blk["b3"], br[1], y2, idn, N, h2, w2, br)
+            else:
+                y3, h3, w3 = self.conv_bn(blk["c3"], blk["b3"], y2, N, h2, w2, True, idn, train, br, res_affine=ra,
+                                          pending=pend)
+                if lin:
+                    br[-1].linbn = True  # backward of conv3 -> bn3 by linearity; needs br[1].colsum / .gram (moments of y2)
             block_recs.append(br)
             cur, h, w = y3, h3, w3
         ops.avgpool_fwd(self.dtype, cur, feat_f32, feat_t, N, h * w, plan.out_dim)
@@ -921,10 +988,6 @@ class SM3Engine:
         dcur = torch.empty(N * h * w, plan.out_dim, dtype=self.tdt, device=dfeat.device)
         ops.avgpool_bwd(self.dtype, dfeat, dcur, N, h * w, plan.out_dim)
         fr = None  # rows of fused BN-backward partials that came with dcur
-        # the weight-gradient products dz^T y2 of the blocks that go by linearity: one zeroed buffer for all of them
-        lin_sz = {bi: br[-1].V * br[-1].cu.Co * br[-1].cu.Ci for bi, br in enumerate(ctx["blocks"]) if br[-1].linbn}
-        lin_P = torch.zeros(sum(lin_sz.values()), dtype=torch.float32, device=dfeat.device) if lin_sz else None
-        lin_off = 0
         for bi in range(len(plan.blocks) - 1, -1, -1):
             blk, br = plan.blocks[bi], ctx["blocks"][bi]
             if "cd" in blk:
@@ -935,16 +998,14 @@ class SM3Engine:
                 # conv3 -> bn3 by linearity: dz (dcur, masked) feeds the weight- and data-gradient GEMMs as it is
                 if fr is None:  # last block: dcur is the un-masked gradient from the pooling layer
                     C3, V3 = r3.cu.Co, r3.V
-                    rows3 = r3.xo.shape[0] // V3
+                    rows3 = r3.N * r3.Ho * r3.Wo // V3
                     prow = ops.bn_bwd_partial_rows(rows3, C3)
                     bpart = self._work("partials", V3 * prow * 2 * C3)
                     ops.bn_bwd_reduce(self.dtype, dcur, None, r3.xo, r3.mean, r3.invstd, dcur, rows3, C3, bpart,
                                       mask=r3.mask, views=V3)
                 else:
                     prow, bpart = fr, self._ws[(self._lane, "fz_partials")]
-                dy2, fr2, dxd = self.conv3_backward_linbn(r3, r2, dcur, bpart, prow,
-                                                          lin_P[lin_off: lin_off + lin_sz[bi]], rd=rd)
-                lin_off += lin_sz[bi]
+                dy2, fr2, dxd = self.conv3_backward_linbn(r3, r2, dcur, bpart, prow, rd=rd)
                 dz = None if rd is not None else dcur
             else:
                 if rd is not None:

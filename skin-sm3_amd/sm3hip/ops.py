@@ -407,55 +407,150 @@ def conv_wgrad_cat(desc, x, dy, dw, dy1=None, dw1=None, views=1):
               "sm3_conv_wgrad_cat")
 
 
-def linbn_stats(dtype, P, w_fwd, mean, invstd, reduce_ws, groups, lsums, colsum, colsum_rows, s_out, Cn, p, views=1):
+SLAB_CAP = 256  # slabs per view a plain-store split-K launch may use (sm3_conv_wgrad_slabs)
+
+
+def conv_wgrad_slabs(desc, x, dy, slabs, views=1):
+    """dy_v^T x_v without atomics: every pixel slice stores its partial [Co][taps*Ci] product into a slab of its own
+    (sm3_conv_wgrad_slabs).  slabs: fp32 with room for views * SLAB_CAP slabs.  Returns the slabs used per view; the slabs
+    of view v are slabs[(v * used + j) * Co * taps * Ci ...]."""
+    tdt = TORCH_DTYPE[desc.dtype]
+    _chk(x, tdt, "x"); _chk(dy, tdt, "dy"); _chk(slabs, torch.float32, "slabs")
+    M = desc.N * desc.Ho * desc.Wo
+    n = desc.Co * desc.w_row_stride
+    if x.numel() != desc.N * desc.Hi * desc.Wi * desc.Ci or dy.numel() != M * desc.Co or M % views or \
+            desc.w_row_stride != desc.ntaps * desc.Ci:
+        raise ValueError("conv_wgrad_slabs: operand size does not match descriptor")
+    cap = min(SLAB_CAP, slabs.numel() // (views * n))
+    if cap < 1:
+        raise ValueError("conv_wgrad_slabs: slab buffer too small")
+    used = C.c_int(0)
+    sz = _sz(desc.dtype)
+    tag = "conv_wgrad"
+    if _PROFILER is not None and getattr(_PROFILER, "detail", False):
+        tag += f"|M{M}_K{desc.ntaps}x{desc.Ci}_N{desc.Co}_v{views}_slabs"
+    with _prof(tag, 2.0 * M * desc.Co * desc.ntaps * desc.Ci, sz * (x.numel() + dy.numel())):
+        check(_lib.load().sm3_conv_wgrad_slabs(C.byref(desc), _ptr(x), _ptr(dy), _ptr(slabs), cap, views, C.byref(used),
+                                               _stream()), "sm3_conv_wgrad_slabs")
+    return used.value
+
+
+def linbn_moments(slabs, nslabs, n, out, views=1, colsum=None, colsum_rows=0, s_out=None, p=0):
+    """out[v] = sum of view v's nslabs slabs (fixed order); with colsum partial rows also s_out[v] = their sum
+    (sm3_linbn_moments)."""
+    _chk(slabs, torch.float32, "slabs"); _chk(out, torch.float32, "out"); _chk(colsum, torch.float32, "colsum")
+    _chk(s_out, torch.float64, "s_out")
+    if slabs.numel() < views * nslabs * n or out.numel() < views * n or n % 4:
+        raise ValueError("linbn_moments: size mismatch")
+    if colsum is not None and (s_out is None or colsum.numel() < views * colsum_rows * p or s_out.numel() < views * p):
+        raise ValueError("linbn_moments: colsum / s_out size mismatch")
+    with _prof("linbn_small", 0.0, 4.0 * views * n * (nslabs + 1)):
+        check(_lib.load().sm3_linbn_moments(_ptr(slabs), nslabs, n, _ptr(out), _ptr(colsum), colsum_rows, _ptr(s_out), p,
+                                            views, _stream()), "sm3_linbn_moments")
+
+
+def linbn_fwd_stats(dtype, G, w_dgrad, w_fwd, s, Tm, sums_ws, Cn, p, views=1):
+    """Tm[v] = W G_v and the batch sums of x = y W^T as [views][p/32][2C] fp64 partial rows for bn_finalize(groups=p/32)
+    (sm3_linbn_fwd_stats).  Returns the number of groups."""
+    tdt = TORCH_DTYPE[dtype]
+    _chk(G, torch.float32, "G"); _chk(w_dgrad, tdt, "w_dgrad"); _chk(w_fwd, tdt, "w_fwd"); _chk(s, torch.float64, "s")
+    _chk(Tm, torch.float32, "Tm"); _chk(sums_ws, torch.float64, "sums_ws")
+    if Cn % 32 or p % 32 or G.numel() < views * p * p or w_dgrad.numel() != p * Cn or w_fwd.numel() != Cn * p or \
+            s.numel() < views * p or Tm.numel() < views * Cn * p or sums_ws.numel() < views * (p // 32) * 2 * Cn:
+        raise ValueError("linbn_fwd_stats: size mismatch")
+    with _prof("linbn_small", 2.0 * views * Cn * p * p, 4.0 * views * (Cn * p + p * p) + _sz(dtype) * 2 * Cn * p):
+        check(_lib.load().sm3_linbn_fwd_stats(dtype, _ptr(G), _ptr(w_dgrad), _ptr(w_fwd), _ptr(s), _ptr(Tm), _ptr(sums_ws),
+                                              Cn, p, views, _stream()), "sm3_linbn_fwd_stats")
+    return p // 32
+
+
+def linbn_stats(dtype, P, w_fwd, mean, invstd, gamma, reduce_ws, groups, lsums, dgamma, dbeta, count, coef, Cn, p, views=1):
     """lsums[v] = (sum dz | sum dz * xhat): the first from stage A of bn_stats_reduce (reduce_ws, groups), the second from
-    P = dz^T y; s_out[v] = column sums of y (sm3_linbn_stats)."""
-    _chk(P, torch.float32, "P"); _chk(w_fwd, TORCH_DTYPE[dtype], "w_fwd"); _chk(mean, torch.float32); _chk(invstd, torch.float32)
-    _chk(lsums, torch.float64, "lsums"); _chk(colsum, torch.float32, "colsum"); _chk(s_out, torch.float32, "s_out")
-    _chk(reduce_ws, torch.float64, "reduce_ws")
+    P = dz^T y; d(gamma), d(beta) accumulated; count > 0: coef [views][C][4] written too (sm3_linbn_stats)."""
+    _chk(P, torch.float32, "P"); _chk(w_fwd, TORCH_DTYPE[dtype], "w_fwd")
+    for t in (mean, invstd, gamma, dgamma, dbeta, coef):
+        _chk(t, torch.float32)
+    _chk(lsums, torch.float64, "lsums"); _chk(reduce_ws, torch.float64, "reduce_ws")
     if P.numel() < views * Cn * p or w_fwd.numel() != Cn * p or mean.numel() < views * Cn or invstd.numel() < views * Cn or \
-            lsums.numel() < views * 2 * Cn or colsum.numel() < views * colsum_rows * p or s_out.numel() < views * p or \
-            reduce_ws.numel() < views * groups * 2 * Cn:
+            lsums.numel() < views * 2 * Cn or reduce_ws.numel() < views * groups * 2 * Cn or \
+            (count > 0 and (coef is None or coef.numel() < views * 4 * Cn)):
         raise ValueError("linbn_stats: size mismatch")
-    with _prof("linbn_small", 0.0, 4.0 * views * (Cn * p + colsum_rows * p)):
-        check(_lib.load().sm3_linbn_stats(dtype, _ptr(P), _ptr(w_fwd), _ptr(mean), _ptr(invstd), _ptr(reduce_ws), groups,
-                                          _ptr(lsums), _ptr(colsum), colsum_rows, _ptr(s_out), Cn, p, views, _stream()),
-              "sm3_linbn_stats")
+    with _prof("linbn_small", 0.0, 4.0 * views * Cn * p):
+        check(_lib.load().sm3_linbn_stats(dtype, _ptr(P), _ptr(w_fwd), _ptr(mean), _ptr(invstd), _ptr(gamma),
+                                          _ptr(reduce_ws), groups, _ptr(lsums), _ptr(dgamma), _ptr(dbeta), float(count),
+                                          _ptr(coef), Cn, p, views, _stream()), "sm3_linbn_stats")
 
 
-def linbn_coeffs(dtype, w_dgrad, gamma, mean, invstd, gsums, count, lsums, dgamma, dbeta, wa, wbn, col_const, coef, Cn, p,
-                 views=1):
+def linbn_coef(gsums, count, gamma, mean, invstd, coef, Cn, views=1):
+    _chk(gsums, torch.float64)
+    for t in (gamma, mean, invstd, coef):
+        _chk(t, torch.float32)
+    if gsums.numel() < views * 2 * Cn or mean.numel() < views * Cn or invstd.numel() < views * Cn or coef.numel() < views * 4 * Cn:
+        raise ValueError("linbn_coef: size mismatch")
+    check(_lib.load().sm3_linbn_coef(_ptr(gsums), float(count), _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(coef), Cn, views,
+                                     _stream()), "sm3_linbn_coef")
+
+
+def linbn_banks(dtype, w_dgrad, coef, wa, wbn, col_const, Cn, p, views=1):
     tdt = TORCH_DTYPE[dtype]
     _chk(w_dgrad, tdt, "w_dgrad"); _chk(wa, tdt, "wa"); _chk(wbn, tdt, "wbn")
-    for t in (gamma, mean, invstd, dgamma, dbeta, col_const, coef):
-        _chk(t, torch.float32)
-    _chk(gsums, torch.float64); _chk(lsums, torch.float64)
+    _chk(coef, torch.float32); _chk(col_const, torch.float32)
     if w_dgrad.numel() != p * Cn or wa.numel() < views * p * Cn or wbn.numel() < views * p * Cn or \
-            col_const.numel() < views * p or coef.numel() < views * 4 * Cn or gsums.numel() < views * 2 * Cn or \
-            mean.numel() < views * Cn or invstd.numel() < views * Cn or (lsums is not None and lsums.numel() < views * 2 * Cn):
-        raise ValueError("linbn_coeffs: size mismatch")
+            col_const.numel() < views * p or coef.numel() < views * 4 * Cn:
+        raise ValueError("linbn_banks: size mismatch")
     with _prof("linbn_small", 0.0, _sz(dtype) * p * Cn * (1 + 2 * views)):
-        check(_lib.load().sm3_linbn_coeffs(dtype, _ptr(w_dgrad), _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(gsums),
-                                           float(count), _ptr(lsums), _ptr(dgamma), _ptr(dbeta), _ptr(wa), _ptr(wbn),
-                                           _ptr(col_const), _ptr(coef), Cn, p, views, _stream()), "sm3_linbn_coeffs")
+        check(_lib.load().sm3_linbn_banks(dtype, _ptr(w_dgrad), _ptr(coef), _ptr(wa), _ptr(wbn), _ptr(col_const), Cn, p,
+                                          views, _stream()), "sm3_linbn_banks")
 
 
-def linbn_post(dtype, wbn, w_dgrad, hn, P, G, w_fwd, s, coef, dw, Cn, p, views=1):
-    """hn[v] = wbn_v w_dgrad^T (= -H_v, dtype [views][p][p]);  dw += sum_v diag(a)(P_v - m1 s^T) - diag(b)(w_fwd G_v - mu s^T)
-    (sm3_linbn_post)."""
+def linbn_post(dtype, wbn, w_dgrad, hn, P, G, Tm, s, coef, dw, Cn, p, views=1):
+    """hn[v] = wbn_v w_dgrad^T (= -H_v, dtype [views][p][p]);  dw += sum_v diag(a)(P_v - m1 s^T) - diag(b)(W G_v - mu s^T),
+    W G_v from Tm or (Tm None) recomputed from G (sm3_linbn_post)."""
     tdt = TORCH_DTYPE[dtype]
-    for t, n in ((wbn, "wbn"), (w_dgrad, "w_dgrad"), (hn, "hn"), (w_fwd, "w_fwd")):
+    for t, n in ((wbn, "wbn"), (w_dgrad, "w_dgrad"), (hn, "hn")):
         _chk(t, tdt, n)
-    for t in (P, G, s, coef, dw):
+    for t in (P, G, Tm, coef, dw):
         _chk(t, torch.float32)
-    if wbn.numel() < views * p * Cn or w_dgrad.numel() != p * Cn or hn.numel() < views * p * p or w_fwd.numel() != Cn * p or \
-            P.numel() < views * Cn * p or G.numel() < views * p * p or s.numel() < views * p or \
+    _chk(s, torch.float64, "s")
+    if wbn.numel() < views * p * Cn or w_dgrad.numel() != p * Cn or hn.numel() < views * p * p or \
+            P.numel() < views * Cn * p or (G is None and Tm is None) or (G is not None and G.numel() < views * p * p) or \
+            (Tm is not None and Tm.numel() < views * Cn * p) or s.numel() < views * p or \
             coef.numel() < views * 4 * Cn or dw.numel() != Cn * p or Cn % 128 or p % 32:
         raise ValueError("linbn_post: size mismatch")
-    flops = 2.0 * views * (p * p * Cn + Cn * p * p)
+    flops = 2.0 * views * p * p * Cn * (1 if Tm is not None else 2)
     with _prof("linbn_small", flops, 4.0 * Cn * p * (2 + views) + _sz(dtype) * p * Cn * (1 + views)):
-        check(_lib.load().sm3_linbn_post(dtype, _ptr(wbn), _ptr(w_dgrad), _ptr(hn), _ptr(P), _ptr(G), _ptr(w_fwd), _ptr(s),
+        check(_lib.load().sm3_linbn_post(dtype, _ptr(wbn), _ptr(w_dgrad), _ptr(hn), _ptr(P), _ptr(G), _ptr(Tm), _ptr(s),
                                          _ptr(coef), _ptr(dw), Cn, p, views, _stream()), "sm3_linbn_post")
+
+
+def conv_bn_act_fused(desc, x, w, scale, shift, residual, relu, y, mask=None, views=1):
+    """y = relu?(conv(x, w) * scale[v] + shift[v] (+ residual)) with the ReLU bits in `mask`: conv -> train-mode BatchNorm ->
+    (+identity) -> ReLU in one launch (sm3_conv_bn_act_fused); scale / shift [views][Co] from bn_finalize."""
+    tdt = TORCH_DTYPE[desc.dtype]
+    _chk(x, tdt, "x"); _chk(w, tdt, "w"); _chk(y, tdt, "y"); _chk(residual, tdt, "residual")
+    _chk(scale, torch.float32, "scale"); _chk(shift, torch.float32, "shift"); _chk(mask, torch.uint8, "mask")
+    if x.numel() != desc.N * desc.Hi * desc.Wi * desc.Ci:
+        raise ValueError("x size does not match descriptor")
+    n_out = desc.N * desc.Hout * desc.Wout * desc.Co
+    if y.numel() != n_out or (residual is not None and residual.numel() != n_out):
+        raise ValueError("y / residual size does not match descriptor")
+    if scale.numel() < views * desc.Co or shift.numel() < views * desc.Co:
+        raise ValueError("scale/shift too small")
+    if mask is not None and (not relu or mask.numel() != n_out // (16 // _sz(desc.dtype))):
+        raise ValueError("mask size mismatch")
+    M = desc.N * desc.Ho * desc.Wo
+    if views > 1 and (views != 2 or M % 256):
+        raise ValueError("two views need a multiple of 128 rows each")
+    if desc.Ci % K_CHUNK[desc.dtype]:
+        raise ValueError(f"Ci={desc.Ci} is not a multiple of {K_CHUNK[desc.dtype]}")
+    sz = _sz(desc.dtype)
+    tag = _conv_tag(desc)
+    if _PROFILER is not None and getattr(_PROFILER, "detail", False):
+        tag += f"|M{M}_K{desc.ntaps}x{desc.Ci}_N{desc.Co}_s{desc.osy}_bnact"
+    with _prof(tag, 2.0 * M * desc.Co * desc.ntaps * desc.Ci,
+               sz * (min(x.numel(), M * desc.ntaps * desc.Ci) + M * desc.Co * (2 if residual is not None else 1))):
+        check(_lib.load().sm3_conv_bn_act_fused(C.byref(desc), _ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(residual),
+                                                int(relu), _ptr(y), _ptr(mask), views, _stream()), "sm3_conv_bn_act_fused")
 
 
 # ------------------------------------------------------------------------------------------
@@ -520,8 +615,8 @@ def bn_eval_scale_shift(gamma, beta, running_mean, running_var, eps, Cn, scale, 
                                               Cn, _ptr(scale), _ptr(shift), _stream()), "sm3_bn_eval_scale_shift")
 
 
-def bn_act_colsum_rows(dtype, rows, Cn, views=1):
-    return _lib.load().sm3_bn_act_colsum_rows(rows, Cn, dtype, views)
+def bn_act_colsum_rows(dtype, rows, Cn):
+    return _lib.load().sm3_bn_act_colsum_rows(rows, Cn, dtype)
 
 
 def bn_act(dtype, x, scale, shift, residual, relu, y, rows, Cn, out_f32=False, mask=None, views=1, colsum=None):
@@ -542,7 +637,7 @@ def bn_act(dtype, x, scale, shift, residual, relu, y, rows, Cn, out_f32=False, m
     if _PROFILER is not None and getattr(_PROFILER, "detail", False):
         tag += f"|rows{views * rows}_C{Cn}_res{int(residual is not None)}"
     _chk(colsum, torch.float32, "colsum")
-    if colsum is not None and (out_f32 or colsum.numel() < views * bn_act_colsum_rows(dtype, rows, Cn, views) * Cn):
+    if colsum is not None and (out_f32 or colsum.numel() < views * bn_act_colsum_rows(dtype, rows, Cn) * Cn):
         raise ValueError("bn_act: colsum needs the storage dtype and [views][colsum_rows][C] floats")
     with _prof(tag, 0.0, _sz(dtype) * n * (2 if residual is None else 3)):
         if colsum is not None:
@@ -670,12 +765,12 @@ def bn_bwd_reduce(dtype, dy, y, x, mean, invstd, dz, rows, Cn, partials, mask=No
     _chk(partials, torch.float32)
     if partials.numel() < views * bn_bwd_partial_rows(rows, Cn) * 2 * Cn:
         raise ValueError("bn_bwd_reduce: partials too small")
-    if mean.numel() < views * Cn or invstd.numel() < views * Cn:
-        raise ValueError("bn_bwd_reduce: mean/invstd too small")
     _chk(mask, torch.uint8, "mask")
     if mask is not None and mask.numel() != n // (16 // _sz(dtype)):
         raise ValueError("bn_bwd_reduce: mask size mismatch")
-    reads = 2 + (1 if (y is not None and mask is None) else 0) + (1 if dz is not None else 0)
+    if x is not None and (mean.numel() < views * Cn or invstd.numel() < views * Cn):
+        raise ValueError("bn_bwd_reduce: mean/invstd too small")
+    reads = 1 + (x is not None) + (1 if (y is not None and mask is None) else 0) + (1 if dz is not None else 0)
     with _prof("bn_bwd_reduce", 0.0, _sz(dtype) * n * reads + (n // 8 if mask is not None else 0)):
         check(_lib.load().sm3_bn_bwd_reduce(dtype, _ptr(dy), _ptr(y), _ptr(mask), _ptr(x), _ptr(mean), _ptr(invstd),
                                             _ptr(dz), rows, Cn, _ptr(partials), views, _stream()), "sm3_bn_bwd_reduce")

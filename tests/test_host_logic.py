@@ -88,9 +88,15 @@ def test_engine_dry_run_sequences_and_bucket_schedule(model, linbn):
     assert calls["sm3_bn_finalize"] == 53 * 4 + 3 * 6 == 230  # 212 BN2d + 18 BN1d per step
     nlin = 64 if linbn else 0  # 16 Bottlenecks x 4 encoder passes: conv3 -> bn3 units whose backward goes by linearity
     assert calls["sm3_conv_wgrad"] == 230 - 4 - nlin and calls["sm3_stem_wgrad_bn"] == 4  # bf16: direct stem (csrc/stem.hip)
-    for name in ("sm3_linbn_stats", "sm3_linbn_coeffs", "sm3_linbn_post", "sm3_conv_dgrad_seg_bnfuse", "sm3_bn_act_colsum"):
+    for name in ("sm3_linbn_stats", "sm3_linbn_banks", "sm3_linbn_post", "sm3_conv_dgrad_seg_bnfuse", "sm3_bn_act_colsum"):
         assert calls[name] == nlin, name
-    assert calls["sm3_conv_wgrad_cat"] == 2 * nlin  # forward: Gram matrix of conv3's input; backward: dz^T y2 per view
+    # forward: Gram matrix of conv3's input; backward: dz^T y2 per view -- plain-store split-K slabs, summed in a fixed order
+    assert calls["sm3_conv_wgrad_slabs"] == 2 * nlin and calls["sm3_linbn_moments"] == 2 * nlin
+    assert calls["sm3_conv_wgrad_cat"] == 0
+    # the 12 blocks without a downsample branch also run conv3 -> bn3 -> +identity -> ReLU as ONE launch, bn3's statistics
+    # from the moments of conv3's input (no join pass, no pre-BatchNorm tensor)
+    nfused = 48 if linbn else 0
+    assert calls["sm3_linbn_fwd_stats"] == nfused and calls["sm3_conv_bn_act_fused"] == nfused
     if linbn:
         # no backward-apply pass for bn3; the downsample BatchNorm of a block keeps its own (the stem's is fused into its
         # weight gradient)
@@ -100,7 +106,7 @@ def test_engine_dry_run_sequences_and_bucket_schedule(model, linbn):
         assert calls["sm3_bn_bwd_apply2"] == 4 * 4 and calls["sm3_bn_bwd_apply"] == 230 - 2 * 16 - 4
     # ... and its forward apply, except where the consumer applies it: the 16 downsample BatchNorms inside their
     # block's join (sm3_bn_add_bn_act), the 4 stem BatchNorms inside the fused BN + ReLU + max-pool pass
-    assert calls["sm3_bn_add_bn_act"] == 16 and calls["sm3_bn_act"] + calls["sm3_bn_act_colsum"] == 230 - 16 - 16 - 4
+    assert calls["sm3_bn_add_bn_act"] == 16 and calls["sm3_bn_act"] + calls["sm3_bn_act_colsum"] == 230 - 16 - 16 - 4 - nfused
     assert calls["sm3_ntxent_fused"] == 4 and calls["sm3_adamw"] == 1
     assert calls["sm3_stem_conv_fwd"] == 4 and calls["sm3_stem_im2col"] == 0
     assert calls["sm3_bn_relu_maxpool_fwd"] == 4 and calls["sm3_maxpool_bn_bwd"] == 4

@@ -57,12 +57,34 @@ def test_wgrad_cat_views(case, dt):
     torch.cuda.synchronize()
     assert torch.allclose(P2, P, rtol=1e-5, atol=1e-4 * P.abs().max().item())
     assert torch.allclose(G2, G, rtol=1e-5, atol=1e-4 * G.abs().max().item())
+    # plain-store split-K: slabs summed in a fixed order -- no atomics, so two launches agree bit for bit, and so does a
+    # launch over ONE view with that view's share of the two-view launch
+    n = C * p
+    slabs = torch.full((V * ops.SLAB_CAP * n,), float("nan"), device=dev())
+    ns = ops.conv_wgrad_slabs(d, yd, dzd, slabs, views=V)
+    assert 1 <= ns <= ops.SLAB_CAP
+    P3 = torch.empty(V, C, p, device=dev())
+    ops.linbn_moments(slabs, ns, n, P3, views=V)
+    slabs_b = torch.full_like(slabs, float("nan"))
+    assert ops.conv_wgrad_slabs(d, yd, dzd, slabs_b, views=V) == ns
+    torch.cuda.synchronize()
+    assert torch.equal(slabs[: V * ns * n], slabs_b[: V * ns * n])
+    assert torch.allclose(P3, P, rtol=1e-5, atol=1e-4 * P.abs().max().item())
+    d1 = ops.fwd_desc(code, N, HW, 1, p, C, 1, 1, 0)
+    for v in range(V):
+        s1 = torch.full((ops.SLAB_CAP * n,), float("nan"), device=dev())
+        assert ops.conv_wgrad_slabs(d1, yd[v * Mv:(v + 1) * Mv], dzd[v * Mv:(v + 1) * Mv], s1, views=1) == ns
+        Pv = torch.empty(1, C, p, device=dev())
+        ops.linbn_moments(s1, ns, n, Pv, views=1)
+        torch.cuda.synchronize()
+        assert torch.equal(Pv[0], P3[v])
 
 
 @pytest.mark.parametrize("dt", DTS + [torch.float32], ids=IDS + ["f32"])
 @pytest.mark.parametrize("case", [(1, 5000, 64), (2, 1664, 128), (2, 777, 512), (1, 40, 2048)])
 def test_bn_act_colsum(case, dt):
-    """sm3_bn_act_colsum: same output and mask as sm3_bn_act, plus per-block column sums of the STORED values."""
+    """sm3_bn_act_colsum: same output and mask as sm3_bn_act, plus per-block column sums of the STORED values whose
+    fixed-order total (sm3_linbn_moments) is bit-identical whether a view shares the launch with its sibling or not."""
     ops = _ops()
     V, rows, C = case
     g = torch.Generator().manual_seed(rows)
@@ -74,7 +96,7 @@ def test_bn_act_colsum(case, dt):
     y0 = torch.empty_like(x)
     m0 = torch.empty(V * rows * C // E, dtype=torch.uint8, device=dev())
     ops.bn_act(code, x, scale, shift, None, True, y0, rows, C, mask=m0, views=V)
-    crow = ops.bn_act_colsum_rows(code, rows, C, V)
+    crow = ops.bn_act_colsum_rows(code, rows, C)
     assert crow >= 1
     cs = torch.full((V, crow, C), float("nan"), device=dev())
     y1 = torch.empty_like(x)
@@ -82,9 +104,16 @@ def test_bn_act_colsum(case, dt):
     ops.bn_act(code, x, scale, shift, None, True, y1, rows, C, mask=m1, views=V, colsum=cs)
     torch.cuda.synchronize()
     assert torch.equal(y0, y1) and torch.equal(m0, m1)
-    got = cs.double().sum(1).cpu()
     want = y1.double().reshape(V, rows, C).sum(1).cpu()
-    assert torch.allclose(got, want, rtol=1e-5, atol=1e-3)
+    assert torch.allclose(cs.double().sum(1).cpu(), want, rtol=1e-5, atol=1e-3)
+    # one view at a time: the same partial rows, bit for bit
+    for v in range(V):
+        csv = torch.full((1, crow, C), float("nan"), device=dev())
+        yv = torch.empty(rows, C, dtype=dt, device=dev())
+        ops.bn_act(code, x[v * rows:(v + 1) * rows], scale[v * C:(v + 1) * C], shift[v * C:(v + 1) * C], None, True, yv, rows, C,
+                   views=1, colsum=csv)
+        torch.cuda.synchronize()
+        assert torch.equal(csv[0], cs[v])
 
 
 @pytest.mark.parametrize("dt", DTS, ids=IDS)
@@ -158,10 +187,10 @@ def _unit_reference(y, W, gamma, beta, dz, eps=1e-5):
 
 @pytest.mark.parametrize("dt", DTS, ids=IDS)
 @pytest.mark.parametrize("case", [(1, 1280, 256, 64), (2, 1024, 256, 64), (2, 640, 512, 128), (2, 256, 1024, 256)])
-def test_conv_bn_backward_by_linearity_matches_fp64_autograd(case, dt):
-    """The launch sequence of SM3Engine.conv3_backward_linbn on one conv3 -> bn3 unit against the fp64 autograd of
-    conv1x1 -> BatchNorm2d(train) (src/models/resnet.py:162-163) on the same (rounded) operands: data gradient, weight
-    gradient, d(gamma), d(beta)."""
+def test_conv_bn_by_linearity_matches_fp64_autograd(case, dt):
+    """The launch sequences of SM3Engine.conv3_bn3_fused / conv3_backward_linbn on one conv3 -> bn3 unit against fp64
+    PyTorch of conv1x1 -> BatchNorm2d(train) (-> + identity -> ReLU) (src/models/resnet.py:162-172) on the same (rounded)
+    operands: batch statistics, output and ReLU bits; data gradient, weight gradient, d(gamma), d(beta)."""
     ops = _ops()
     V, Mv, C, p = case
     M = V * Mv
@@ -173,68 +202,108 @@ def test_conv_bn_backward_by_linearity_matches_fp64_autograd(case, dt):
     dz = (torch.randn(V, Mv, C, generator=g) * (torch.rand(V, Mv, C, generator=g) > 0.4)).to(dt)
     Wr = Wm.to(dt)                                                # the bank the forward used
     ref_dy, ref_dW, ref_dg, ref_db = _unit_reference(y.float(), Wr.float(), gamma, beta, dz.float())
-    # forward statistics as the engine has them: of the STORED convolution output
-    x = (y.float().double() @ Wr.float().double().t()).to(dt).double()   # [V][Mv][C]
-    mean = x.mean(1).float()
-    invstd = (x.var(1, unbiased=False) + 1e-5).rsqrt().float()
-
     D = dev()
     yd, dzd = y.reshape(M, p).to(D), dz.reshape(M, C).to(D)
     w_master = Wm.to(D)
     w_fwd = torch.empty(C, p, dtype=dt, device=D)
     w_dg = torch.empty(p, 1, C, dtype=dt, device=D)
     ops.weight_prep(code, w_master, C, 1, p, w_fwd, p, w_dg)
-    # column sums of y through the apply kernel (identity scale/shift reproduces y)
-    crow = ops.bn_act_colsum_rows(code, Mv, p, V)
+    # sum(y) through the apply kernel (identity scale/shift reproduces y); Gram matrix through the weight-gradient kernel
+    crow = ops.bn_act_colsum_rows(code, Mv, p)
     cs = torch.empty(V * crow * p, device=D)
     ytmp = torch.empty_like(yd)
     ops.bn_act(code, yd, torch.ones(V * p, device=D), torch.zeros(V * p, device=D), None, False, ytmp, Mv, p, views=V,
                colsum=cs)
     assert torch.equal(ytmp, yd)
-    # sum(dz) partial rows as a producing data-gradient epilogue leaves them: here from the standalone reduce kernel
+    slabs = torch.empty(V * ops.SLAB_CAP * max(p * p, C * p), device=D)
+    ns = ops.conv_wgrad_slabs(ops.fwd_desc(code, V, Mv, 1, p, p, 1, 1, 0), yd, yd, slabs, views=V)
+    G = torch.empty(V * p * p, device=D)
+    sd = torch.empty(V * p, dtype=torch.float64, device=D)
+    ops.linbn_moments(slabs, ns, p * p, G, views=V, colsum=cs, colsum_rows=crow, s_out=sd, p=p)
+    # ---- forward: bn3's batch statistics from the moments, W G saved
+    Tm = torch.empty(V * C * p, device=D)
+    groups = p // 32
+    fws = torch.empty(V * groups * 2 * C, dtype=torch.float64, device=D)
+    assert ops.linbn_fwd_stats(code, G, w_dg, w_fwd, sd, Tm, fws, C, p, V) == groups
+    scale, shift = torch.empty(V * C, device=D), torch.empty(V * C, device=D)
+    mean_d, invstd_d = torch.empty(V * C, device=D), torch.empty(V * C, device=D)
+    rm, rv = torch.zeros(C, device=D), torch.ones(C, device=D)
+    nbt = torch.zeros(1, dtype=torch.int64, device=D)
+    ops.bn_finalize(fws, Mv, C, gamma.to(D), beta.to(D), 1e-5, 0.1, rm, rv, nbt, scale, shift, mean_d, invstd_d,
+                    groups=groups, views=V)
+    torch.cuda.synchronize()
+    xe = y.double() @ Wr.double().t()                                   # un-rounded conv output [V][Mv][C]
+    mu_e, var_e = xe.mean(1), xe.var(1, unbiased=False)
+    assert torch.allclose(sd.reshape(V, p).cpu(), y.double().sum(1), rtol=1e-5)  # fp32 per thread, fp64 across blocks
+    assert torch.allclose(mean_d.reshape(V, C).cpu().double(), mu_e, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(invstd_d.reshape(V, C).cpu().double(), (var_e + 1e-5).rsqrt(), rtol=2e-4)
+    Gd = G.reshape(V, p, p).double().cpu()
+    assert torch.allclose(Tm.reshape(V, C, p).double().cpu(), torch.einsum("ck,vkj->vcj", Wr.double(), Gd), rtol=1e-5,
+                          atol=1e-5 * Gd.abs().max().item())
+    assert int(nbt) == V
+    # ... and conv3 -> bn3 -> +identity -> ReLU in one launch against conv -> BatchNorm2d(train) -> add -> relu in fp64
+    idn = torch.randn(V, Mv, C, generator=g).to(dt)
+    y3 = torch.empty(M, C, dtype=dt, device=D)
+    mask3 = torch.empty(M * C // 8, dtype=torch.uint8, device=D)
+    ops.conv_bn_act_fused(ops.fwd_desc(code, V, Mv, 1, p, C, 1, 1, 0), yd, w_fwd, scale, shift, idn.reshape(M, C).to(D),
+                          True, y3, mask3, views=V)
+    torch.cuda.synchronize()
+    z = (xe - mu_e[:, None]) * (var_e[:, None] + 1e-5).rsqrt() * gamma.double() + beta.double() + idn.double()
+    ref3 = torch.relu(z)
+    got3 = y3.reshape(V, Mv, C).double().cpu()
+    assert (got3 - ref3).abs().max().item() < tol(dt) * ref3.abs().max().item()
+    bits = (mask3.cpu().reshape(M, C // 8, 1) >> torch.arange(8, dtype=torch.uint8)) & 1
+    assert torch.equal(bits.reshape(V, Mv, C).bool(), y3.reshape(V, Mv, C).cpu() > 0)
+
+    # ---- backward.  sum(dz) partial rows as a producing data-gradient epilogue leaves them (mask + sum only: x = None)
     prow = ops.bn_bwd_partial_rows(Mv, C)
     bpart = torch.empty(V * prow * 2 * C, device=D)
-    xd = x.reshape(M, C).to(dt).to(D)
-    ops.bn_bwd_reduce(code, dzd, None, xd, mean.reshape(-1).to(D), invstd.reshape(-1).to(D), None, Mv, C, bpart, views=V)
+    ops.bn_bwd_reduce(code, dzd, None, None, None, None, None, Mv, C, bpart, views=V)
+    xd = xe.reshape(M, C).to(dt).to(D)                                  # the tensor the two-pass form would have stored
+    bpart2 = torch.empty_like(bpart)
+    ops.bn_bwd_reduce(code, dzd, None, xd, mean_d, invstd_d, None, Mv, C, bpart2, views=V)
     want = torch.empty(V * 2 * C, dtype=torch.float64, device=D)
-    ops.bn_stats_reduce(bpart, prow, C, want, views=V)
+    ops.bn_stats_reduce(bpart2, prow, C, want, views=V)
     want = want.reshape(V, 2, C).clone()
     lsums = torch.full((V * 2 * C,), float("nan"), dtype=torch.float64, device=D)  # the linear path writes both halves
-
-    P = torch.zeros(V * C * p, device=D)
-    G = torch.zeros(V * p * p, device=D)
-    ops.conv_wgrad_cat(ops.fwd_desc(code, V, Mv, 1, p, p, 1, 1, 0), yd, yd, G, views=V)      # forward pass
-    ops.conv_wgrad_cat(ops.fwd_desc(code, V, Mv, 1, p, C, 1, 1, 0), yd, dzd, P, views=V)     # backward pass
-    s = torch.empty(V * p, device=D)
-    mean_d, invstd_d = mean.reshape(-1).to(D), invstd.reshape(-1).to(D)
-    ws, groups = ops.bn_stats_reduce(bpart, prow, C, None, views=V)
-    ops.linbn_stats(code, P, w_fwd, mean_d, invstd_d, ws, groups, lsums, cs, crow, s, C, p, V)
+    ns = ops.conv_wgrad_slabs(ops.fwd_desc(code, V, Mv, 1, p, C, 1, 1, 0), yd, dzd, slabs, views=V)
+    P = torch.empty(V * C * p, device=D)
+    ops.linbn_moments(slabs, ns, C * p, P, views=V)
+    ws, rgroups = ops.bn_stats_reduce(bpart, prow, C, None, views=V)
+    dgamma, dbeta = torch.zeros(C, device=D), torch.zeros(C, device=D)
+    coef = torch.empty(V * 4 * C, device=D)
+    ops.linbn_stats(code, P, w_fwd, mean_d, invstd_d, gamma.to(D), ws, rgroups, lsums, dgamma, dbeta, Mv, coef, C, p, V)
     torch.cuda.synchronize()
     got = lsums.reshape(V, 2, C)
     assert torch.allclose(got[:, 0], want[:, 0], rtol=1e-12, atol=0)  # stage B of the reduction, folded into linbn_stats
     assert torch.allclose(got[:, 1], want[:, 1], rtol=2e-2, atol=2e-2 * want[:, 1].abs().max().item())  # stored x vs y W^T
-    assert torch.allclose(s.reshape(V, p).cpu().double(), y.double().sum(1), rtol=1e-5)
+    coef2 = torch.empty_like(coef)                                      # the data-parallel route to the same coefficients
+    ops.linbn_coef(lsums, Mv, gamma.to(D), mean_d, invstd_d, coef2, C, V)
+    torch.cuda.synchronize()
+    assert torch.equal(coef, coef2)
 
     wa = torch.empty(V * p * C, dtype=dt, device=D)
     wbn = torch.empty(V * p * C, dtype=dt, device=D)
     cconst = torch.empty(V * p, device=D)
-    coef = torch.empty(V * 4 * C, device=D)
-    dgamma, dbeta = torch.zeros(C, device=D), torch.zeros(C, device=D)
-    ops.linbn_coeffs(code, w_dg, gamma.to(D), mean_d, invstd_d, lsums, Mv, lsums, dgamma, dbeta, wa, wbn, cconst, coef, C, p, V)
+    ops.linbn_banks(code, w_dg, coef, wa, wbn, cconst, C, p, V)
     Hn = torch.empty(V * p * p, dtype=dt, device=D)
     dW = torch.zeros(C, p, device=D)
-    ops.linbn_post(code, wbn, w_dg, Hn, P, G, w_fwd, s, coef, dW, C, p, V)
+    ops.linbn_post(code, wbn, w_dg, Hn, P, G, Tm, sd, coef, dW, C, p, V)
+    Hn2 = torch.empty_like(Hn)
+    dW2 = torch.zeros(C, p, device=D)
+    ops.linbn_post(code, wbn, w_dg, Hn2, P, G, None, sd, coef, dW2, C, p, V)   # W G recomputed in the kernel
     torch.cuda.synchronize()
+    assert torch.equal(Hn, Hn2) and torch.equal(dW, dW2)
     # the two small products of the post kernel against the generic gather-GEMM / fp64
     Hn_ref = torch.empty(V * p * p, dtype=dt, device=D)
     ops.conv_gemm(ops.fwd_desc(code, V * p, 1, 1, C, p, 1, 1, 0), wbn, w_dg, Hn_ref)
     torch.cuda.synchronize()
     hs = Hn_ref.float().abs().max().item()
     assert (Hn.float() - Hn_ref.float()).abs().max().item() <= tol(dt) * hs
-    cf = coef.reshape(V, 4, C).double().cpu()
-    Wd, Pd, Gd, sd = Wr.double(), P.reshape(V, C, p).double().cpu(), G.reshape(V, p, p).double().cpu(), s.reshape(V, p).double().cpu()
-    dW_ref = sum(cf[v, 0, :, None] * (Pd[v] - cf[v, 2, :, None] * sd[v][None]) -
-                 cf[v, 1, :, None] * (Wd @ Gd[v] - cf[v, 3, :, None] * sd[v][None]) for v in range(V))
+    cf = coef.reshape(V, C, 4).double().cpu()
+    Wd, Pd, sdd = Wr.double(), P.reshape(V, C, p).double().cpu(), sd.reshape(V, p).cpu()
+    dW_ref = sum(cf[v, :, 0, None] * (Pd[v] - cf[v, :, 2, None] * sdd[v][None]) -
+                 cf[v, :, 1, None] * (Wd @ Gd[v] - cf[v, :, 3, None] * sdd[v][None]) for v in range(V))
     assert (dW.double().cpu() - dW_ref).abs().max().item() < 2e-5 * dW_ref.abs().max().item()
     dd = ops.dgrad_descs(code, V, Mv, 1, p, C, 1, 1, 0)[0][0]
     dy = torch.empty(M, p, dtype=dt, device=D)
@@ -255,12 +324,12 @@ def test_conv_bn_backward_by_linearity_matches_fp64_autograd(case, dt):
 
 @pytest.mark.parametrize("dt", DTS, ids=IDS)
 @pytest.mark.parametrize("views", [1, 2])
-def test_encoder_gradients_linear_backward_on_and_off(dt, views):
-    """A whole ResNet-50 encoder backward with conv3 -> bn3 by linearity against the two-pass BatchNorm backward, same
-    weights and inputs, both measured against the exact-f32 mode of the same engine: the linear form is no further from
-    the f32 gradient than the two-pass form is (they differ only in where the 16-bit roundings fall; through 53 train-mode
-    BatchNorms either form is several per cent away from f32 in the earliest layers).  Features and running statistics
-    are bit-identical: the forward is the same code."""
+def test_encoder_with_and_without_batchnorm_by_linearity(dt, views):
+    """A whole ResNet-50 encoder forward + backward with conv3 -> bn3 by linearity against the two-pass BatchNorm form,
+    same weights and inputs, both measured against the exact-f32 mode of the same engine: features, running statistics
+    and gradients of the linear form are no further from the f32 ones than those of the two-pass form (the two differ only
+    in where 16-bit roundings fall -- the linear form never rounds conv3's output; through 53 train-mode BatchNorms either
+    is several per cent away from f32 in the earliest layers' gradients)."""
     from src.models import resnet
     from sm3hip.engine import SM3Engine
     torch.manual_seed(3)
@@ -288,10 +357,20 @@ def test_encoder_gradients_linear_backward_on_and_off(dt, views):
         eng.encoder_backward(ctx[0], dfeat)
         torch.cuda.synchronize()
         res[mode] = (f32.clone(), eng.store.flat_g.clone(),
-                     {k: v.clone() for k, v in m.state_dict().items() if "running" in k}, eng.store)
-    assert torch.equal(res["off"][0], res["on"][0])
-    for k in res["off"][2]:
-        assert torch.equal(res["off"][2][k], res["on"][2][k]), k
+                     {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}, eng.store)
+    fref = res["f32"][0].double()
+    f_off = ((res["off"][0].double() - fref).norm() / fref.norm()).item()
+    f_on = ((res["on"][0].double() - fref).norm() / fref.norm()).item()
+    print(f"features, relative error vs f32: two-pass {f_off:.5f}, linear {f_on:.5f}")
+    assert f_on < 1.25 * f_off + 1e-4
+    for k, ref_b in res["f32"][2].items():
+        if "num_batches" in k:
+            assert torch.equal(res["on"][2][k], ref_b), k
+            continue
+        sc = ref_b.double().abs().max().item() + 1e-12
+        a = (res["off"][2][k].double() - ref_b.double()).abs().max().item() / sc
+        b = (res["on"][2][k].double() - ref_b.double()).abs().max().item() / sc
+        assert b < 1.5 * a + 2e-3, (k, a, b)
     st = res["on"][3]
     ref = res["f32"][1].double()
     e_off = ((res["off"][1].double() - ref).norm() / ref.norm()).item()
