@@ -311,27 +311,122 @@ def mlc_train_bench(args):
                      "kernel": "conv_igemm_kernel<bf16_t,128,128,2,2,*> with the conv+evalBN+ReLU epilogue"}}), flush=True)
 
 
-def spawn_ranks(n):
+def visible_gpus():
+    """Compute nodes the kernel driver exposes (KFD topology: a node with SIMDs is a GPU), read from sysfs -- the parent
+    of the rank processes never touches HIP.  None when the topology is not readable."""
+    import glob
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    n = 0
+    try:
+        for f in nodes:
+            for line in open(f):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+    except OSError:
+        return None
+    return n
+
+
+def spawn_ranks(n, argv=None, extra_env=None, grace=5.0):
     """`python bench.py --gpus N` without a launcher: start N fresh worker processes of this same file, one rank
-    per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1), and return
-    rank 0's exit code.  Decided before this process has touched the GPU: the parent never initialises HIP (no
-    torch.cuda call but device_count(), no exec of a GPU process); rank 0's stdout carries the ONE JSON line."""
+    per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1), relay their
+    stderr line by line with a "[rank r]" prefix, and watch them: as soon as ONE rank exits non-zero the others are
+    terminated (they would otherwise sit in their next collective until the process-group timeout) and that exit code is
+    returned.  The parent never initialises HIP; rank 0's stdout carries the ONE JSON line."""
     import socket
     import subprocess
-    have = torch.cuda.device_count()  # does not initialise the GPU
-    if os.environ.get("SM3_FORCE_DEVICE") is None and have < n:
+    import threading
+    have = visible_gpus()
+    if os.environ.get("SM3_FORCE_DEVICE") is None and os.environ.get("SM3_BENCH_DRYRUN") != "1" and have is not None \
+            and have < n:
         raise SystemExit(f"--gpus {n} but only {have} GPU(s) visible")
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
-    procs = []
+    argv = sys.argv[1:] if argv is None else list(argv)
+    procs, relays = [], []
+
+    def relay(r, pipe):
+        for line in iter(pipe.readline, b""):
+            sys.stderr.buffer.write(b"[rank %d] " % r + line)
+            sys.stderr.buffer.flush()
+        pipe.close()
+
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rcs = [p.wait() for p in procs]
-    return next((rc for rc in rcs if rc), 0)
+        env.update(extra_env or {})
+        pr = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                              stdout=None if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE)
+        procs.append(pr)
+        th = threading.Thread(target=relay, args=(r, pr.stderr), daemon=True)
+        th.start()
+        relays.append(th)
+    rc = 0
+    live = set(range(n))
+    while live and rc == 0:
+        time.sleep(0.05)
+        for r in list(live):
+            code = procs[r].poll()
+            if code is not None:
+                live.discard(r)
+                if code != 0:
+                    rc = code
+                    print(f"[bench] rank {r} exited with code {code}: stopping the other ranks", file=sys.stderr, flush=True)
+                    break
+    if rc != 0:  # children of this process, never re-exec'd: terminate, then kill what ignores it
+        for r in live:
+            procs[r].terminate()
+        t_end = time.monotonic() + grace
+        for r in live:
+            try:
+                procs[r].wait(timeout=max(0.0, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+                procs[r].wait()
+    for th in relays:
+        th.join(timeout=2.0)
+    return rc
+
+
+def dry_run_rank(args):
+    """TEST MODE (SM3_BENCH_DRYRUN=1, tests/test_bench_launcher.py): the host side of one rank of this benchmark on CPU
+    tensors with the C ABI replaced by tests/fakelib.py -- launcher, rendezvous, per-rank data, collectives (gloo), JSON
+    line; no kernel runs, so the numbers mean nothing and the line says "dry_run": true.  Never used by the driver."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fakelib import installed
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if os.environ.get("SM3_BENCH_FAIL_RANK") == str(rank):
+        raise RuntimeError(f"rank {rank}: injected start-up failure")
+    if world > 1:
+        import datetime
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    from sm3hip.trainer import SM3Trainer
+    from src.models.simclr import SimCLRSkinV32
+    with installed():
+        torch.manual_seed(3407)
+        model = SimCLRSkinV32("resnet50", None, 128, 0.1)
+        model.sm3_dtype = torch.bfloat16
+        trainer = SM3Trainer(model, lr=1e-6, weight_decay=5e-2, eps=1e-5, style=0)
+        g = torch.Generator().manual_seed(3407 + rank)
+        x = [torch.randn(2, 3, 32, 32, generator=g) for _ in range(4)]
+        t0 = time.perf_counter()
+        for _ in range(max(1, args.steps)):
+            trainer.step(x[:2], x[2:])
+        if world > 1:
+            dist.barrier()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "SM3 pretrain images/sec (paired 224x224)", "dry_run": True, "value": None,
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "config": {"parallelism": f"dp{world}"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -344,6 +439,8 @@ def main():
         return mlc_train_bench(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+    if os.environ.get("SM3_BENCH_DRYRUN") == "1":
+        return dry_run_rank(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -359,10 +456,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        tmo = datetime.timedelta(seconds=120)  # a rank that never arrives fails the run in two minutes, not in thirty
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
 
     from sm3hip import ops, profiler
     from sm3hip.trainer import SM3Trainer

@@ -40,7 +40,8 @@ int sm3_abi_version(void);
 /* ------------------------------------------------------------------------------------------
  * Gather-GEMM convolution: forward conv, data-gradient of a conv, and bias-free Linear.
  *   replaces nn.Conv2d forward/backward-data  (src/models/resnet.py:49-67 conv3x3/conv1x1, used at
- *   :144-148,:260; stem :208-210 via sm3_stem_im2col) and nn.Linear(bias=False)
+ *   :144-148,:260; the 7x7 stem :208-210 runs on sm3_stem_conv_fwd straight from the images in the 16-bit modes and
+ *   through sm3_stem_im2col + this GEMM in the exact-f32 parity mode) and nn.Linear(bias=False)
  *   (src/models/simclr.py:17-27).
  *
  *   y[n, oy*osy+ooy, ox*osx+oox, co] = sum_t sum_ci x[n, oy*sy+dy[t], ox*sx+dx[t], ci]

@@ -9,8 +9,13 @@ requirements.txt:3; absent from this image) and PIL.  Restated here from their p
     adjust_brightness / contrast / saturation / hue with _rgb2hsv / _hsv2rgb;
   * GaussianBlur: _get_gaussian_kernel1d over linspace(-1, 1, 3), reflect padding;
   * ToTensor (/255) and Normalize.
-PARITY UNPINNED: the reference's tests hold no vectors for this path and torchvision cannot be imported here to make
-any; the float pipeline also differs from the reference's PIL path by the uint8 rounding PIL applies after every op.
+PINNED TO PIL for five of the six image operations (tests/test_augment_pil.py, CPU): the reference feeds PIL images, on
+which torchvision 0.13's RandomResizedCrop, brightness / contrast / saturation / hue and RandomGrayscale ARE PIL calls
+(Image.crop + resize(BILINEAR), ImageEnhance.Brightness / Contrast / Color, the HSV round trip, convert("L")); resized_crop,
+color_op and gray here agree with PIL 12.2 on uint8 inputs to 1 LSB of rounding plus PIL's own truncations (hue: PIL's
+8-bit H, S, V).  This float chain is the un-quantised form of that pipeline: PIL rounds to uint8 after every operation, the
+chain only at the end.  UNPINNED: blur3 -- torchvision's GaussianBlur uses its tensor kernel even on PIL inputs, and
+torchvision cannot be imported here; restated from its published algorithm.
 """
 import torch
 

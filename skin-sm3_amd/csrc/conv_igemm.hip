@@ -15,6 +15,8 @@
 // data-gradients.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "conv_common.h"
 
 using namespace sm3conv;
@@ -535,12 +537,15 @@ int launch_conv_st(const ConvParams& p0, hipStream_t st) {
     p.tilesM = (p.M + BM - 1) / BM;
     p.tilesN = (p.Co + BN - 1) / BN;
     auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, STAGES, LEAN, SEG>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the dynamic-LDS limit is a per-device attribute of the function: set it once per (instantiation, device)
+    static std::atomic<uint32_t> attr_set{0};  // bit d: done on device d
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 31) dev = 0;
+    if (!(attr_set.load(std::memory_order_acquire) & (1u << dev))) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_set.fetch_or(1u << dev, std::memory_order_release);
     }
     const long nblocks = (long)p.tilesM * p.tilesN;
     if (nblocks <= 0 || nblocks > 0x7fffffffL) return SM3_EINVAL;

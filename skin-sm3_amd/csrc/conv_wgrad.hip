@@ -15,6 +15,8 @@
 // and nn.Linear (src/models/simclr.py:17-27) inside loss.backward() (tools/backbone_train.py:125).
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "conv_common.h"
 
 namespace {
@@ -337,17 +339,24 @@ static int env_int(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-// CUs per XCD and workgroups of `kern` a CU holds at once (LDS / VGPR / wave limits), looked up once per kernel.
+static int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 31) dev = 0;
+    return dev;
+}
+
+// CUs per XCD (every device of a node is the same part: looked up once)
 static int cus_per_xcd() {
-    static int v = 0;
-    if (!v) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+    static std::atomic<int> v{0};
+    int r = v.load(std::memory_order_relaxed);
+    if (!r) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, current_device()) != hipSuccess || cus < 8)
             cus = 256;
-        v = cus / 8;
+        r = cus / 8;
+        v.store(r, std::memory_order_relaxed);
     }
-    return v;
+    return r;
 }
 
 template <typename T, int BMW, int BNW, int KP, bool DENSE, int NST, int KG = 1>
@@ -362,7 +371,10 @@ int launch_wgrad_kp(WgradParams p, hipStream_t st) {
     p.adv_ox = (KP % p.HoWo) % p.Wo;
     const long gx = (long)p.tilesCo * p.ntaps * p.tilesCi;
     auto kern = conv_wgrad_kernel<T, BMW, BNW, KP, DENSE, NST, KG>;
-    static int per_cu = 0;  // resident workgroups per CU
+    // resident workgroups per CU, and the dynamic-LDS limit of the function: per (instantiation, device), set once each
+    static std::atomic<int> per_cu_dev[32];
+    const int dev = current_device();
+    int per_cu = per_cu_dev[dev].load(std::memory_order_acquire);
     if (!per_cu) {
         if (LDS > 65536) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -372,6 +384,7 @@ int launch_wgrad_kp(WgradParams p, hipStream_t st) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256 * KG, LDS) != hipSuccess || n < 1) n = 1;
         per_cu = n;
+        per_cu_dev[dev].store(n, std::memory_order_release);
     }
     // Split the pixel axis so that the launch is ONE full wave of workgroups: every XCD holds whole pixel slices (all
     // gx tiles of a slice side by side, re-reading the slice's dY / X rows from that XCD's L2 while they walk it in step)

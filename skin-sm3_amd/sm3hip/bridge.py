@@ -108,6 +108,7 @@ class _ModelFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng, views, style, train, temperature, *params):
         zs, _feats, saved = eng.forward(views, style, train, True)
+        eng.last_feats = {k: v[0] for k, v in _feats.items()}  # fp32 pooled features of this very forward (detached)
         outs, nt = [], []
         for name, z in zs.items():
             R = z.shape[0]
@@ -142,6 +143,7 @@ def model_logits(model, kind, views, style, temperature):
     if _needs_grad(model):
         return list(_ModelFn.apply(eng, views, style, model.training, temperature, *_params(model)))
     zs, _feats, _ = eng.forward(views, style, model.training, False)
+    eng.last_feats = {k: v[0] for k, v in _feats.items()}
     outs = []
     for z in zs.values():
         R = z.shape[0]

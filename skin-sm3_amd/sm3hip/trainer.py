@@ -20,7 +20,8 @@ class SM3Trainer:
                  growth_interval=2000, global_negatives=False, target_momentum=None):
         """loss_scale: None = on exactly when the model's arithmetic is fp16 (the reference's AMP recipe: autocast +
         GradScaler with its defaults, tools/backbone_train.py:98,125-127,480); True / False force it.
-        global_negatives: every NT-Xent term contrasts this rank's 2B projections against the projections of ALL ranks,
+        global_negatives (needs world * 2B and proj_dim to be multiples of 32): every NT-Xent term contrasts this rank's 2B
+        projections against the projections of ALL ranks,
         all-gathered over RCCL (BASELINE.json north_star).  NOT the reference's behaviour -- its negatives are the local
         batch and more negatives mean a larger logsumexp -- hence opt-in, default off.
         target_momentum: None (reference behaviour: both views through the online network) or m in [0, 1): north_star's
@@ -96,6 +97,8 @@ class SM3Trainer:
         W = self.world if self.dp else 1
         rank = dist.get_rank() if self.dp else 0
         Rg = W * Rl
+        if Rg % 32 or D % 32:  # K chunk of the exact-f32 gather-GEMM: S = zn zg^T sums over D, dS zg over Rg
+            raise ValueError(f"global_negatives needs world * 2B (= {Rg}) and proj_dim (= {D}) to be multiples of 32")
         zn = torch.empty_like(z)
         inv = torch.empty(Rl, dtype=torch.float32, device=dev)
         ops.normalize_rows(z, zn, inv)
@@ -122,9 +125,12 @@ class SM3Trainer:
         if not on:
             return None
         if self._scaler is None or self._scaler["scale"].device != dev:
+            # a growth tracker loaded before the first step (resume: load_scaler_state_dict runs when no device state
+            # exists yet) is carried over, as GradScaler.load_state_dict does
+            tracker0 = self.__dict__.pop("_tracker_init", 0)
             self._scaler = {"scale": torch.full((1,), self.scaler_cfg[0], dtype=torch.float32, device=dev),
                             "found_inf": torch.zeros(1, dtype=torch.int32, device=dev),
-                            "tracker": torch.zeros(1, dtype=torch.int32, device=dev),
+                            "tracker": torch.full((1,), tracker0, dtype=torch.int32, device=dev),
                             "steps": torch.full((1,), self.step_count, dtype=torch.int32, device=dev)}
         return self._scaler
 
@@ -144,6 +150,8 @@ class SM3Trainer:
         if self._scaler is not None:
             self._scaler["scale"].fill_(float(sd["scale"]))
             self._scaler["tracker"].fill_(int(sd.get("_growth_tracker", 0)))
+        else:
+            self._tracker_init = int(sd.get("_growth_tracker", 0))
 
     def step(self, derm_imgs, clinic_imgs, metadata=None):
         """One optimizer step on this rank's batch; returns the (device, fp32, 1-element) loss tensor.
@@ -261,8 +269,9 @@ class SM3Trainer:
         st = eng.store
         state = {}
         if self.m is not None:  # before the first step torch.optim.AdamW's state is empty too
+            taken = float(self.steps_taken())  # one host read, not one per parameter
             for i, n in enumerate(st.names):
-                state[i] = {"step": torch.tensor(float(self.steps_taken())),
+                state[i] = {"step": torch.tensor(taken),
                             "exp_avg": st._view(self.m, n).clone(), "exp_avg_sq": st._view(self.v, n).clone()}
         group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.wd, "amsgrad": False,
                  "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,

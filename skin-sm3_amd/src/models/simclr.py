@@ -46,12 +46,14 @@ class SimCLR(nn.Module):
     def forward(self, x1, x2):
         from sm3hip import bridge
         if self.return_feats:
-            # features with autograd attached are only produced inside SimCLRSkinV3/V32 (one fused graph);
-            # standalone return_feats=True falls back to two calls: logits, then detached features.
+            # The pooled features of THIS forward (reference simclr.py:58-59,90: f1, f2 = encoder(x1), encoder(x2) are
+            # the very tensors the projector saw) -- no second pass, so BatchNorm running statistics and
+            # num_batches_tracked advance exactly as in the reference.  Returned detached: features with autograd attached
+            # are only produced inside SimCLRSkinV3 / V32, where they feed the cross projectors of the same fused graph.
             (logits,) = bridge.model_logits(self, "simclr", {"main": [x1, x2]}, 0, self.temperature)
-            with torch.no_grad():
-                f1, f2 = self.encoder(x1), self.encoder(x2)
-            return (logits, _labels(logits)), (f1, f2)
+            f = bridge.sm3_engine_for(self, "simclr").last_feats["main"].detach()
+            B = x1.shape[0]
+            return (logits, _labels(logits)), (f[:B], f[B:])
         (logits,) = bridge.model_logits(self, "simclr", {"main": [x1, x2]}, 0, self.temperature)
         return (logits, _labels(logits))
 

@@ -60,7 +60,8 @@ def get_parser():
     p.add_argument("--amp", action="store_true")
     p.add_argument("--amp-dtype", default="bf16", choices=["bf16", "fp16"])
     p.add_argument("--global-negatives", action="store_true",
-                   help="extension (not reference behaviour): NT-Xent against the all-gathered projections of all ranks")
+                   help="extension (not reference behaviour): NT-Xent against the all-gathered projections of all ranks; "
+                        "world * 2 * batch and --proj-dim must be multiples of 32")
     p.add_argument("--gpu-augment", action="store_true",
                    help="synthetic uint8 source images + the reference's augmentation chain on the GPU instead of "
                         "ready-made normalised tensors")

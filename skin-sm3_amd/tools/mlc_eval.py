@@ -95,12 +95,19 @@ def synthetic(bs, size, dev, gen):
     return derm, clinic, labels
 
 
+def set_train_modes(evaluator, finetune):
+    """tools/mlc_eval.py:124-138.  fc: extractor, projectors AND the self-attention layer in eval mode (no dropout in
+    mlc_sa), only the prototypes train; projector: extractor in eval mode; all: everything in train mode."""
+    evaluator.train()
+    evaluator.extractor.train(finetune == "all")
+    if finetune == "fc":
+        evaluator.projectors.eval()
+        evaluator.mlc_sa.eval()
+
+
 def run_epoch(args, evaluator, criterion, optimizer, steps, gen, dev, train):
-    if train:  # mlc_eval.py:118-131: frozen parts in eval mode
-        evaluator.train()
-        evaluator.extractor.train(args.finetune == "all")
-        if args.finetune == "fc":
-            evaluator.projectors.eval()
+    if train:  # the reference's mode matrix, tools/mlc_eval.py:124-138
+        set_train_modes(evaluator, args.finetune)
     else:
         evaluator.eval()
     preds_all, targets_all, total, t0 = [], [], 0.0, time.time()

@@ -1,0 +1,55 @@
+"""bench.py's own rank launcher (`python bench.py --gpus N` without torch.distributed.run) on CPU: two ranks end to end
+in the dry-run test mode (kernels stubbed by tests/fakelib.py, gloo), and a rank that dies at start-up -- the launcher
+must stop the survivor and return non-zero within seconds instead of leaving it in a collective until the timeout."""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("sm3_bench", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _run(extra_env, timeout=240):
+    env = dict(os.environ, SM3_BENCH_DRYRUN="1", **extra_env)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    t0 = time.monotonic()
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                        env=env, capture_output=True, text=True, timeout=timeout)
+    return pr, time.monotonic() - t0
+
+
+def test_two_ranks_end_to_end_dry_run():
+    pr, _ = _run({})
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, pr.stdout          # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["dry_run"] is True and out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2"
+
+
+def test_a_rank_that_dies_stops_the_run_quickly():
+    pr, dt = _run({"SM3_BENCH_FAIL_RANK": "1"})
+    assert pr.returncode != 0
+    assert dt < 90, dt                          # far below the 120 s process-group timeout rank 0 would sit out
+    assert "[rank 1]" in pr.stderr and "injected start-up failure" in pr.stderr   # per-rank stderr, tagged
+    assert "stopping the other ranks" in pr.stderr
+    assert not [l for l in pr.stdout.splitlines() if l.startswith("{")]
+
+
+def test_gpu_count_comes_from_sysfs_not_from_hip():
+    b = _bench()
+    n = b.visible_gpus()
+    assert n is None or isinstance(n, int)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def spawn_ranks("):src.index("def dry_run_rank(")]
+    assert "torch.cuda" not in body             # the parent of the ranks never touches the GPU runtime

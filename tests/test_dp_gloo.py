@@ -169,3 +169,61 @@ def test_trainer_collective_pattern_gloo():
     assert a["n_stats"] == 428
     assert a["bucket_elems"] == a["total"]            # gradient buckets tile the flat buffer exactly once
     assert 4 <= a["n_buckets"] <= 16 and a["async"]
+
+
+def _kmeans_cpu(emb, K, iters=10, generator=None):
+    """CPU restatement of the reference's spherical k-means (tools/mlc_train.py:146-177) with sm3hip.mlc.spherical_kmeans'
+    interface: the HIP kernels are checked against this same restatement in tests/test_mlc.py (GPU)."""
+    N = emb.shape[0]
+    c = emb[torch.randperm(N, generator=generator)[:K]].double()
+    e = emb.double()
+    for it in range(iters + 1):
+        a = (e @ c.t()).max(1).indices
+        if it == iters:
+            break
+        for k in range(K):
+            if (a == k).any():
+                c[k] = e[a == k].sum(0) / (a == k).sum()
+        c = torch.nn.functional.normalize(c, dim=1)
+    return c.float(), a
+
+
+def _cluster_rank(rank, world):
+    """tools/mlc_train.py:136-143,185-186 under data parallelism: every rank holds a shard of the memory bank; rank 0
+    gathers it, clusters, and broadcasts centroids + assignments."""
+    import importlib.util
+    import types
+    from sm3hip import mlc
+    spec = importlib.util.spec_from_file_location("sm3_mlc_train", os.path.join(ROOT, "skin-sm3_amd", "tools", "mlc_train.py"))
+    mt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mt)
+    mlc.spherical_kmeans = _kmeans_cpu                      # the clustering itself is a HIP kernel: GPU-tested elsewhere
+    N_local, D, K = 37, 32, 5
+    g = torch.Generator().manual_seed(100)                   # the whole bank, identical on both ranks; each keeps its shard
+    centers = torch.nn.functional.normalize(torch.randn(K, D, generator=g), dim=1)
+    full = torch.nn.functional.normalize(centers[torch.randint(0, K, (world * N_local,), generator=g)]
+                                         + 0.2 * torch.randn(world * N_local, D, generator=g), dim=1)
+    perm = torch.randperm(world * N_local, generator=g)      # DistributedSampler-style interleaved sample indices
+    local_index = perm[rank::world].contiguous()
+    local_emb = full[local_index].contiguous()
+    proto = torch.nn.Linear(D, K, bias=False)
+    args = types.SimpleNamespace(world_size=world, rank=rank)
+    gk = torch.Generator().manual_seed(7)                    # only rank 0 draws from it
+    assign = mt.cluster_memory(args, proto, K, local_index, local_emb, generator=gk)
+    # single-process answer on the bank in the order rank 0 assembles it (rank-major)
+    order = torch.cat([perm[r::world] for r in range(world)])
+    c_ref, a_ref = _kmeans_cpu(full[order], K, generator=torch.Generator().manual_seed(7))
+    want = torch.empty(world * N_local, dtype=torch.long)
+    want[order] = a_ref
+    # plain lists: tensors handed through a multiprocessing queue need their producer alive
+    return {"assign": assign.tolist(), "weight": proto.weight.detach().tolist(), "want": want.tolist(),
+            "c_ref": c_ref.tolist()}
+
+
+def test_mlc_cluster_memory_gather_kmeans_broadcast_gloo():
+    res = _spawn(_cluster_rank)
+    a, b = res[0], res[1]
+    assert a["assign"] == b["assign"] and a["weight"] == b["weight"]   # both ranks hold rank 0's result
+    assert a["assign"] == a["want"]                          # every sample's cluster, addressed by its dataset index
+    assert min(a["assign"]) >= 0                             # no -100 left: the shards cover the bank
+    assert a["weight"] == a["c_ref"]                         # the centroids became the prototype weights

@@ -184,3 +184,28 @@ def test_checkpoint_wire_format_round_trip(model, golden_dir, tmp_path):
     for (k, a), (_, b) in zip(fresh.state_dict().items(), sd.items()):
         assert torch.equal(a, b), k
     assert ck["epoch"] == 3
+
+
+def test_mlc_eval_mode_matrix_matches_the_reference():
+    """tools/mlc_eval.py:124-138 of the reference: --finetune fc puts extractor, projectors AND the self-attention layer in
+    eval mode (no dropout anywhere, only the prototypes train); projector: only the extractor; all: nothing."""
+    import importlib.util
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "skin-sm3_amd", "tools")
+    spec = importlib.util.spec_from_file_location("sm3_mlc_eval_modes", os.path.join(tools, "mlc_eval.py"))
+    me = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(me)
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.extractor = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.BatchNorm1d(4))
+            self.projectors = torch.nn.Sequential(torch.nn.Linear(4, 4))
+            self.mlc_sa = torch.nn.TransformerEncoderLayer(d_model=4, nhead=1, dim_feedforward=8, dropout=0.1)
+            self.prototypes = torch.nn.ModuleList([torch.nn.Linear(4, 3)])
+    want = {"fc": (False, False, False, True), "projector": (False, True, True, True), "all": (True, True, True, True)}
+    for mode, flags in want.items():
+        m = Tiny().eval()
+        me.set_train_modes(m, mode)
+        got = (m.extractor.training, m.projectors.training, m.mlc_sa.training, m.prototypes.training)
+        assert got == flags, (mode, got)
+        assert m.mlc_sa.dropout.training == flags[2]

@@ -153,7 +153,31 @@ def test_mlc_train_tool_runs_and_learns(tmp_path):
     assert "mlc_sa.self_attn.in_proj_weight" in keys and "prototypes.7.weight" in keys and "projectors.projectors.0.0.weight" in keys
 
 
-@pytest.mark.parametrize("mode", ["projector", "all"])
+def test_fc_mode_heads_run_without_dropout():
+    """--finetune fc (reference tools/mlc_eval.py:124-128): mlc_sa is in eval mode, so the head forward is deterministic
+    (no dropout mask, whatever the seed) and equals torch's own TransformerEncoderLayer in eval mode."""
+    from sm3hip import mlc
+    torch.manual_seed(2)
+    D, ff = 128, 64
+    ref = _RefHeads(2 * 2048, D, 1, ff, 0.1, False, True).to(DEV)
+    feats = torch.randn(6, 2 * 2048, device=DEV)
+    ref.train()
+    ref.projectors.eval()
+    ref.mlc_sa.eval()                                  # what tools/mlc_eval.py's set_train_modes(., "fc") leaves
+    _, a = mlc.heads_forward(ref, feats, seed=1)
+    _, b = mlc.heads_forward(ref, feats, seed=99)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    want = ref(feats)[1]
+    for x, y in zip(a, want):
+        assert float((x - y).abs().max()) < 2e-4 * (float(y.abs().max()) + 1.0)
+    ref.mlc_sa.train()                                 # projector / all modes: dropout active, seed-dependent
+    _, c = mlc.heads_forward(ref, feats, seed=1)
+    _, d = mlc.heads_forward(ref, feats, seed=99)
+    assert any(not torch.equal(x, y) for x, y in zip(c, d))
+
+
+@pytest.mark.parametrize("mode", ["fc", "projector", "all"])
 def test_mlc_eval_tool_finetunes_from_an_mlc_train_checkpoint(tmp_path, mode):
     """tools/mlc_eval.py: loads the mlc_train checkpoint format (bias-free prototypes dropped, strict=False), fine-tunes
     with real labels in the `projector` and `all` freeze modes (the latter sends gradients into the HIP encoders'

@@ -158,6 +158,22 @@ def test_simclr_alone():
     torch.cuda.synchronize()
     assert lab.dtype == torch.long and tuple(lg.shape) == (8, 7)
     assert (lg.detach().cpu().double() - lg_ref.detach()).abs().max().item() < 2e-3
+    # return_feats=True standalone (reference simclr.py:54-91): the features of the SAME forward -- BatchNorm buffers
+    # advance by exactly the two encoder calls of one forward, no hidden extra passes
+    (lg_ref2, _), (f1_ref, f2_ref) = O.simclr_forward(x1.double(), x2.double(), P, Bf, "", 0.5, True)
+    m2 = SimCLR("resnet50", None, 128, 0.5, return_feats=True)
+    m2.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    m2.sm3_dtype = torch.float32
+    m2.cuda().train()
+    nbt0 = int(m2.encoder.bn1.num_batches_tracked)
+    (lg2, lab2), (f1, f2) = m2(x1.cuda(), x2.cuda())
+    torch.cuda.synchronize()
+    assert int(m2.encoder.bn1.num_batches_tracked) == nbt0 + 2
+    assert int(m2.encoder.layer4[2].bn3.num_batches_tracked) == nbt0 + 2
+    assert torch.equal(lg2.detach(), lg.detach()) and not f1.requires_grad
+    for got, ref in ((f1, f1_ref), (f2, f2_ref)):
+        assert tuple(got.shape) == (4, 2048)
+        assert torch.allclose(got.cpu().double(), ref.detach(), rtol=1e-3, atol=1e-4)
 
 
 def test_adamw_grad_scale_and_overflow_skip_in_trainer_units():
