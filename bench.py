@@ -69,6 +69,9 @@ def parse():
                     help="bf16 = BASELINE.json configs[1] (default); f16 = the reference's AMP type, with dynamic loss scaling "
                          "(configs[4]); f32 = exact-f32 MFMA parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-dtypes", action="store_true",
+                    help="skip the two short extra loops that time the same step in the other arithmetic modes "
+                         "(config.other_modes; N=1 default run only)")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--workload", default="pretrain", choices=["pretrain", "linear_probe", "inference", "mlc_train"],
@@ -555,6 +558,7 @@ def main():
                 "avg_launch_gflop": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 3),
                 "whole_step_mfma_frac": round(pairs_per_s / world * (FLOP_PER_PAIR_224 * (S / 224.0) ** 2) / (peak * 1e12), 4)}
 
+    peak_gb = round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)  # of the headline mode (read before the other-mode loops)
     if args.breakdown and rank == 0:
         full = profiler.Profiler()
         ops.set_profiler(full)
@@ -563,6 +567,37 @@ def main():
         ops.set_profiler(None)
         with open(args.breakdown, "w") as f:
             f.write(full.format_table(f"per-kernel-class breakdown of one step, B={B}, {S}x{S}, {args.dtype}"))
+
+    # The same step in the other two arithmetic modes, next to the headline (bf16 = BASELINE.json configs[1]): fp16 +
+    # dynamic loss scaling is the reference's own AMP recipe (run.sh:10, backbone_train.py:27,98,480); exact-f32 MFMA is the
+    # mode that meets north_star's 1e-3 loss / logit tolerance.  Short loops (same inputs, fresh weights), N=1 only.
+    other_modes = None
+    plain = not (args.global_negatives or args.metadata_dim or args.target_momentum or args.single_lane)
+    if world == 1 and args.dtype == "bf16" and plain and not args.no_other_dtypes and not args.no_cpu_baseline:
+        del trainer, model, eng
+        torch.cuda.empty_cache()
+        other_modes = {}
+        for name, odt, nw, ns in (("f16", torch.float16, 2, 6), ("f32", torch.float32, 1, 3)):
+            torch.manual_seed(3407)
+            om = SimCLRSkinV32("resnet50", None, 128, 0.1)
+            om.sm3_dtype = odt
+            om.to(dev)
+            otr = SM3Trainer(om, lr=1e-6, weight_decay=5e-2, eps=1e-5, style=0)
+            for _ in range(nw):
+                otr.step(derm, clinic)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(ns):
+                otr.step(derm, clinic)
+            torch.cuda.synchronize()
+            dt_ = time.perf_counter() - t1
+            other_modes[name + "_pairs_per_s"] = round(B * ns / dt_, 1)
+            other_modes[name + "_steps_timed"] = ns
+            del otr, om
+            torch.cuda.empty_cache()
+        other_modes["note"] = ("same step, same inputs: f16 = fp16 storage + f16 MFMA + device-side dynamic loss scaling "
+                               "(the reference's AMP type); f32 = exact-f32 MFMA parity mode (loss / logits within 1e-3 "
+                               "of the reference)")
 
     if rank == 0:
         out = {
@@ -576,9 +611,11 @@ def main():
                        "negatives": "global (all-gather)" if args.global_negatives else "local (reference)",
                        "extensions": {"metadata_dim": args.metadata_dim, "target_momentum": args.target_momentum},
                        "loss": round(loss_val, 5),
-                       "peak_hbm_allocated_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)},
+                       "peak_hbm_allocated_gb": peak_gb},
             "roofline": roofline,
         }
+        if other_modes:
+            out["config"]["other_modes"] = other_modes
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, S, args.cpu_steps)
         print(json.dumps(out), flush=True)

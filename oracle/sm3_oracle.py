@@ -229,6 +229,29 @@ def sm3_loss(outputs, style):
     return cross_entropy_zero_label(derm_outs[0]) + cross_entropy_zero_label(clinic_outs[0]) + cross_loss
 
 
+def momentum_target_loss(P, B, P_target, derm_imgs, clinic_imgs, style, temperature):
+    """BASELINE.json north_star's "momentum-updated target encoders" as SM3Trainer(target_momentum=) defines them -- an
+    EXTENSION with no reference semantics (the reference has no target network; its nearest code, the never-called queue
+    helper src/utils/misc.py:629-659, defines no loss).  Every term of the loss composition (sm3_loss weights) becomes the
+    symmetrised query / key pair
+        w/2 * NTXent(cat[q_first_half, k_second_half]) + w/2 * NTXent(cat[k_first_half, q_second_half])
+    with q the ONLINE projections (parameters P, gradient flows, BatchNorm buffers B advance) and k the TARGET network's
+    projections of the same batch (parameters P_target, train-mode batch statistics, no gradient, buffers untouched).
+    Both halves of a concatenation act as anchors and as candidates; only q receives gradient."""
+    q = sm3_v32_projections(P, B, derm_imgs, clinic_imgs, style, training=True)
+    with torch.no_grad():
+        Bt = {k: v.clone() for k, v in B.items()}
+        k = sm3_v32_projections(P_target, Bt, derm_imgs, clinic_imgs, style, training=True)
+    wc = 0.25 if style == 2 else 0.5
+    weights = [1.0, 1.0] + [wc] * (len(q) - 2)
+    loss = 0.0
+    for w, zq, zk in zip(weights, q, k):
+        h = zq.shape[0] // 2
+        loss = loss + 0.5 * w * (ntxent_loss_closed_form(torch.cat([zq[:h], zk[h:]], 0), temperature)
+                                 + ntxent_loss_closed_form(torch.cat([zk[:h], zq[h:]], 0), temperature))
+    return loss
+
+
 def ntxent_global_rows(z_local, z_all, offset, temperature):
     """NT-Xent of this rank's rows against the candidate rows of EVERY rank (opt-in "global negatives" mode of the build;
     not reference behaviour): mean_i[ -S_ip/T + log sum_{j != self} exp(S_ij/T) ] with S the cosines
