@@ -173,7 +173,7 @@ def test_simclr_alone():
     assert torch.equal(lg2.detach(), lg.detach()) and not f1.requires_grad
     for got, ref in ((f1, f1_ref), (f2, f2_ref)):
         assert tuple(got.shape) == (4, 2048)
-        assert torch.allclose(got.cpu().double(), ref.detach(), rtol=1e-3, atol=1e-4)
+        assert torch.allclose(got.cpu().double(), ref.detach(), rtol=2e-3, atol=1e-3)  # f32 vs fp64 through 4-image BatchNorms
 
 
 def test_adamw_grad_scale_and_overflow_skip_in_trainer_units():
