@@ -30,9 +30,17 @@ namespace {
 // SEG: the K loop may draw taps from a SECOND (A, B) operand pair (ConvParams::x1 / w1, tap_src): Y = sum_t A_t B_t^T
 // over two tensors with different channel counts -- the data gradient of "BatchNorm backward by linearity" (linbn.hip),
 // [dz | y_in] x [diag(a) W ; -H]^T.  Only the general epilogue has it; the production forward kernels are untouched.
-template <typename T, int BM, int BN, int WM, int WN, int STAGES, bool LEAN, bool SEG = false>
+// EPI: 0 = general epilogue (f32 staging, one wave-row at a time: every feature, every type); 16-bit types only:
+//      1 = lean (whole tile staged once as 16-bit, stored with no arithmetic: the train-mode forward convolutions),
+//      2 = lean + per-row work on the read-back: addend (dense or compact), BatchNorm affine + ReLU + ReLU bits
+//          (sm3_conv_bn_act_fused / the inference forms with a residual), strided outputs,
+//      3 = 2 + the fused BatchNorm-backward phase 1 (ReLU mask, sum dz, sum dz*xhat) of the data-gradient launches.
+//      2 / 3 round the GEMM result to 16 bits BEFORE the addend is added in fp32 -- what autocast does with a convolution
+//      output that is then accumulated -- and keep twice the bytes of 0 in flight per workgroup with half its barriers.
+template <typename T, int BM, int BN, int WM, int WN, int STAGES, int EPI, bool SEG = false>
 __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvParams p) {
-    static_assert(!(SEG && LEAN) && !(SEG && STAGES > 2), "segments: general epilogue, 1 or 2 stages");
+    constexpr bool LEAN = EPI >= 1;
+    static_assert(!(SEG && EPI != 0 && EPI != 3) && !(SEG && STAGES > 2), "segments: data-gradient epilogues, 1 or 2 stages");
     constexpr int NT = WM * WN * 64;
     constexpr int RPP = NT / 8;  // rows covered per loader pass
     constexpr int AI = BM / RPP, BI = BN / RPP;
@@ -252,22 +260,81 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
         char* sC = smem;
         float* sStat = reinterpret_cast<float*>(smem + MAIN_BYTES);  // [WM][BN][2]
         const uint32_t ones = ones2<T>();
+        const int cc = tid % CPR, r0 = tid / CPR;
+        const int ncol = n0 + cc * 8;
+        const bool fz = EPI == 3 && p.fz_partials != nullptr;
+        const bool fzx = fz && p.fz_x != nullptr;
+        // ---- EPI >= 2: what the read-back loop needs from global memory, requested NOW (all NPASS rows of this thread:
+        // 16-32 KB per workgroup in flight while the accumulators are converted and staged)
+        uint32_t eoff[EPI >= 2 ? NPASS : 1];           // byte offset of the thread's vector in row k of the output; ~0 = none
+        uint4 pre_add[EPI >= 2 ? NPASS : 1], pre_x[EPI == 3 ? NPASS : 1];
+        unsigned pre_mk[EPI == 3 ? NPASS : 1];
+        if constexpr (EPI >= 2) {
+            const bool dense = (p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.HWout == p.HoWo);
+#pragma unroll
+            for (int k = 0; k < NPASS; ++k) {
+                const int m = m0 + r0 + k * RSTEP;
+                eoff[k] = ~0u;
+                pre_add[k] = make_uint4(0, 0, 0, 0);
+                if constexpr (EPI == 3) {
+                    pre_x[k] = make_uint4(0, 0, 0, 0);
+                    pre_mk[k] = 0xffu;
+                }
+                if (m < p.M && ncol < p.Co) {
+                    long opix = m;
+                    int nn = 0, oy = 0, ox = 0;
+                    if (!dense || p.add_sp_h) {
+                        nn = fdiv(m, p.div_HoWo);
+                        const int rem = m - nn * p.HoWo;
+                        oy = fdiv(rem, p.div_Wo);
+                        ox = rem - oy * p.Wo;
+                        if (!dense) opix = (long)nn * p.HWout + (long)(oy * p.osy + p.ooy) * p.Wout + (ox * p.osx + p.oox);
+                    }
+                    eoff[k] = (uint32_t)((opix * p.Co + ncol) * 2);  // tensors stay below 3 GB (host check)
+                    if (p.addend) {
+                        if (p.add_sp_h) {  // compact stride-2 addend: present at even (y, x) only
+                            if (((oy | ox) & 1) == 0)
+                                pre_add[k] = ldg16<true>(p.addend + ((((long)nn * p.add_sp_h + (oy >> 1)) * p.add_sp_w + (ox >> 1)) * p.Co + ncol) * 2);
+                        } else {
+                            pre_add[k] = ldg16<true>(p.addend + eoff[k]);
+                        }
+                    }
+                    if constexpr (EPI == 3) {
+                        if (fzx) pre_x[k] = ldg16<true>(p.fz_x + eoff[k]);
+                        if (fz && p.fz_mask) pre_mk[k] = p.fz_mask[eoff[k] >> 4];
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float s1 = 0.f, s2 = 0.f;
             char* colp = sC + (wn * WTN + j * 32 + frow) * 2 + (wm * WTM + 4 * fh) * LEAN_PITCH;
-            // inference: eval-mode BatchNorm (+ReLU) of this lane's column, applied in the accumulator layout
+            // BatchNorm affine (+ReLU when nothing is added afterwards) of this lane's column, in the accumulator layout;
+            // per view in the train-mode fused form
             const int gcol = n0 + wn * WTN + j * 32 + frow;
             const bool epl = p.ep_scale != nullptr || p.ep_rv != nullptr;
             float esc = 1.f, esh = 0.f;
-            if (epl && gcol < p.Co) ep_affine(p, gcol, esc, esh);
-            const float elo = (epl && p.ep_relu) ? 0.f : -INFINITY;
+            if (epl && gcol < p.Co) {
+                if (p.ep_rv) {
+                    ep_affine(p, gcol, esc, esh);
+                } else {
+                    esc = p.ep_scale[tile_view * p.Co + gcol];
+                    esh = p.ep_shift[tile_view * p.Co + gcol];
+                }
+            }
+            if constexpr (SEG) {  // constant term of the linear BatchNorm backward (per output channel and view)
+                if (p.col_bias && gcol < p.Co) esh += p.col_bias[tile_view * p.Co + gcol];
+            }
+            const bool early_relu = epl && p.ep_relu && (EPI == 1 || !p.addend) && !p.ep_mask;
+            const float elo = early_relu ? 0.f : -INFINITY;
+            const bool aff = epl || (SEG && p.col_bias);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {  // registers 2q, 2q+1 = rows R, R+1 of this lane's column
                     float v0 = acc[i][j][2 * q], v1 = acc[i][j][2 * q + 1];
-                    if (epl) {
+                    if (aff) {
                         v0 = fmaxf(v0 * esc + esh, elo);
                         v1 = fmaxf(v1 * esc + esh, elo);
                     }
@@ -299,19 +366,96 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
             p.partials[((long)bm * 2 + 0) * p.Co + n0 + tid] = s1;
             p.partials[((long)bm * 2 + 1) * p.Co + n0 + tid] = s2;
         }
-        const int cc = tid % CPR, r0 = tid / CPR;
-        const int ncol = n0 + cc * 8;
-        if (ncol < p.Co) {
-            char* yp = p.y + ((long)(m0 + r0) * p.Co + ncol) * 2;
-            const long ystep = (long)RSTEP * p.Co * 2;
-            const char* sp = sC + r0 * LEAN_PITCH + cc * 16;
+        const char* sp = sC + r0 * LEAN_PITCH + cc * 16;
+        if constexpr (EPI == 1) {
+            if (ncol < p.Co) {
+                char* yp = p.y + ((long)(m0 + r0) * p.Co + ncol) * 2;
+                const long ystep = (long)RSTEP * p.Co * 2;
+#pragma unroll
+                for (int k = 0; k < NPASS; ++k) {
+                    if (m0 + r0 + k * RSTEP < p.M)
+                        stg16<true>(yp + k * ystep, *reinterpret_cast<const uint4*>(sp + k * RSTEP * LEAN_PITCH));
+                }
+            }
+            return;
+        } else {
+            const bool late_relu = (p.ep_scale != nullptr || p.ep_rv != nullptr) && p.ep_relu && (p.addend || p.ep_mask);
+            float f_mu[8], f_is[8], f_s1[8], f_s2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                f_s1[e] = f_s2[e] = f_mu[e] = f_is[e] = 0.f;
+                if (EPI == 3 && fzx && ncol < p.Co) {
+                    f_mu[e] = p.fz_mean[tile_view * p.Co + ncol + e];
+                    f_is[e] = p.fz_invstd[tile_view * p.Co + ncol + e];
+                }
+            }
 #pragma unroll
             for (int k = 0; k < NPASS; ++k) {
-                if (m0 + r0 + k * RSTEP < p.M)
-                    stg16<true>(yp + k * ystep, *reinterpret_cast<const uint4*>(sp + k * RSTEP * LEAN_PITCH));
+                if (eoff[k] == ~0u) continue;
+                uint4 packed = *reinterpret_cast<const uint4*>(sp + k * RSTEP * LEAN_PITCH);
+                if (p.addend || late_relu || (EPI == 3 && fz)) {
+                    float v[8];
+                    unpack16<T>(packed, v);
+                    if (p.addend) {
+                        float a[8];
+                        unpack16<T>(pre_add[k], a);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += a[e];
+                    }
+                    if (late_relu) {
+                        if (p.ep_mask) {  // what the backward pass needs of the output: one bit per element
+                            unsigned mbits = 0;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) mbits |= (v[e] > 0.f ? 1u : 0u) << e;
+                            p.ep_mask[eoff[k] >> 4] = (uint8_t)mbits;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if constexpr (EPI == 3) {
+                        if (fz) {
+                            const unsigned mk = pre_mk[k];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = ((mk >> e) & 1u) ? v[e] : 0.f;
+                        }
+                    }
+                    packed = pack16<T>(v);
+                    if constexpr (EPI == 3) {
+                        if (fz) {  // sums of the STORED (rounded) dz, as the standalone kernel's
+                            float dzr[8], xv[8];
+                            unpack16<T>(packed, dzr);
+                            unpack16<T>(pre_x[k], xv);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                f_s1[e] += dzr[e];
+                                f_s2[e] += dzr[e] * (xv[e] - f_mu[e]) * f_is[e];  // f_mu = f_is = 0 without x: stays 0
+                            }
+                        }
+                    }
+                }
+                stg16<true>(p.y + eoff[k], packed);
             }
+            if constexpr (EPI == 3) {
+                if (fz) {
+                    const int fz_prow = tile_view ? p.fz_row_off1 + bm - p.fz_view_tiles : p.fz_row_off + bm;
+                    __syncthreads();  // everyone is done reading sC: reuse it for the cross-thread reduction
+                    float* sRed = reinterpret_cast<float*>(smem);  // [NT][16] floats = 16 KB
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        sRed[tid * 16 + e] = f_s1[e];
+                        sRed[tid * 16 + 8 + e] = f_s2[e];
+                    }
+                    __syncthreads();
+                    for (int o = tid; o < 2 * BN; o += NT) {
+                        const int stat = o / BN, col = o % BN;  // channel n0+col lives in threads with cc == col/8
+                        float a = 0.f;
+                        for (int rl = 0; rl < NT / CPR; ++rl) a += sRed[(rl * CPR + col / 8) * 16 + stat * 8 + col % 8];
+                        if (n0 + col < p.Co) p.fz_partials[((long)fz_prow * 2 + stat) * p.Co + n0 + col] = a;
+                    }
+                }
+            }
+            return;
         }
-        return;
     }
 
     // ---- epilogue -----------------------------------------------------------------------
@@ -526,17 +670,18 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int STAGES, bool LEAN, bool SEG = false>
+template <typename T, int BM, int BN, int WM, int WN, int STAGES, int EPI, bool SEG = false>
 int launch_conv_st(const ConvParams& p0, hipStream_t st) {
     ConvParams p = p0;
+    constexpr bool LEAN = EPI >= 1;
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int C_BYTES = LEAN ? BM * (BN * 2 + 16) : (BM / WM) * (BN + 4) * 4;
     constexpr int MAIN = (STAGES * STAGE > C_BYTES) ? STAGES * STAGE : C_BYTES;
     constexpr int LDS = MAIN + WM * BN * 2 * 4;
-    static_assert(LEAN || MAIN >= 256 * 2 * 8 * 4, "reduction scratch of the fused BN-backward epilogue must fit");
+    static_assert(MAIN >= 256 * 2 * 8 * 4, "reduction scratch of the fused BN-backward epilogue must fit");
     p.tilesM = (p.M + BM - 1) / BM;
     p.tilesN = (p.Co + BN - 1) / BN;
-    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, STAGES, LEAN, SEG>;
+    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, STAGES, EPI, SEG>;
     // the dynamic-LDS limit is a per-device attribute of the function: set it once per (instantiation, device)
     static std::atomic<uint32_t> attr_set{0};  // bit d: done on device d
     int dev = 0;
@@ -554,14 +699,23 @@ int launch_conv_st(const ConvParams& p0, hipStream_t st) {
     return 0;
 }
 
+template <typename T, int BM, int BN, int WM, int WN, int EPI>
+int launch_conv_epi(const ConvParams& p, hipStream_t st, bool single, bool deep) {
+    if (deep) return launch_conv_st<T, BM, BN, WM, WN, 4, EPI>(p, st);
+    return single ? launch_conv_st<T, BM, BN, WM, WN, 1, EPI>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, EPI>(p, st);
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_conv(const ConvParams& p, hipStream_t st) {
     const char* v = getenv("SM3_CONV_SINGLE_STAGE_MAX");
     const int single_max = v ? atoi(v) : 8;
+    const char* lv = getenv("SM3_CONV_LEAN");
+    const bool lean = !(lv && atoi(lv) == 0);  // SM3_CONV_LEAN=0: everything through the general epilogue (A/B, debugging)
     if (p.x1) {  // two K segments (16-bit types only: the exact-f32 parity mode never takes the linear BatchNorm backward)
         if constexpr (sizeof(T) == 2) {
-            return p.nsteps_seg <= single_max ? launch_conv_st<T, BM, BN, WM, WN, 1, false, true>(p, st)
-                                              : launch_conv_st<T, BM, BN, WM, WN, 2, false, true>(p, st);
+            const bool one = p.nsteps_seg <= single_max;
+            if (lean) return one ? launch_conv_st<T, BM, BN, WM, WN, 1, 3, true>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, 3, true>(p, st);
+            return one ? launch_conv_st<T, BM, BN, WM, WN, 1, 0, true>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, 0, true>(p, st);
         } else {
             return SM3_EDTYPE;
         }
@@ -572,18 +726,16 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
     const char* dv = getenv("SM3_CONV_DEEP");
     const bool deep = !(dv && atoi(dv) == 0) && nblocks <= 256 && p.ntaps * p.kchunks >= 6;
     if constexpr (sizeof(T) == 2) {
-        const char* lv = getenv("SM3_CONV_LEAN");
-        const bool dense = p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.HWout == p.HoWo;
-        // (the lean epilogue knows neither per-view scale / shift nor the ReLU-bit output of the train-mode fused form)
-        if (!(lv && atoi(lv) == 0) && dense && !p.addend && !p.fz_partials && !p.ep_mask &&
-            !(p.ep_scale && p.fz_view_tiles)) {  // train-mode forward, and conv+evalBN(+ReLU)
-            if (deep) return launch_conv_st<T, BM, BN, WM, WN, 4, true>(p, st);
-            return single ? launch_conv_st<T, BM, BN, WM, WN, 1, true>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, true>(p, st);
+        if (lean) {
+            const bool dense = p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.HWout == p.HoWo;
+            if (p.fz_partials) return launch_conv_epi<T, BM, BN, WM, WN, 3>(p, st, single, deep);  // data gradient + BN-backward phase 1
+            // per-row work on the read-back: an addend, ReLU bits, per-view affine, a strided output
+            if (p.addend || p.ep_mask || !dense || (p.ep_scale && p.fz_view_tiles))
+                return launch_conv_epi<T, BM, BN, WM, WN, 2>(p, st, single, deep);
+            return launch_conv_epi<T, BM, BN, WM, WN, 1>(p, st, single, deep);  // train-mode forward, conv + evalBN (+ReLU)
         }
     }
-    if (deep) return launch_conv_st<T, BM, BN, WM, WN, 4, false>(p, st);
-    if (single) return launch_conv_st<T, BM, BN, WM, WN, 1, false>(p, st);
-    return launch_conv_st<T, BM, BN, WM, WN, 2, false>(p, st);
+    return launch_conv_epi<T, BM, BN, WM, WN, 0>(p, st, single, deep);
 }
 
 constexpr int kBM = 128;
