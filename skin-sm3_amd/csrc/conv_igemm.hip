@@ -38,7 +38,7 @@ namespace {
 //      2 / 3 round the GEMM result to 16 bits BEFORE the addend is added in fp32 -- what autocast does with a convolution
 //      output that is then accumulated -- and keep twice the bytes of 0 in flight per workgroup with half its barriers.
 template <typename T, int BM, int BN, int WM, int WN, int STAGES, int EPI, bool SEG = false>
-__global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(WM* WN * 64, (EPI == 3 ? 4 : 2)) void conv_igemm_kernel(const ConvParams p) {  // EPI 3: 130 -> 128 registers, 4 workgroups per CU
     constexpr bool LEAN = EPI >= 1;
     static_assert(!(SEG && EPI != 0 && EPI != 3) && !(SEG && STAGES > 2), "segments: data-gradient epilogues, 1 or 2 stages");
     constexpr int NT = WM * WN * 64;
@@ -269,42 +269,46 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
         uint32_t eoff[EPI >= 2 ? NPASS : 1];           // byte offset of the thread's vector in row k of the output; ~0 = none
         uint4 pre_add[EPI >= 2 ? NPASS : 1], pre_x[EPI == 3 ? NPASS : 1];
         unsigned pre_mk[EPI == 3 ? NPASS : 1];
-        if constexpr (EPI >= 2) {
-            const bool dense = (p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.HWout == p.HoWo);
-#pragma unroll
-            for (int k = 0; k < NPASS; ++k) {
-                const int m = m0 + r0 + k * RSTEP;
-                eoff[k] = ~0u;
-                pre_add[k] = make_uint4(0, 0, 0, 0);
-                if constexpr (EPI == 3) {
-                    pre_x[k] = make_uint4(0, 0, 0, 0);
-                    pre_mk[k] = 0xffu;
+        // EPI 3 asks for the first half of its rows here and for the second half right after the barrier (while the first
+        // half is being finished): two operand streams per row would otherwise hold 64 registers beside the accumulators
+        constexpr int NEARLY = EPI == 3 ? NPASS / 2 : NPASS;
+        const bool dense_out = (p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.HWout == p.HoWo);
+        auto request = [&](int k) {
+            const int m = m0 + r0 + k * RSTEP;
+            eoff[k] = ~0u;
+            pre_add[k] = make_uint4(0, 0, 0, 0);
+            if constexpr (EPI == 3) {
+                pre_x[k] = make_uint4(0, 0, 0, 0);
+                pre_mk[k] = 0xffu;
+            }
+            if (m < p.M && ncol < p.Co) {
+                long opix = m;
+                int nn = 0, oy = 0, ox = 0;
+                if (!dense_out || p.add_sp_h) {
+                    nn = fdiv(m, p.div_HoWo);
+                    const int rem = m - nn * p.HoWo;
+                    oy = fdiv(rem, p.div_Wo);
+                    ox = rem - oy * p.Wo;
+                    if (!dense_out) opix = (long)nn * p.HWout + (long)(oy * p.osy + p.ooy) * p.Wout + (ox * p.osx + p.oox);
                 }
-                if (m < p.M && ncol < p.Co) {
-                    long opix = m;
-                    int nn = 0, oy = 0, ox = 0;
-                    if (!dense || p.add_sp_h) {
-                        nn = fdiv(m, p.div_HoWo);
-                        const int rem = m - nn * p.HoWo;
-                        oy = fdiv(rem, p.div_Wo);
-                        ox = rem - oy * p.Wo;
-                        if (!dense) opix = (long)nn * p.HWout + (long)(oy * p.osy + p.ooy) * p.Wout + (ox * p.osx + p.oox);
+                eoff[k] = (uint32_t)((opix * p.Co + ncol) * 2);  // tensors stay below 3 GB (host check)
+                if (p.addend) {
+                    if (p.add_sp_h) {  // compact stride-2 addend: present at even (y, x) only
+                        if (((oy | ox) & 1) == 0)
+                            pre_add[k] = ldg16<true>(p.addend + ((((long)nn * p.add_sp_h + (oy >> 1)) * p.add_sp_w + (ox >> 1)) * p.Co + ncol) * 2);
+                    } else {
+                        pre_add[k] = ldg16<true>(p.addend + eoff[k]);
                     }
-                    eoff[k] = (uint32_t)((opix * p.Co + ncol) * 2);  // tensors stay below 3 GB (host check)
-                    if (p.addend) {
-                        if (p.add_sp_h) {  // compact stride-2 addend: present at even (y, x) only
-                            if (((oy | ox) & 1) == 0)
-                                pre_add[k] = ldg16<true>(p.addend + ((((long)nn * p.add_sp_h + (oy >> 1)) * p.add_sp_w + (ox >> 1)) * p.Co + ncol) * 2);
-                        } else {
-                            pre_add[k] = ldg16<true>(p.addend + eoff[k]);
-                        }
-                    }
-                    if constexpr (EPI == 3) {
-                        if (fzx) pre_x[k] = ldg16<true>(p.fz_x + eoff[k]);
-                        if (fz && p.fz_mask) pre_mk[k] = p.fz_mask[eoff[k] >> 4];
-                    }
+                }
+                if constexpr (EPI == 3) {
+                    if (fzx) pre_x[k] = ldg16<true>(p.fz_x + eoff[k]);
+                    if (fz && p.fz_mask) pre_mk[k] = p.fz_mask[eoff[k] >> 4];
                 }
             }
+        };
+        if constexpr (EPI >= 2) {
+#pragma unroll
+            for (int k = 0; k < NEARLY; ++k) request(k);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -367,6 +371,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvPa
             p.partials[((long)bm * 2 + 1) * p.Co + n0 + tid] = s2;
         }
         const char* sp = sC + r0 * LEAN_PITCH + cc * 16;
+        if constexpr (EPI == 3) {
+#pragma unroll
+            for (int k = NEARLY; k < NPASS; ++k) request(k);
+        }
         if constexpr (EPI == 1) {
             if (ncol < p.Co) {
                 char* yp = p.y + ((long)(m0 + r0) * p.Co + ncol) * 2;

@@ -130,7 +130,7 @@ def test_T2_loss_trajectories_and_linear_probe_auroc():
     probe on the three frozen encoder pairs.  Trajectories on a STREAM of batches are chaotic from random init (any
     rounding difference is amplified step by step: tests/test_e2e_gpu.py), so the curves are compared where the reference
     arithmetic itself is reproducible: stepping on one fixed batch of 16 learnable pairs at lr = 3e-4 (fp32 oracle:
-    11.6 -> 0.09 in 15 steps, 0.02 in 30).  Bands as measured on MI355X, stated below; the probe (ridge regression on
+    11.6 -> 0.09 in 15 steps, 0.02 in 30).  Band stated below; the probe (ridge regression on
     model.extract features in eval mode, AUROC by the reference's AUC_AVG rule src/utils/misc.py:299-327) must agree
     between the three arithmetic modes within its own sampling noise (3e-2 at 512 samples; SURVEY's 1e-2 needs a real
     dataset-sized evaluation set)."""
@@ -172,12 +172,17 @@ def test_T2_loss_trajectories_and_linear_probe_auroc():
     pick = [0, 2, 4, 9, 14, 19, 29]
     print("loss f32 ", np.round(f32[pick], 3), "AUROC", {k: round(v, 4) for k, v in aucs.items()})
     assert f32[0] > 5.0 and f32[-3:].mean() < 0.3
-    for name, rel, ab in (("f16", 0.35, 0.05), ("bf16", 0.6, 0.1)):
+    # the loss falls by a factor of ~2 per step in mid-descent, so a curve that is half a step ahead or behind differs by
+    # tens of per cent there: the band around the f32 curve is taken over a +-1 step window, x0.65 .. x1.35 (+-0.05)
+    lo = np.minimum.reduce([np.roll(f32, 1), f32, np.roll(f32, -1)])
+    hi = np.maximum.reduce([np.roll(f32, 1), f32, np.roll(f32, -1)])
+    lo[0], hi[0], lo[-1], hi[-1] = min(f32[0], f32[1]), max(f32[0], f32[1]), min(f32[-2:]), max(f32[-2:])
+    for name in ("f16", "bf16"):
         c = np.array(curves[name])
         d = np.abs(c - f32)
         print(f"loss {name}", np.round(c[pick], 3), "max |d|", round(float(d.max()), 3), "max |d| / f32",
               round(float((d / np.maximum(f32, 1e-3)).max()), 3))
-        assert (d <= rel * f32 + ab).all(), (name, d.max(), (d / f32).max())      # band around the f32 curve, step by step
+        assert ((c >= 0.65 * lo - 0.05) & (c <= 1.35 * hi + 0.05)).all(), (name, np.round(c, 3), np.round(f32, 3))
         assert abs(c[0] - f32[0]) < (0.15 if name == "f16" else 0.5)              # same starting point (B = 16: 0.09 / ~0.3)
         assert c[-3:].mean() < 0.3                                                  # same end state
     # encoders overfitted to ONE batch of 16 pairs carry little of the held-out samples' statistics (AUROC ~0.56 measured,
