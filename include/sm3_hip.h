@@ -111,9 +111,16 @@ typedef struct sm3_conv_seg {
     int64_t w_view_stride;     /* elements between the views' w0 banks (0: shared) */
     int64_t w1_view_stride;
     const float* col_bias;     /* [views][Co], nullable */
+    int32_t views;             /* sm3_conv_gather_gemm_seg only (0 / 1: one view; 2: two views back to back, each a multiple
+                                * of 128 rows); sm3_conv_dgrad_seg_bnfuse takes the views from its fuse argument */
 } sm3_conv_seg;
 int sm3_conv_dgrad_seg_bnfuse(const sm3_conv_desc* d, const void* x0, const void* w0, const sm3_conv_seg* seg,
                               void* dz_out, const void* addend, const sm3_bn_bwd_fuse* fuse, void* stream);
+/* The two-segment product alone, y = x0 w0^T + x1 w1^T + col_bias (+ addend): the data gradient of an expanding conv ->
+ * BatchNorm pair whose result has no producer BatchNorm to prepare (a Bottleneck's downsample branch: the compact
+ * gradient that the block's conv1 data gradient then takes as its sparse addend). */
+int sm3_conv_gather_gemm_seg(const sm3_conv_desc* d, const void* x0, const void* w0, const sm3_conv_seg* seg, void* y,
+                             const void* addend, void* stream);
 
 /* Inference: conv + eval-mode BatchNorm (+ residual) (+ ReLU) in one launch,
  *   y = relu?( conv(x, w) * scale[co] + shift[co] (+ residual) ),
@@ -197,6 +204,13 @@ int sm3_bn_act(int dtype, const void* x, const float* scale, const float* shift,
 int sm3_bn_act_colsum_rows(int64_t rows, int C, int dtype);
 int sm3_bn_act_colsum(int dtype, const void* x, const float* scale, const float* shift, const void* residual, int relu,
                       void* y, uint8_t* relu_mask, float* colsum_partials, int64_t rows, int C, int views, void* stream);
+/* Column sums of x [N, H, W, C] at the pixels (y % stride == 0, x % stride == 0) as partial rows
+ * [views][sm3_subsample_colsum_rows(N / views * Hs * Ws, C, dtype)][C] fp32 (summed by sm3_linbn_moments), and -- y given --
+ * those pixels as a compact tensor y [N, Hs, Ws, C], Hs = (H - 1) / stride + 1: the input of a strided 1x1 convolution
+ * (a Bottleneck's downsample branch, resnet.py:260) as the dense operand that BatchNorm by linearity needs. */
+int sm3_subsample_colsum_rows(int64_t rows, int C, int dtype);
+int sm3_subsample_colsum(int dtype, const void* x, void* y, float* colsum_partials, int N, int H, int W, int C, int stride,
+                         int views, void* stream);
 /* The join of a Bottleneck with a downsample branch in ONE pass (resnet.py:164-172: out = bn3(conv3); identity =
  * downsample(x) [conv + BatchNorm]; out += identity; relu):  y = [relu]( x*scale + shift + x2*scale2 + shift2 ),
  * x2 the pre-BatchNorm output of the downsample convolution, scale2/shift2 [views][C] from its sm3_bn_finalize.

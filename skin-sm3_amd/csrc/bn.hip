@@ -286,6 +286,68 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x, co
     }
 }
 
+// Input of a strided 1x1 convolution as a dense operand: y[n, oy, ox, :] = x[n, oy*stride, ox*stride, :] (y nullable) and the
+// per-block column sums of those rows, as bn_act_kernel's colsum (same thread layout, same view-independent row cut).
+template <typename T, int U>
+__global__ __launch_bounds__(256) void subsample_colsum_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                               float* __restrict__ colsum, int64_t rows, int C, int Hs,
+                                                               int Ws, int H, int W, int stride, FastDiv div_hw,
+                                                               FastDiv div_w, int tbx, int tby) {
+    constexpr int E = ElemTraits<T>::kPer16B;
+    __shared__ float scol[256 * 8];
+    const int tx = threadIdx.x % tbx, ty = threadIdx.x / tbx;
+    const int cv = blockIdx.x * tbx + tx;
+    const bool active = !(cv * E >= C || ty >= tby);
+    float cs[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) cs[e] = 0.f;
+    if (active) {
+        const int64_t r_lo = (int64_t)blockIdx.z * rows;  // view blockIdx.z: its own range of OUTPUT rows
+        const int64_t rstep = (int64_t)gridDim.y * tby;
+        auto src_row = [&](int64_t r) {  // output row (n, oy, ox) -> input row
+            const uint32_t g = (uint32_t)(r_lo + r);
+            const uint32_t n = fdiv(g, div_hw), rem = g - n * (uint32_t)(Hs * Ws);
+            const uint32_t oy = fdiv(rem, div_w), ox = rem - oy * (uint32_t)Ws;
+            return ((int64_t)n * H + (int64_t)oy * stride) * W + (int64_t)ox * stride;
+        };
+        int64_t r = (int64_t)blockIdx.y * tby + ty;
+        for (; r + (U - 1) * rstep < rows; r += U * rstep) {
+            uint4 xu[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) xu[u] = ldg16<false>(x + src_row(r + u * rstep) * C + (int64_t)cv * E);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (y) stg16<true>(y + (r_lo + r + u * rstep) * C + (int64_t)cv * E, xu[u]);
+                float q[E];
+                unpack16<T>(xu[u], q);
+#pragma unroll
+                for (int e = 0; e < E; ++e) cs[e] += q[e];
+            }
+        }
+        for (; r < rows; r += rstep) {
+            const uint4 xu = ldg16<false>(x + src_row(r) * C + (int64_t)cv * E);
+            if (y) stg16<true>(y + (r_lo + r) * C + (int64_t)cv * E, xu);
+            float q[E];
+            unpack16<T>(xu, q);
+#pragma unroll
+            for (int e = 0; e < E; ++e) cs[e] += q[e];
+        }
+    }
+    if constexpr (E <= 8) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) scol[threadIdx.x * E + e] = cs[e];
+    }
+    __syncthreads();
+    if (active && ty == 0) {
+        for (int j = 1; j < tby; ++j)
+#pragma unroll
+            for (int e = 0; e < E; ++e) cs[e] += scol[(j * tbx + tx) * E + e];
+        float* o = colsum + ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * C + (int64_t)cv * E;
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] = cs[e];
+    }
+}
+
 // phase 1 of backward: relu mask, optional dz write-back, partial sums of dz and dz*xhat
 template <typename T, int U, bool NT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y,
@@ -672,6 +734,35 @@ extern "C" int sm3_bn_act_colsum(int dtype, const void* x, const float* scale, c
     if (!colsum_partials) return SM3_EINVAL;
     return bn_act_impl(dtype, x, scale, shift, residual, nullptr, nullptr, relu, 0, y, relu_mask, rows, C, views, stream,
                        colsum_partials);
+}
+
+extern "C" int sm3_subsample_colsum_rows(int64_t rows, int C, int dtype) { return sm3_bn_act_colsum_rows(rows, C, dtype); }
+
+extern "C" int sm3_subsample_colsum(int dtype, const void* x, void* y, float* colsum_partials, int N, int H, int W, int C,
+                                    int stride, int views, void* stream) {
+    if (!x || !colsum_partials || N <= 0 || H <= 0 || W <= 0 || C <= 0 || stride < 1 || views < 1 || N % views)
+        return SM3_EINVAL;
+    if (!SM3_DTYPE_OK(dtype)) return SM3_EDTYPE;
+    const int E = dtype == SM3_F32 ? 4 : 8;
+    if (C % E) return SM3_EALIGN;
+    const int Hs = (H - 1) / stride + 1, Ws = (W - 1) / stride + 1;
+    const int64_t rows = (int64_t)(N / views) * Hs * Ws;  // output rows of ONE view
+    if ((int64_t)N * Hs * Ws > 0x7fffffffL) return SM3_EINVAL;
+    const RowWalk w = make_walk(rows, C / E, 8192, views < 2 ? 2 : views);  // as sm3_bn_act_colsum: view-independent cut
+    dim3 grid(w.gx, w.gy, views), block(256);
+    const FastDiv dhw = make_fastdiv((uint32_t)(Hs * Ws)), dw = make_fastdiv((uint32_t)Ws);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SM3_F32)
+        hipLaunchKernelGGL((subsample_colsum_kernel<float, 4>), grid, block, 0, st, (const float*)x, (float*)y, colsum_partials, rows,
+                           C, Hs, Ws, H, W, stride, dhw, dw, w.tbx, w.tby);
+    else if (dtype == SM3_BF16)
+        hipLaunchKernelGGL((subsample_colsum_kernel<bf16_t, 4>), grid, block, 0, st, (const bf16_t*)x, (bf16_t*)y, colsum_partials,
+                           rows, C, Hs, Ws, H, W, stride, dhw, dw, w.tbx, w.tby);
+    else
+        hipLaunchKernelGGL((subsample_colsum_kernel<f16_t, 4>), grid, block, 0, st, (const f16_t*)x, (f16_t*)y, colsum_partials,
+                           rows, C, Hs, Ws, H, W, stride, dhw, dw, w.tbx, w.tby);
+    SM3_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int sm3_bn_add_bn_act(int dtype, const void* x, const float* scale, const float* shift, const void* x2,

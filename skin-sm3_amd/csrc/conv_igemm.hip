@@ -40,7 +40,7 @@ namespace {
 template <typename T, int BM, int BN, int WM, int WN, int STAGES, int EPI, bool SEG = false>
 __global__ __launch_bounds__(WM* WN * 64, (EPI == 3 ? 4 : 2)) void conv_igemm_kernel(const ConvParams p) {  // EPI 3: 130 -> 128 registers, 4 workgroups per CU
     constexpr bool LEAN = EPI >= 1;
-    static_assert(!(SEG && EPI != 0 && EPI != 3) && !(SEG && STAGES > 2), "segments: data-gradient epilogues, 1 or 2 stages");
+    static_assert(!(SEG && EPI == 1) && !(SEG && STAGES > 2), "segments: data-gradient epilogues, 1 or 2 stages");
     constexpr int NT = WM * WN * 64;
     constexpr int RPP = NT / 8;  // rows covered per loader pass
     constexpr int AI = BM / RPP, BI = BN / RPP;
@@ -722,7 +722,9 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
     if (p.x1) {  // two K segments (16-bit types only: the exact-f32 parity mode never takes the linear BatchNorm backward)
         if constexpr (sizeof(T) == 2) {
             const bool one = p.nsteps_seg <= single_max;
-            if (lean) return one ? launch_conv_st<T, BM, BN, WM, WN, 1, 3, true>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, 3, true>(p, st);
+            if (lean && p.fz_partials)
+                return one ? launch_conv_st<T, BM, BN, WM, WN, 1, 3, true>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, 3, true>(p, st);
+            if (lean) return one ? launch_conv_st<T, BM, BN, WM, WN, 1, 2, true>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, 2, true>(p, st);
             return one ? launch_conv_st<T, BM, BN, WM, WN, 1, 0, true>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, 0, true>(p, st);
         } else {
             return SM3_EDTYPE;
@@ -855,7 +857,11 @@ static int conv_gather_gemm_impl(const sm3_conv_desc* d, const void* x, const vo
                            d->Wout == d->Wo && d->Ho == d->Hi && d->Wo == d->Wi;
         if (!plain || !seg->x1 || !seg->w1 || seg->Ci1 <= 0 || sz != 2 || ebn) return SM3_EINVAL;
         if ((seg->Ci1 * sz) % 128 != 0) return SM3_EALIGN;
-        const int nviews = (fuse && fuse->views > 1) ? 2 : 1;
+        const int nviews = ((fuse && fuse->views > 1) || seg->views > 1) ? 2 : 1;
+        if (!fuse && seg->views > 1) {
+            if (seg->views != 2 || (p.M % 2) || ((p.M / 2) % kBM)) return SM3_EALIGN;
+            p.fz_view_tiles = p.M / 2 / kBM;
+        }
         if (seg->w_view_stride < 0 || seg->w1_view_stride < 0) return SM3_EINVAL;
         const long x1b = (long)p.M * seg->Ci1 * sz;
         const long w0b = ((long)(nviews - 1) * seg->w_view_stride + (long)(d->Co - 1) * d->w_row_stride + d->Ci) * sz;
@@ -904,6 +910,12 @@ extern "C" int sm3_conv_dgrad_seg_bnfuse(const sm3_conv_desc* d, const void* x0,
                                          void* dz_out, const void* addend, const sm3_bn_bwd_fuse* fuse, void* stream) {
     if (!seg) return SM3_EINVAL;
     return conv_gather_gemm_impl(d, x0, w0, dz_out, addend, nullptr, fuse, stream, nullptr, seg);
+}
+
+extern "C" int sm3_conv_gather_gemm_seg(const sm3_conv_desc* d, const void* x0, const void* w0, const sm3_conv_seg* seg,
+                                        void* y, const void* addend, void* stream) {
+    if (!seg) return SM3_EINVAL;
+    return conv_gather_gemm_impl(d, x0, w0, y, addend, nullptr, nullptr, stream, nullptr, seg);
 }
 
 extern "C" int sm3_conv_bn_act_eval(const sm3_conv_desc* d, const void* x, const void* w, const float* scale,

@@ -34,7 +34,7 @@ class BnBwdFuse(C.Structure):
 
 class ConvSeg(C.Structure):
     _fields_ = [("x1", C.c_void_p), ("w1", C.c_void_p), ("Ci1", C.c_int32), ("w_view_stride", C.c_int64),
-                ("w1_view_stride", C.c_int64), ("col_bias", C.c_void_p)]
+                ("w1_view_stride", C.c_int64), ("col_bias", C.c_void_p), ("views", C.c_int32)]
 
 
 class BnApplySide(C.Structure):
@@ -59,6 +59,9 @@ SIGNATURES = {
     "sm3_conv_gather_gemm": [_DESC, _P, _P, _P, _P, _P, _P],
     "sm3_conv_dgrad_bnfuse": [_DESC, _P, _P, _P, _P, _P, _P],
     "sm3_conv_dgrad_seg_bnfuse": [_DESC, _P, _P, _P, _P, _P, _P, _P],
+    "sm3_conv_gather_gemm_seg": [_DESC, _P, _P, _P, _P, _P, _P],
+    "sm3_subsample_colsum_rows": [_L, _I, _I],
+    "sm3_subsample_colsum": [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "sm3_conv_wgrad_cat": [_DESC, _P, _P, _P, _P, _I, _P, _I, _L, _L, _P],
     "sm3_bn_act_colsum_rows": [_L, _I, _I],
     "sm3_conv_wgrad_slabs": [_DESC, _P, _P, _P, _I, _I, _P, _P],

@@ -292,6 +292,8 @@ class SM3Engine:
         # ... and, for the blocks without a downsample branch, the forward half of it: bn3's batch statistics from the
         # moments of conv3's input, bn3 + residual + ReLU inside conv3's epilogue -- conv3's output never reaches HBM
         self.linbn_fwd = _os.environ.get("SM3_LINBN_FWD", "1") != "0"
+        # ... and the downsample conv -> BatchNorm of a stage's first block in the backward pass
+        self.linbn_ds = _os.environ.get("SM3_LINBN_DS", "1") != "0"
 
     # ---- setup ---------------------------------------------------------------------------
     def _all_conv_units(self):
@@ -722,30 +724,51 @@ class SM3Engine:
         save.append(r)
         return y3, d.Ho, d.Wo
 
-    def conv3_backward_linbn(self, r3, r2, dz, bpart, prow, rd=None):
+    def _lin_unit_products(self, tag, cu, N, Hs, Ws, y_in, dz, V):
+        """P = dz^T y_in [V][C][Cin] of an expanding 1x1 conv unit over compact pixels: plain-store split-K slabs of the
+        weight-gradient kernel, summed in a fixed order."""
+        C, p = cu.Co, cu.Ci
+        slabs = self._slab_buf(C * p, V)
+        ns = ops.conv_wgrad_slabs(self._lin_conv_desc(self.dtype, N, Hs, Ws, p, C), y_in, dz, slabs, views=V)
+        P = self._work("linbn_P" + tag, V * C * p)
+        ops.linbn_moments(slabs, ns, C * p, P, views=V)
+        return P
+
+    def _lin_unit_finish(self, tag, cu, P, G, Tm, s, coef, V):
+        """Banks diag(a) W / -diag(b) W, the constant term, -H, and the unit's weight gradient.  Returns (wa, -H, const)."""
+        C, p = cu.Co, cu.Ci
+        wa = self._work("linbn_wa" + tag, V * p * C, self.tdt)
+        wbn = self._work("linbn_wbn" + tag, V * p * C, self.tdt)
+        cconst = self._work("linbn_const" + tag, V * p)
+        ops.linbn_banks(self.dtype, cu.w_dgrad, coef, wa, wbn, cconst, C, p, V)
+        Hn = self._work("linbn_H" + tag, V * p * p, self.tdt)
+        ops.linbn_post(self.dtype, wbn, cu.w_dgrad, Hn, P, G, Tm, s, coef, self._g(cu.name + ".weight"), C, p, V)
+        return wa[: V * p * C], Hn[: V * p * p], cconst[: V * p]
+
+    def conv3_backward_linbn(self, r3, r2, dz, bpart, prow, rd=None, lin_d=False):
         """Backward of conv3 -> bn3 BY LINEARITY (csrc/linbn.hip; reference: the autograd backward of
         src/models/resnet.py:162-163).  dz: the masked gradient of the block output [M, C]; bpart: its partial rows
         [V][prow][2][C] (only sum(dz) is used) as left by the producing data-gradient launch.
         No pass over bn3's input or output: the weight gradient runs on dz itself, the data gradient is one GEMM over the
         two K segments [dz | y2]; the moments of y2 (r2.colsum, r2.gram) and W G (r3.Tm) came with the forward pass.
         Accumulates d(conv3.weight), d(bn3.weight/bias).
-        rd: the downsample unit of the block, whose BatchNorm received the same dz (resnet.py:164-172): its two-pass
-        backward runs alongside -- statistics in the SAME SyncBN exchange as bn3's, apply pass in place over dz once the
-        GEMMs above have read it.
-        Returns (dz2 = masked gradient of bn2's output, bn2's phase-1 partial rows per view, d(downsample conv output))."""
+        rd: the downsample unit of the block, whose BatchNorm received the same dz (resnet.py:164-172), with its statistics
+        in the SAME SyncBN exchange as bn3's.  lin_d: it goes by linearity too -- the moments of the (strided) block input
+        are taken here, its weight gradient and BatchNorm parameter gradients are accumulated, and the ingredients of its
+        data gradient are returned for the caller to launch (sm3_conv_gather_gemm_seg: it joins conv1's data gradient);
+        otherwise its two-pass backward runs alongside, the apply pass in place over dz once the GEMMs have read it.
+        Returns (dz2 = masked gradient of bn2's output, bn2's phase-1 partial rows per view,
+                 d(downsample conv output) | dict(x1, wa, hn, const) | None)."""
         cu, bu = r3.cu, r3.bu
         C, p, V = cu.Co, cu.Ci, r3.V
         M = r3.N * r3.Ho * r3.Wo
         rows = M // V
         y2 = r3.x_in
-        G, s = r2.gram, r2.colsum
         aff = bu.affine
         gamma = self._p(bu.name + ".weight") if aff else None
-        # 1. P = dz^T y2 [V][C][p]: the weight-gradient kernel on dz itself, plain-store split-K slabs summed in order
-        slabs = self._slab_buf(C * p, V)
-        ns = ops.conv_wgrad_slabs(cu.wgrad_desc(self.dtype, r3.N, r3.H, r3.W), y2, dz, slabs, views=V)
-        P = self._work("linbn_P", V * C * p)
-        ops.linbn_moments(slabs, ns, C * p, P, views=V)
+        local = rows if self.stat_sync is None else 0  # single rank: the local sums are the global ones
+        # 1. P = dz^T y2 [V][C][p]: the weight-gradient kernel on dz itself
+        P = self._lin_unit_products("", cu, r3.N, r3.Ho, r3.Wo, y2, dz, V)
         # 2. local sums [bn3 | downsample][V][2C]: sum(dz) from the fused partial rows, sum(dz * xhat) from P; d(gamma),
         #    d(beta); single rank: the coefficients (a, b, m1, mu) too
         n = V * 2 * C
@@ -755,8 +778,32 @@ class SM3Engine:
         ws, groups = ops.bn_stats_reduce(bpart, prow, C, None, views=V)  # stage A; stage B runs inside linbn_stats
         ops.linbn_stats(self.dtype, P, cu.w_fwd, r3.mean, r3.invstd, gamma, ws, groups, lsums,
                         self._g(bu.name + ".weight") if aff else None, self._g(bu.name + ".bias") if aff else None,
-                        rows if self.stat_sync is None else 0, coef, C, p, V)
-        if rd is not None:
+                        local, coef, C, p, V)
+        if lin_d:
+            # the downsample unit: moments of its (strided) input, taken now; same dz, same sum(dz)
+            cd, bd = rd.cu, rd.bu
+            Cin = cd.Ci
+            affd = bd.affine
+            gamma_d = self._p(bd.name + ".weight") if affd else None
+            crow = ops.subsample_colsum_rows(self.dtype, rows, Cin)
+            csd = self._work("linbn_cs", V * crow * Cin)
+            if cd.stride == 1:
+                in_s = rd.x_in
+                ops.subsample_colsum(self.dtype, rd.x_in, None, csd, rd.N, rd.H, rd.W, Cin, 1, V)
+            else:
+                in_s = torch.empty(M, Cin, dtype=self.tdt, device=dz.device)
+                ops.subsample_colsum(self.dtype, rd.x_in, in_s, csd, rd.N, rd.H, rd.W, Cin, cd.stride, V)
+            slabs = self._slab_buf(Cin * Cin, V)
+            ns = ops.conv_wgrad_slabs(self._lin_conv_desc(self.dtype, rd.N, rd.Ho, rd.Wo, Cin, Cin), in_s, in_s, slabs, views=V)
+            Gd = self._work("linbn_Gd", V * Cin * Cin)
+            sd = self._work("linbn_sd", V * Cin, torch.float64)
+            ops.linbn_moments(slabs, ns, Cin * Cin, Gd, views=V, colsum=csd, colsum_rows=crow, s_out=sd, p=Cin)
+            Pd = self._lin_unit_products("d", cd, rd.N, rd.Ho, rd.Wo, in_s, dz, V)
+            coef_d = self._work("linbn_coef_d", V * 4 * C)
+            ops.linbn_stats(self.dtype, Pd, cd.w_fwd, rd.mean, rd.invstd, gamma_d, ws, groups, lsums[n: 2 * n],
+                            self._g(bd.name + ".weight") if affd else None, self._g(bd.name + ".bias") if affd else None,
+                            local, coef_d, C, Cin, V)
+        elif rd is not None:
             prow_d = ops.bn_bwd_partial_rows(rows, C)
             dpart = self._work("partials_d", V * prow_d * 2 * C)
             ops.bn_bwd_reduce(self.dtype, dz, None, rd.xo, rd.mean, rd.invstd, None, rows, C, dpart, views=V)
@@ -768,32 +815,32 @@ class SM3Engine:
             self.stat_sync(gsums[:tot])  # one all-reduce for the two BatchNorms (and both views)
             count = rows * self.world_size
             ops.linbn_coef(gsums[:n], count, gamma, r3.mean, r3.invstd, coef, C, V)
-        # 3. diag(a) W and -diag(b) W in data-gradient order, the constant term
-        wa = self._work("linbn_wa", V * p * C, self.tdt)
-        wbn = self._work("linbn_wbn", V * p * C, self.tdt)
-        cconst = self._work("linbn_const", V * p)
-        ops.linbn_banks(self.dtype, cu.w_dgrad, coef, wa, wbn, cconst, C, p, V)
-        # 4. -H_v = (-diag(b_v) W)^T W [V][p][p], and d(conv3.weight) += diag(a)(P - m1 s^T) - diag(b)(W G - mu s^T)
-        Hn = self._work("linbn_H", V * p * p, self.tdt)
-        ops.linbn_post(self.dtype, wbn, cu.w_dgrad, Hn, P, G, r3.Tm, s, coef, self._g(cu.name + ".weight"), C, p, V)
-        # 5. data gradient [dz | y2] x [diag(a) W ; -H]^T + const, with bn2's ReLU mask and phase 1 in the epilogue
+            if lin_d:
+                ops.linbn_coef(gsums[n: 2 * n], count, gamma_d, rd.mean, rd.invstd, coef_d, C, V)
+        # 3. diag(a) W and -diag(b) W in data-gradient order, the constant term, -H; d(conv.weight) += diag(a)(P - m1 s^T) -
+        #    diag(b)(W G - mu s^T)
+        wa, Hn, cconst = self._lin_unit_finish("", cu, P, r2.gram, r3.Tm, r2.colsum, coef, V)
+        ds = None
+        if lin_d:
+            wa_d, Hn_d, cconst_d = self._lin_unit_finish("d", cd, Pd, Gd, None, sd, coef_d, V)
+            ds = {"x1": in_s, "wa": wa_d, "hn": Hn_d, "const": cconst_d}
+        # 4. data gradient [dz | y2] x [diag(a) W ; -H]^T + const, with bn2's ReLU mask and phase 1 in the epilogue
         descs, full = cu.dgrad_descs(self.dtype, r3.N, r3.H, r3.W)
         dd = descs[0]
         dz2 = torch.empty(M, p, dtype=self.tdt, device=dz.device)
         total = ops.conv_partial_rows(dd)
         part = self._work("fz_partials", total * 2 * p)
-        nrows = ops.conv_dgrad_seg_bnfuse(dd, dz, wa[: V * p * C], y2, Hn[: V * p * p], cconst[: V * p], dz2,
+        nrows = ops.conv_dgrad_seg_bnfuse(dd, dz, wa, y2, Hn, cconst, dz2,
                                           r2.mask if r2.relu else None, None if r2.linbn else r2.xo, r2.mean, r2.invstd,
                                           part, 0, views=V, row_offset_view1=total // V, w_view_stride=p * C,
                                           w1_view_stride=p * p)
-        dxd = None
-        if rd is not None:  # the downsample BatchNorm's apply pass, in place over dz (its last reader was launch 5)
+        if rd is not None and not lin_d:  # the downsample BatchNorm's apply pass, in place over dz (its last reader: 4.)
             affd = rd.bu.affine
             ops.bn_bwd_apply(self.dtype, dz, rd.xo, rd.mean, rd.invstd, self._p(rd.bu.name + ".weight") if affd else None,
                              gsums[n: 2 * n], count, lsums[n: 2 * n], self._g(rd.bu.name + ".weight") if affd else None,
                              self._g(rd.bu.name + ".bias") if affd else None, dz, rows, C, views=V)
-            dxd = dz
-        return dz2, nrows // V, dxd
+            ds = dz
+        return dz2, nrows // V, ds
 
     def _wgrad(self, cu, r, dxo):
         """Weight gradient on the lane's side stream: nothing on the critical path (data gradient -> BN backward ->
@@ -1005,7 +1052,11 @@ class SM3Engine:
                                       mask=r3.mask, views=V3)
                 else:
                     prow, bpart = fr, self._ws[(self._lane, "fz_partials")]
-                dy2, fr2, dxd = self.conv3_backward_linbn(r3, r2, dcur, bpart, prow, rd=rd)
+                prev_r3 = ctx["blocks"][bi - 1][-1] if bi > 0 else None
+                lin_d = (rd is not None and self.linbn_ds and rd.cu.Ci % 64 == 0 and not rd.frozen_stats and
+                         (rd.cu.stride == 1 or (prev_r3 is not None and self.fuse_bn_bwd and rd.cu.stride == 2 and
+                                                (prev_r3.V == 1 or (r1.N * r1.H * r1.W) % 256 == 0))))
+                dy2, fr2, dxd = self.conv3_backward_linbn(r3, r2, dcur, bpart, prow, rd=rd, lin_d=lin_d)
                 dz = None if rd is not None else dcur
             else:
                 if rd is not None:
@@ -1019,7 +1070,25 @@ class SM3Engine:
             dy1, fr1 = self.conv_backward(r2, dx2, fuse=r1)
             del dx2, dy2
             dx1, _ = self.bn_backward(r1, dy1, keep_dz=False, fused_rows=fr1)
-            if rd is not None:
+            if rd is not None and isinstance(dxd, dict):
+                # the downsample unit went by linearity: its data gradient is the two-segment product of dz (= dcur) and the
+                # compact block input, joined with conv1's data gradient as the two-pass form's is
+                prev_r3 = ctx["blocks"][bi - 1][-1] if bi > 0 else None
+                cd = rd.cu
+                Vd = r3.V
+                Cd, Cin = cd.Co, cd.Ci
+                dd = cd.compact_dgrad_desc(self.dtype, rd.N, rd.Ho, rd.Wo)
+                if cd.stride == 2:
+                    dsp = torch.empty(rd.N * rd.Ho * rd.Wo, Cin, dtype=self.tdt, device=dcur.device)
+                    ops.conv_gemm_seg(dd, dcur, dxd["wa"], dxd["x1"], dxd["hn"], dxd["const"], dsp, None, views=Vd,
+                                      w_view_stride=Cin * Cd, w1_view_stride=Cin * Cin)
+                    din, fr = self.conv_backward(r1, dx1, addend=dsp, fuse=prev_r3, addend_sparse=(rd.Ho, rd.Wo))
+                else:
+                    din, _ = self.conv_backward(r1, dx1)
+                    ops.conv_gemm_seg(dd, dcur, dxd["wa"], dxd["x1"], dxd["hn"], dxd["const"], din, din, views=Vd,
+                                      w_view_stride=Cin * Cd, w1_view_stride=Cin * Cin)
+                    fr = None
+            elif rd is not None:
                 prev_r3 = ctx["blocks"][bi - 1][-1] if bi > 0 else None
                 cd = rd.cu
                 V = prev_r3.V if prev_r3 is not None else 1

@@ -315,6 +315,44 @@ def conv_dgrad_seg_bnfuse(desc, x0, w0, x1, w1, col_bias, dz_out, mask, bn_x, me
     return conv_partial_rows(desc)
 
 
+def conv_gemm_seg(desc, x0, w0, x1, w1, col_bias, y, addend=None, views=1, w_view_stride=0, w1_view_stride=0):
+    """y = x0 w0^T + x1 w1^T + col_bias (+ addend, which may be y itself) with per-view banks (sm3_conv_gather_gemm_seg):
+    the data gradient of a downsample conv -> BatchNorm pair by linearity."""
+    tdt = TORCH_DTYPE[desc.dtype]
+    for t, n in ((x0, "x0"), (w0, "w0"), (x1, "x1"), (w1, "w1"), (y, "y"), (addend, "addend")):
+        _chk(t, tdt, n)
+    _chk(col_bias, torch.float32, "col_bias")
+    if desc.dtype == SM3_F32:
+        raise ValueError("conv_gemm_seg: 16-bit activation types only")
+    M = desc.N * desc.Ho * desc.Wo
+    if desc.ntaps != 1 or desc.Hout != desc.Ho or desc.Wout != desc.Wo or desc.Hi != desc.Ho or desc.Wi != desc.Wo:
+        raise ValueError("conv_gemm_seg: 1x1 / stride-1 descriptor expected")
+    if x0.numel() != M * desc.Ci or x1.numel() % M or y.numel() != M * desc.Co or \
+            (addend is not None and addend.numel() != y.numel()):
+        raise ValueError("conv_gemm_seg: operand size does not match descriptor")
+    Ci1 = x1.numel() // M
+    if Ci1 % K_CHUNK[desc.dtype] or desc.Ci % K_CHUNK[desc.dtype]:
+        raise ValueError("conv_gemm_seg: channel counts must be multiples of the K chunk")
+    if w0.numel() < (views - 1) * w_view_stride + desc.Co * desc.w_row_stride or \
+            w1.numel() < (views - 1) * w1_view_stride + desc.Co * Ci1 or \
+            (col_bias is not None and col_bias.numel() < views * desc.Co):
+        raise ValueError("conv_gemm_seg: weight bank / col_bias too small")
+    if views > 1 and (views != 2 or M % 256):
+        raise ValueError("two views need a multiple of 128 rows each")
+    sg = _lib.ConvSeg()
+    sg.x1, sg.w1, sg.Ci1 = x1.data_ptr(), w1.data_ptr(), Ci1
+    sg.w_view_stride, sg.w1_view_stride = w_view_stride, w1_view_stride
+    sg.col_bias = col_bias.data_ptr() if col_bias is not None else None
+    sg.views = views
+    sz = _sz(desc.dtype)
+    tag = _conv_tag(desc)
+    if _PROFILER is not None and getattr(_PROFILER, "detail", False):
+        tag += f"|M{M}_K{desc.Ci}+{Ci1}_N{desc.Co}_seg"
+    with _prof(tag, 2.0 * M * desc.Co * desc.Ci, sz * (x0.numel() + x1.numel() + M * desc.Co * (1 + (addend is not None)))):
+        check(_lib.load().sm3_conv_gather_gemm_seg(C.byref(desc), _ptr(x0), _ptr(w0), C.byref(sg), _ptr(y), _ptr(addend),
+                                                   _stream()), "sm3_conv_gather_gemm_seg")
+
+
 def conv_bn_act_eval(desc, x, w, scale, shift, residual, relu, y):
     """conv + eval-mode BN (+residual) (+ReLU) in one launch (sm3_conv_bn_act_eval)."""
     tdt = TORCH_DTYPE[desc.dtype]
@@ -613,6 +651,25 @@ def bn_eval_scale_shift(gamma, beta, running_mean, running_var, eps, Cn, scale, 
         _chk(t, torch.float32)
     check(_lib.load().sm3_bn_eval_scale_shift(_ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), eps,
                                               Cn, _ptr(scale), _ptr(shift), _stream()), "sm3_bn_eval_scale_shift")
+
+
+def subsample_colsum_rows(dtype, rows, Cn):
+    return _lib.load().sm3_subsample_colsum_rows(rows, Cn, dtype)
+
+
+def subsample_colsum(dtype, x, y, colsum, N, H, W, Cn, stride, views=1):
+    """Column-sum partial rows of x [N, H, W, C] at the stride-th pixels (and, y given, those pixels as a compact tensor):
+    sm3_subsample_colsum."""
+    tdt = TORCH_DTYPE[dtype]
+    _chk(x, tdt, "x"); _chk(y, tdt, "y"); _chk(colsum, torch.float32, "colsum")
+    Hs, Ws = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if x.numel() != N * H * W * Cn or (y is not None and y.numel() != N * Hs * Ws * Cn) or N % views:
+        raise ValueError("subsample_colsum: size mismatch")
+    if colsum.numel() < views * subsample_colsum_rows(dtype, N // views * Hs * Ws, Cn) * Cn:
+        raise ValueError("subsample_colsum: colsum too small")
+    with _prof("subsample", 0.0, _sz(dtype) * N * Hs * Ws * Cn * (2 if y is not None else 1)):
+        check(_lib.load().sm3_subsample_colsum(dtype, _ptr(x), _ptr(y), _ptr(colsum), N, H, W, Cn, stride, views, _stream()),
+              "sm3_subsample_colsum")
 
 
 def bn_act_colsum_rows(dtype, rows, Cn):

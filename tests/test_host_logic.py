@@ -87,20 +87,22 @@ def test_engine_dry_run_sequences_and_bucket_schedule(model, linbn):
     # 53 convs x 4 encoder passes + 3 linears x (2 in-modal + 4 cross) projector passes
     assert calls["sm3_bn_finalize"] == 53 * 4 + 3 * 6 == 230  # 212 BN2d + 18 BN1d per step
     nlin = 64 if linbn else 0  # 16 Bottlenecks x 4 encoder passes: conv3 -> bn3 units whose backward goes by linearity
-    assert calls["sm3_conv_wgrad"] == 230 - 4 - nlin and calls["sm3_stem_wgrad_bn"] == 4  # bf16: direct stem (csrc/stem.hip)
-    for name in ("sm3_linbn_stats", "sm3_linbn_banks", "sm3_linbn_post", "sm3_conv_dgrad_seg_bnfuse", "sm3_bn_act_colsum"):
-        assert calls[name] == nlin, name
-    # forward: Gram matrix of conv3's input; backward: dz^T y2 per view -- plain-store split-K slabs, summed in a fixed order
-    assert calls["sm3_conv_wgrad_slabs"] == 2 * nlin and calls["sm3_linbn_moments"] == 2 * nlin
+    nds = 16 if linbn else 0   # ... and the 4 downsample conv -> BatchNorm units of every pass
+    assert calls["sm3_conv_wgrad"] == 230 - 4 - nlin - nds and calls["sm3_stem_wgrad_bn"] == 4  # bf16: direct stem (csrc/stem.hip)
+    for name in ("sm3_linbn_stats", "sm3_linbn_banks", "sm3_linbn_post"):
+        assert calls[name] == nlin + nds, name
+    assert calls["sm3_conv_dgrad_seg_bnfuse"] == nlin and calls["sm3_bn_act_colsum"] == nlin
+    assert calls["sm3_conv_gather_gemm_seg"] == nds and calls["sm3_subsample_colsum"] == nds
+    # Gram matrix of the unit's input and dz^T input per view -- plain-store split-K slabs, summed in a fixed order
+    assert calls["sm3_conv_wgrad_slabs"] == 2 * (nlin + nds) and calls["sm3_linbn_moments"] == 2 * (nlin + nds)
     assert calls["sm3_conv_wgrad_cat"] == 0
     # the 12 blocks without a downsample branch also run conv3 -> bn3 -> +identity -> ReLU as ONE launch, bn3's statistics
     # from the moments of conv3's input (no join pass, no pre-BatchNorm tensor)
     nfused = 48 if linbn else 0
     assert calls["sm3_linbn_fwd_stats"] == nfused and calls["sm3_conv_bn_act_fused"] == nfused
     if linbn:
-        # no backward-apply pass for bn3; the downsample BatchNorm of a block keeps its own (the stem's is fused into its
-        # weight gradient)
-        assert calls["sm3_bn_bwd_apply2"] == 0 and calls["sm3_bn_bwd_apply"] == 230 - 4 - 64
+        # no backward-apply pass for bn3 nor for the downsample BatchNorms (the stem's is fused into its weight gradient)
+        assert calls["sm3_bn_bwd_apply2"] == 0 and calls["sm3_bn_bwd_apply"] == 230 - 4 - 64 - 16
     else:
         # every BatchNorm gets its backward apply: the bn3 / downsample pair of a downsample block in one dual launch
         assert calls["sm3_bn_bwd_apply2"] == 4 * 4 and calls["sm3_bn_bwd_apply"] == 230 - 2 * 16 - 4

@@ -385,3 +385,64 @@ def test_encoder_with_and_without_batchnorm_by_linearity(dt, views):
         if b > 2.0 * a + 2e-2:
             worse.append((name, a, b))
     assert not worse, worse[:8]
+
+
+@pytest.mark.parametrize("dt", DTS + [torch.float32], ids=IDS + ["f32"])
+@pytest.mark.parametrize("case", [(2, 4, 14, 14, 256, 2), (1, 6, 9, 7, 64, 2), (2, 2, 8, 8, 512, 1), (1, 3, 5, 11, 128, 1)])
+def test_subsample_colsum(case, dt):
+    """sm3_subsample_colsum: the stride-th pixels of an NHWC map as a compact tensor + the column sums of exactly those rows
+    (partial rows, view-independent cut)."""
+    ops = _ops()
+    V, Nv, H, W, C, stride = case
+    N = V * Nv
+    g = torch.Generator().manual_seed(H * W + C)
+    x = torch.randn(N, H, W, C, generator=g).to(dt)
+    code = ops.dtype_code(dt)
+    Hs, Ws = (H - 1) // stride + 1, (W - 1) // stride + 1
+    want = x[:, ::stride, ::stride, :].contiguous()
+    rows = Nv * Hs * Ws
+    crow = ops.subsample_colsum_rows(code, rows, C)
+    cs = torch.full((V, crow, C), float("nan"), device=dev())
+    y = torch.empty(N, Hs, Ws, C, dtype=dt, device=dev()) if stride > 1 else None
+    ops.subsample_colsum(code, x.to(dev()), y, cs, N, H, W, C, stride, views=V)
+    torch.cuda.synchronize()
+    if y is not None:
+        assert torch.equal(y.cpu(), want)
+    ref = want.double().reshape(V, rows, C).sum(1)
+    assert torch.allclose(cs.double().sum(1).cpu(), ref, rtol=1e-5, atol=1e-3)
+    s = torch.empty(V, C, dtype=torch.float64, device=dev())
+    out = torch.empty(V, 4, device=dev())
+    ops.linbn_moments(torch.zeros(V * 4, device=dev()), 1, 4, out, views=V, colsum=cs, colsum_rows=crow, s_out=s, p=C)
+    torch.cuda.synchronize()
+    assert torch.allclose(s.cpu(), ref, rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("dt", DTS, ids=IDS)
+@pytest.mark.parametrize("addend", [False, True])
+@pytest.mark.parametrize("case", [(1, 640, 256, 64), (2, 512, 512, 256), (2, 128, 2048, 1024)])
+def test_two_segment_gemm_without_a_fused_batchnorm(case, addend, dt):
+    """sm3_conv_gather_gemm_seg: y = x0 w0^T + x1 w1^T + col_bias (+ addend, in place) with per-view banks -- the data
+    gradient of the downsample conv -> BatchNorm pair."""
+    ops = _ops()
+    V, Mv, C, p = case
+    M = V * Mv
+    g = torch.Generator().manual_seed(M + C + p + 1)
+    x0 = torch.randn(M, C, generator=g).to(dt)
+    x1 = torch.randn(M, p, generator=g).to(dt)
+    w0 = (torch.randn(V, p, C, generator=g) / math.sqrt(C)).to(dt)
+    w1 = (torch.randn(V, p, p, generator=g) / math.sqrt(p)).to(dt)
+    bias = torch.randn(V, p, generator=g)
+    add = torch.randn(M, p, generator=g).to(dt)
+    code = ops.dtype_code(dt)
+    d = ops.fwd_desc(code, V, Mv, 1, C, p, 1, 1, 0)
+    y = add.clone().to(dev()) if addend else torch.empty(M, p, dtype=dt, device=dev())
+    ops.conv_gemm_seg(d, x0.to(dev()), w0.to(dev()), x1.to(dev()), w1.to(dev()), bias.to(dev()), y, y if addend else None,
+                      views=V, w_view_stride=p * C, w1_view_stride=p * p)
+    torch.cuda.synchronize()
+    for v in range(V):
+        sl = slice(v * Mv, (v + 1) * Mv)
+        ref = x0[sl].double() @ w0[v].double().t() + x1[sl].double() @ w1[v].double().t() + bias[v].double()
+        if addend:
+            ref = ref + add[sl].double()
+        sc = ref.abs().max().item()
+        assert (y[sl].double().cpu() - ref).abs().max().item() < 1.5 * tol(dt) * sc
