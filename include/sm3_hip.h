@@ -121,6 +121,12 @@ int sm3_conv_dgrad_seg_bnfuse(const sm3_conv_desc* d, const void* x0, const void
  * gradient that the block's conv1 data gradient then takes as its sparse addend). */
 int sm3_conv_gather_gemm_seg(const sm3_conv_desc* d, const void* x0, const void* w0, const sm3_conv_seg* seg, void* y,
                              const void* addend, void* stream);
+/* ... and with a ReLU (+ its bits) on the sum: y = relu?(x0 w0^T + x1 w1^T + col_bias).  With the two BatchNorm scales
+ * folded into the banks and the shifts into col_bias (sm3_linbn_scale_banks) this is the WHOLE join of a Bottleneck that has
+ * a downsample branch -- conv3, bn3, the 1x1 downsample convolution, its BatchNorm, the add and the ReLU
+ * (resnet.py:162-172) -- in one launch, neither pre-BatchNorm tensor stored. */
+int sm3_conv_seg_act(const sm3_conv_desc* d, const void* x0, const void* w0, const sm3_conv_seg* seg, int relu, void* y,
+                     uint8_t* relu_mask, void* stream);
 
 /* Inference: conv + eval-mode BatchNorm (+ residual) (+ ReLU) in one launch,
  *   y = relu?( conv(x, w) * scale[co] + shift[co] (+ residual) ),
@@ -286,6 +292,12 @@ int sm3_linbn_coef(const double* global_sums, double count, const float* gamma, 
  * col_const [views][p] = (b mu - a m1) W, summed over the rounded products. */
 int sm3_linbn_banks(int dtype, const void* w_dgrad, const float* coef, void* wa, void* wbn, float* col_const, int C, int p,
                     int views, void* stream);
+/* out3[v][c][:] = scale3[v][c] w3[c][:] ([C][K3] banks), outd[v][c][:] = scaled[v][c] wd[c][:] ([C][Kd]), and
+ * bias[v][c] = shift3[v][c] + shiftd[v][c]: what sm3_conv_seg_act needs to run conv3 + bn3 + downsample conv + its BatchNorm
+ * + add + ReLU as one two-segment GEMM. */
+int sm3_linbn_scale_banks(int dtype, const void* w3, int K3, const float* scale3, const float* shift3, void* out3,
+                          const void* wd, int Kd, const float* scaled, const float* shiftd, void* outd, float* bias, int C,
+                          int views, void* stream);
 /* One launch of 32 x 32 MFMA tiles:  hn [views][p][p] (dtype) = wbn_v w_dgrad^T = -H_v, and
  * dw[C][p] += sum_v diag(a_v)(P_v - m1_v s_v^T) - diag(b_v)(W G_v - mu_v s_v^T), W G_v from Tm (sm3_linbn_fwd_stats) or,
  * Tm NULL, recomputed from G.  C % 128 == 0, p % 32 == 0. */

@@ -387,7 +387,8 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI == 3 ? 4 : 2)) void conv_igemm_ke
             }
             return;
         } else {
-            const bool late_relu = (p.ep_scale != nullptr || p.ep_rv != nullptr) && p.ep_relu && (p.addend || p.ep_mask);
+            const bool epl2 = p.ep_scale != nullptr || p.ep_rv != nullptr;
+            const bool late_relu = p.ep_relu && !(epl2 && !p.addend && !p.ep_mask);  // i.e. not applied before the staging
             float f_mu[8], f_is[8], f_s1[8], f_s2[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -627,7 +628,7 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI == 3 ? 4 : 2)) void conv_igemm_ke
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) v[e] += a[e];
             }
-            if (ep && p.ep_relu) {
+            if (p.ep_relu) {
                 if (p.ep_mask) {  // what the backward pass needs of the output: one bit per element
                     unsigned m = 0;
 #pragma unroll
@@ -855,7 +856,7 @@ static int conv_gather_gemm_impl(const sm3_conv_desc* d, const void* x, const vo
         const bool plain = d->ntaps == 1 && d->sy == 1 && d->sx == 1 && d->dy[0] == 0 && d->dx[0] == 0 && d->wtap[0] == 0 &&
                            d->osy == 1 && d->osx == 1 && d->ooy == 0 && d->oox == 0 && d->Hout == d->Ho &&
                            d->Wout == d->Wo && d->Ho == d->Hi && d->Wo == d->Wi;
-        if (!plain || !seg->x1 || !seg->w1 || seg->Ci1 <= 0 || sz != 2 || ebn) return SM3_EINVAL;
+        if (!plain || !seg->x1 || !seg->w1 || seg->Ci1 <= 0 || sz != 2 || (ebn && (ebn->scale || ebn->rv))) return SM3_EINVAL;
         if ((seg->Ci1 * sz) % 128 != 0) return SM3_EALIGN;
         const int nviews = ((fuse && fuse->views > 1) || seg->views > 1) ? 2 : 1;
         if (!fuse && seg->views > 1) {
@@ -916,6 +917,15 @@ extern "C" int sm3_conv_gather_gemm_seg(const sm3_conv_desc* d, const void* x0, 
                                         void* y, const void* addend, void* stream) {
     if (!seg) return SM3_EINVAL;
     return conv_gather_gemm_impl(d, x0, w0, y, addend, nullptr, nullptr, stream, nullptr, seg);
+}
+
+extern "C" int sm3_conv_seg_act(const sm3_conv_desc* d, const void* x0, const void* w0, const sm3_conv_seg* seg, int relu,
+                                void* y, uint8_t* relu_mask, void* stream) {
+    if (!seg || (relu_mask && !relu)) return SM3_EINVAL;
+    EvalBn e{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, relu};
+    e.mask = relu_mask;
+    e.views = seg->views > 1 ? seg->views : 1;
+    return conv_gather_gemm_impl(d, x0, w0, y, nullptr, nullptr, nullptr, stream, &e, seg);
 }
 
 extern "C" int sm3_conv_bn_act_eval(const sm3_conv_desc* d, const void* x, const void* w, const float* scale,

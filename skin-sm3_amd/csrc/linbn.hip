@@ -236,6 +236,33 @@ __global__ __launch_bounds__(256) void linbn_banks_kernel(const T* __restrict__ 
     if (threadIdx.x == 0) col_const[(long)v * p + ci] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// ---- sm3_linbn_scale_banks ------------------------------------------------------------------------------------------
+// Forward of a Bottleneck's join with a downsample branch in ONE two-segment GEMM: the two BatchNorm scales go into the
+// filter banks, out3[v][c][:] = T(scale3[v][c] w3[c][:]), outd[v][c][:] = T(scaled[v][c] wd[c][:]), and the two shifts add
+// up to the GEMM's column bias.  grid (C, views).
+template <typename T>
+__global__ __launch_bounds__(256) void linbn_scale_banks_kernel(const T* __restrict__ w3, int K3, const float* __restrict__ sc3,
+                                                                T* __restrict__ out3, const T* __restrict__ wd, int Kd,
+                                                                const float* __restrict__ scd, T* __restrict__ outd,
+                                                                const float* __restrict__ sh3, const float* __restrict__ shd,
+                                                                float* __restrict__ bias, int C) {
+    const int c = blockIdx.x, v = blockIdx.y;
+    const float a = sc3[(long)v * C + c], b = scd[(long)v * C + c];
+    for (int k0 = threadIdx.x * 8; k0 < K3 + Kd; k0 += 256 * 8) {
+        const bool first = k0 < K3;
+        const int k = first ? k0 : k0 - K3;
+        const T* src = first ? w3 + (long)c * K3 + k : wd + (long)c * Kd + k;
+        T* dst = first ? out3 + ((long)v * C + c) * K3 + k : outd + ((long)v * C + c) * Kd + k;
+        float f[8];
+        unpack16<T>(*reinterpret_cast<const uint4*>(src), f);
+        const float q = first ? a : b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] *= q;
+        *reinterpret_cast<uint4*>(dst) = pack16<T>(f);
+    }
+    if (threadIdx.x == 0) bias[(long)v * C + c] = sh3[(long)v * C + c] + shd[(long)v * C + c];
+}
+
 // ---- sm3_linbn_post -------------------------------------------------------------------------------------------------
 // 32 x 32 output tiles, one wave each, no LDS:
 //   tiles [0, views (p/32)^2):  hn[v][k][ci] = sum_co wbn_v[k][co] wd[ci][co] = -H_v          (16-bit MFMA, K = C)
@@ -392,6 +419,24 @@ extern "C" int sm3_linbn_banks(int dtype, const void* w_dgrad, const float* coef
     else
         hipLaunchKernelGGL(linbn_banks_kernel<f16_t>, dim3(p, views), dim3(256), 0, st, (const f16_t*)w_dgrad,
                            (const float4*)coef, (f16_t*)wa, (f16_t*)wbn, col_const, C, p);
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_linbn_scale_banks(int dtype, const void* w3, int K3, const float* scale3, const float* shift3, void* out3,
+                                     const void* wd, int Kd, const float* scaled, const float* shiftd, void* outd,
+                                     float* bias, int C, int views, void* stream) {
+    if (!w3 || !scale3 || !shift3 || !out3 || !wd || !scaled || !shiftd || !outd || !bias) return SM3_EINVAL;
+    if (C <= 0 || K3 <= 0 || Kd <= 0 || views < 1) return SM3_EINVAL;
+    if (!lin16(dtype)) return SM3_EDTYPE;
+    if (K3 % 8 || Kd % 8) return SM3_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SM3_BF16)
+        hipLaunchKernelGGL(linbn_scale_banks_kernel<bf16_t>, dim3(C, views), dim3(256), 0, st, (const bf16_t*)w3, K3, scale3,
+                           (bf16_t*)out3, (const bf16_t*)wd, Kd, scaled, (bf16_t*)outd, shift3, shiftd, bias, C);
+    else
+        hipLaunchKernelGGL(linbn_scale_banks_kernel<f16_t>, dim3(C, views), dim3(256), 0, st, (const f16_t*)w3, K3, scale3,
+                           (f16_t*)out3, (const f16_t*)wd, Kd, scaled, (f16_t*)outd, shift3, shiftd, bias, C);
     SM3_CHECK_LAUNCH();
     return 0;
 }

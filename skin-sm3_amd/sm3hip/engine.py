@@ -163,7 +163,7 @@ class BNUnit:
 class Rec:
     """What one conv+BN(+act) application saves for backward."""
     __slots__ = ("cu", "bu", "N", "H", "W", "Ho", "Wo", "x_in", "xo", "mean", "invstd", "y", "relu", "mask", "V",
-                 "frozen_stats", "scale", "shift", "colsum", "linbn", "gram", "Tm")
+                 "frozen_stats", "scale", "shift", "colsum", "linbn", "gram", "Tm", "in_s")
 
 
 class EncoderPlan:
@@ -294,6 +294,7 @@ class SM3Engine:
         self.linbn_fwd = _os.environ.get("SM3_LINBN_FWD", "1") != "0"
         # ... and the downsample conv -> BatchNorm of a stage's first block in the backward pass
         self.linbn_ds = _os.environ.get("SM3_LINBN_DS", "1") != "0"
+        self.linbn_join = _os.environ.get("SM3_LINBN_JOIN", "1") != "0"
 
     # ---- setup ---------------------------------------------------------------------------
     def _all_conv_units(self):
@@ -724,6 +725,79 @@ class SM3Engine:
         save.append(r)
         return y3, d.Ho, d.Wo
 
+    def join_fused(self, blk, r2, y2, cur, N, h, w, h2, w2, save):
+        """The whole join of a Bottleneck with a downsample branch -- conv3 -> bn3, downsample conv -> its BatchNorm, add,
+        ReLU (resnet.py:162-172) -- as ONE two-segment GEMM over [y2 | strided block input]: both units' batch statistics
+        come from input moments (sm3_linbn_fwd_stats; data parallel: one exchange for the two), their scales go into the
+        filter banks and their shifts into the column bias (sm3_linbn_scale_banks).  Neither pre-BatchNorm tensor exists;
+        the compact block input and its moments are kept for the backward pass."""
+        dev = y2.device
+        c3, b3, cd, bd = blk["c3"], blk["b3"], blk["cd"], blk["bd"]
+        C, p, Cin, V = c3.Co, c3.Ci, cd.Ci, self._V
+        M = N * h2 * w2
+        rows_v = M // V
+        if V > 1 and rows_v % 128:
+            raise ValueError("two views in one batch need a multiple of 128 rows per view")
+        # moments of the (strided) block input
+        crow = ops.subsample_colsum_rows(self.dtype, rows_v, Cin)
+        csd = self._work("linbn_cs", V * crow * Cin)
+        if cd.stride == 1:
+            in_s = cur
+            ops.subsample_colsum(self.dtype, cur, None, csd, N, h, w, Cin, 1, V)
+        else:
+            in_s = torch.empty(M, Cin, dtype=self.tdt, device=dev)
+            ops.subsample_colsum(self.dtype, cur, in_s, csd, N, h, w, Cin, cd.stride, V)
+        slabs = self._slab_buf(Cin * Cin, V)
+        ns = ops.conv_wgrad_slabs(self._lin_conv_desc(self.dtype, N, h2, w2, Cin, Cin), in_s, in_s, slabs, views=V)
+        Gd = torch.empty(V * Cin * Cin, dtype=torch.float32, device=dev)
+        sd = torch.empty(V * Cin, dtype=torch.float64, device=dev)
+        ops.linbn_moments(slabs, ns, Cin * Cin, Gd, views=V, colsum=csd, colsum_rows=crow, s_out=sd, p=Cin)
+        # batch statistics of both units
+        g3, gd = p // 32, Cin // 32
+        n3, nd = V * g3 * 2 * C, V * gd * 2 * C
+        ws = self._work("linbn_fws2", n3 + nd, torch.float64)
+        Tm3 = torch.empty(V * C * p, dtype=torch.float32, device=dev)
+        Tmd = torch.empty(V * C * Cin, dtype=torch.float32, device=dev)
+        ops.linbn_fwd_stats(self.dtype, r2.gram, c3.w_dgrad, c3.w_fwd, r2.colsum, Tm3, ws[:n3], C, p, V)
+        ops.linbn_fwd_stats(self.dtype, Gd, cd.w_dgrad, cd.w_fwd, sd, Tmd, ws[n3: n3 + nd], C, Cin, V)
+        count = rows_v
+        if self.stat_sync is not None:
+            self.stat_sync(ws[: n3 + nd])  # SyncBatchNorm: one exchange for the two units
+            count = rows_v * self.world_size
+        track = not self.__dict__.get("_no_stat_update", False)
+        out = []
+        for bu, wsl, groups, tag in ((b3, ws[:n3], g3, ""), (bd, ws[n3: n3 + nd], gd, "_d")):
+            scale, shift = self._work("scale" + tag, 2 * 2048), self._work("shift" + tag, 2 * 2048)
+            mean = torch.empty(V * C, dtype=torch.float32, device=dev)
+            invstd = torch.empty(V * C, dtype=torch.float32, device=dev)
+            ops.bn_finalize(wsl, count, C, self._p(bu.name + ".weight") if bu.affine else None,
+                            self._p(bu.name + ".bias") if bu.affine else None, BN_EPS, BN_MOMENTUM,
+                            self.buffers[bu.name + ".running_mean"] if track else None,
+                            self.buffers[bu.name + ".running_var"] if track else None,
+                            self.buffers[bu.name + ".num_batches_tracked"] if track else None,
+                            scale, shift, mean, invstd, groups=groups, views=V)
+            out.append((scale, shift, mean, invstd))
+        (sc3, sh3, mean3, inv3), (scd, shd, meand, invd) = out
+        w3s = self._work("linbn_w3s", V * C * p, self.tdt)
+        wds = self._work("linbn_wds", V * C * Cin, self.tdt)
+        bias = self._work("linbn_fbias", V * C)
+        ops.linbn_scale_banks(self.dtype, c3.w_fwd, sc3, sh3, w3s, cd.w_fwd, scd, shd, wds, bias, C, V)
+        y3 = torch.empty(M, C, dtype=self.tdt, device=dev)
+        mask = torch.empty(M * C // (16 // ops._sz(self.dtype)), dtype=torch.uint8, device=dev)
+        ops.conv_seg_act(self._lin_conv_desc(self.dtype, N, h2, w2, p, C), y2, w3s, in_s, wds, bias, y3, mask, True,
+                         views=V, w_view_stride=C * p, w1_view_stride=C * Cin)
+        rd, r3 = Rec(), Rec()
+        for r in (rd, r3):
+            r.N, r.Ho, r.Wo, r.V, r.frozen_stats, r.linbn = N, h2, w2, V, False, True
+            r.scale = r.shift = r.xo = r.colsum = r.gram = r.in_s = None
+        rd.cu, rd.bu, rd.H, rd.W, rd.x_in, rd.mean, rd.invstd, rd.y, rd.relu, rd.mask = cd, bd, h, w, cur, meand, invd, None, False, None
+        rd.in_s, rd.gram, rd.colsum, rd.Tm = in_s, Gd, sd, Tmd
+        r3.cu, r3.bu, r3.H, r3.W, r3.x_in, r3.mean, r3.invstd, r3.y, r3.relu, r3.mask = c3, b3, h2, w2, y2, mean3, inv3, y3, True, mask
+        r3.Tm = Tm3
+        save.append(rd)
+        save.append(r3)
+        return y3, h2, w2
+
     def _lin_unit_products(self, tag, cu, N, Hs, Ws, y_in, dz, V):
         """P = dz^T y_in [V][C][Cin] of an expanding 1x1 conv unit over compact pixels: plain-store split-K slabs of the
         weight-gradient kernel, summed in a fixed order."""
@@ -785,19 +859,24 @@ class SM3Engine:
             Cin = cd.Ci
             affd = bd.affine
             gamma_d = self._p(bd.name + ".weight") if affd else None
-            crow = ops.subsample_colsum_rows(self.dtype, rows, Cin)
-            csd = self._work("linbn_cs", V * crow * Cin)
-            if cd.stride == 1:
-                in_s = rd.x_in
-                ops.subsample_colsum(self.dtype, rd.x_in, None, csd, rd.N, rd.H, rd.W, Cin, 1, V)
+            Tmd = None
+            if rd.linbn:  # the forward pass ran the join by linearity (join_fused) and kept the moments
+                in_s, Gd, sd, Tmd = rd.in_s, rd.gram, rd.colsum, rd.Tm
             else:
-                in_s = torch.empty(M, Cin, dtype=self.tdt, device=dz.device)
-                ops.subsample_colsum(self.dtype, rd.x_in, in_s, csd, rd.N, rd.H, rd.W, Cin, cd.stride, V)
-            slabs = self._slab_buf(Cin * Cin, V)
-            ns = ops.conv_wgrad_slabs(self._lin_conv_desc(self.dtype, rd.N, rd.Ho, rd.Wo, Cin, Cin), in_s, in_s, slabs, views=V)
-            Gd = self._work("linbn_Gd", V * Cin * Cin)
-            sd = self._work("linbn_sd", V * Cin, torch.float64)
-            ops.linbn_moments(slabs, ns, Cin * Cin, Gd, views=V, colsum=csd, colsum_rows=crow, s_out=sd, p=Cin)
+                crow = ops.subsample_colsum_rows(self.dtype, rows, Cin)
+                csd = self._work("linbn_cs", V * crow * Cin)
+                if cd.stride == 1:
+                    in_s = rd.x_in
+                    ops.subsample_colsum(self.dtype, rd.x_in, None, csd, rd.N, rd.H, rd.W, Cin, 1, V)
+                else:
+                    in_s = torch.empty(M, Cin, dtype=self.tdt, device=dz.device)
+                    ops.subsample_colsum(self.dtype, rd.x_in, in_s, csd, rd.N, rd.H, rd.W, Cin, cd.stride, V)
+                slabs = self._slab_buf(Cin * Cin, V)
+                ns = ops.conv_wgrad_slabs(self._lin_conv_desc(self.dtype, rd.N, rd.Ho, rd.Wo, Cin, Cin), in_s, in_s, slabs,
+                                          views=V)
+                Gd = self._work("linbn_Gd", V * Cin * Cin)
+                sd = self._work("linbn_sd", V * Cin, torch.float64)
+                ops.linbn_moments(slabs, ns, Cin * Cin, Gd, views=V, colsum=csd, colsum_rows=crow, s_out=sd, p=Cin)
             Pd = self._lin_unit_products("d", cd, rd.N, rd.Ho, rd.Wo, in_s, dz, V)
             coef_d = self._work("linbn_coef_d", V * 4 * C)
             ops.linbn_stats(self.dtype, Pd, cd.w_fwd, rd.mean, rd.invstd, gamma_d, ws, groups, lsums[n: 2 * n],
@@ -822,7 +901,7 @@ class SM3Engine:
         wa, Hn, cconst = self._lin_unit_finish("", cu, P, r2.gram, r3.Tm, r2.colsum, coef, V)
         ds = None
         if lin_d:
-            wa_d, Hn_d, cconst_d = self._lin_unit_finish("d", cd, Pd, Gd, None, sd, coef_d, V)
+            wa_d, Hn_d, cconst_d = self._lin_unit_finish("d", cd, Pd, Gd, Tmd, sd, coef_d, V)
             ds = {"x1": in_s, "wa": wa_d, "hn": Hn_d, "const": cconst_d}
         # 4. data gradient [dz | y2] x [diag(a) W ; -H]^T + const, with bn2's ReLU mask and phase 1 in the epilogue
         descs, full = cu.dgrad_descs(self.dtype, r3.N, r3.H, r3.W)
@@ -981,7 +1060,7 @@ class SM3Engine:
         Vt = self._V if train else 1
         lin_ok = [self.linbn and train and save is not None and b["c3"].Co % 128 == 0 and b["c3"].Ci % 64 == 0
                   for b in plan.blocks]
-        for blk, lin in zip(plan.blocks, lin_ok):
+        for bi, (blk, lin) in enumerate(zip(plan.blocks, lin_ok)):
             br = [] if save is not None else None
             y1, h1, w1 = self.conv_bn(blk["c1"], blk["b1"], cur, N, h, w, True, None, train, br)
             pp = blk["c3"].Ci
@@ -1000,6 +1079,16 @@ class SM3Engine:
                                   s_out=br[1].colsum, p=pp)
             ra = None
             pend = None
+            # the join by linearity needs what its backward needs (conv3_backward_linbn, lin_d)
+            join_lin = (lin and "cd" in blk and self.linbn_fwd and self.linbn_ds and self.linbn_join and not self._ordered_bn
+                        and self.fuse_bn_bwd and blk["cd"].Ci % 64 == 0 and
+                        (blk["cd"].stride == 1 or (bi > 0 and blk["cd"].stride == 2 and
+                                                   (Vt == 1 or (N * h * w) % 256 == 0))))
+            if join_lin:
+                y3, h3, w3 = self.join_fused(blk, br[1], y2, cur, N, h, w, h2, w2, br)
+                block_recs.append(br)
+                cur, h, w = y3, h3, w3
+                continue
             if "cd" in blk and lazy:
                 # downsample branch: convolution + statistics only; its BatchNorm is applied inside the join below
                 # (data parallel: its statistics travel in conv3's all-reduce)
@@ -1053,9 +1142,10 @@ class SM3Engine:
                 else:
                     prow, bpart = fr, self._ws[(self._lane, "fz_partials")]
                 prev_r3 = ctx["blocks"][bi - 1][-1] if bi > 0 else None
-                lin_d = (rd is not None and self.linbn_ds and rd.cu.Ci % 64 == 0 and not rd.frozen_stats and
-                         (rd.cu.stride == 1 or (prev_r3 is not None and self.fuse_bn_bwd and rd.cu.stride == 2 and
-                                                (prev_r3.V == 1 or (r1.N * r1.H * r1.W) % 256 == 0))))
+                lin_d = rd is not None and (rd.linbn or (
+                    self.linbn_ds and rd.cu.Ci % 64 == 0 and not rd.frozen_stats and
+                    (rd.cu.stride == 1 or (prev_r3 is not None and self.fuse_bn_bwd and rd.cu.stride == 2 and
+                                           (prev_r3.V == 1 or (r1.N * r1.H * r1.W) % 256 == 0)))))
                 dy2, fr2, dxd = self.conv3_backward_linbn(r3, r2, dcur, bpart, prow, rd=rd, lin_d=lin_d)
                 dz = None if rd is not None else dcur
             else:

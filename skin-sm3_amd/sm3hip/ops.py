@@ -353,6 +353,44 @@ def conv_gemm_seg(desc, x0, w0, x1, w1, col_bias, y, addend=None, views=1, w_vie
                                                    _stream()), "sm3_conv_gather_gemm_seg")
 
 
+def conv_seg_act(desc, x0, w0, x1, w1, col_bias, y, mask=None, relu=True, views=1, w_view_stride=0, w1_view_stride=0):
+    """y = relu?(x0 w0^T + x1 w1^T + col_bias) with the ReLU bits in `mask` (sm3_conv_seg_act): with BatchNorm-scaled banks
+    (linbn_scale_banks) the whole join of a Bottleneck that has a downsample branch."""
+    tdt = TORCH_DTYPE[desc.dtype]
+    for t, n in ((x0, "x0"), (w0, "w0"), (x1, "x1"), (w1, "w1"), (y, "y")):
+        _chk(t, tdt, n)
+    _chk(col_bias, torch.float32, "col_bias"); _chk(mask, torch.uint8, "mask")
+    if desc.dtype == SM3_F32:
+        raise ValueError("conv_seg_act: 16-bit activation types only")
+    M = desc.N * desc.Ho * desc.Wo
+    if desc.ntaps != 1 or desc.Hout != desc.Ho or desc.Wout != desc.Wo or desc.Hi != desc.Ho or desc.Wi != desc.Wo:
+        raise ValueError("conv_seg_act: 1x1 / stride-1 descriptor expected")
+    if x0.numel() != M * desc.Ci or x1.numel() % M or y.numel() != M * desc.Co:
+        raise ValueError("conv_seg_act: operand size does not match descriptor")
+    Ci1 = x1.numel() // M
+    if Ci1 % K_CHUNK[desc.dtype] or desc.Ci % K_CHUNK[desc.dtype]:
+        raise ValueError("conv_seg_act: channel counts must be multiples of the K chunk")
+    if w0.numel() < (views - 1) * w_view_stride + desc.Co * desc.w_row_stride or \
+            w1.numel() < (views - 1) * w1_view_stride + desc.Co * Ci1 or col_bias.numel() < views * desc.Co:
+        raise ValueError("conv_seg_act: weight bank / col_bias too small")
+    if mask is not None and (not relu or mask.numel() != M * desc.Co // (16 // _sz(desc.dtype))):
+        raise ValueError("conv_seg_act: mask size mismatch")
+    if views > 1 and (views != 2 or M % 256):
+        raise ValueError("two views need a multiple of 128 rows each")
+    sg = _lib.ConvSeg()
+    sg.x1, sg.w1, sg.Ci1 = x1.data_ptr(), w1.data_ptr(), Ci1
+    sg.w_view_stride, sg.w1_view_stride = w_view_stride, w1_view_stride
+    sg.col_bias = col_bias.data_ptr()
+    sg.views = views
+    sz = _sz(desc.dtype)
+    tag = _conv_tag(desc)
+    if _PROFILER is not None and getattr(_PROFILER, "detail", False):
+        tag += f"|M{M}_K{desc.Ci}+{Ci1}_N{desc.Co}_segact"
+    with _prof(tag, 2.0 * M * desc.Co * (desc.Ci + Ci1), sz * (x0.numel() + x1.numel() + M * desc.Co)):
+        check(_lib.load().sm3_conv_seg_act(C.byref(desc), _ptr(x0), _ptr(w0), C.byref(sg), int(relu), _ptr(y), _ptr(mask),
+                                           _stream()), "sm3_conv_seg_act")
+
+
 def conv_bn_act_eval(desc, x, w, scale, shift, residual, relu, y):
     """conv + eval-mode BN (+residual) (+ReLU) in one launch (sm3_conv_bn_act_eval)."""
     tdt = TORCH_DTYPE[desc.dtype]
@@ -500,6 +538,25 @@ def linbn_fwd_stats(dtype, G, w_dgrad, w_fwd, s, Tm, sums_ws, Cn, p, views=1):
         check(_lib.load().sm3_linbn_fwd_stats(dtype, _ptr(G), _ptr(w_dgrad), _ptr(w_fwd), _ptr(s), _ptr(Tm), _ptr(sums_ws),
                                               Cn, p, views, _stream()), "sm3_linbn_fwd_stats")
     return p // 32
+
+
+def linbn_scale_banks(dtype, w3, scale3, shift3, out3, wd, scaled, shiftd, outd, bias, Cn, views=1):
+    """out3[v] = diag(scale3[v]) w3, outd[v] = diag(scaled[v]) wd, bias[v] = shift3[v] + shiftd[v] (sm3_linbn_scale_banks)."""
+    tdt = TORCH_DTYPE[dtype]
+    for t in (w3, out3, wd, outd):
+        _chk(t, tdt)
+    for t in (scale3, shift3, scaled, shiftd, bias):
+        _chk(t, torch.float32)
+    if w3.numel() % Cn or wd.numel() % Cn:
+        raise ValueError("linbn_scale_banks: bank size is not a multiple of C")
+    K3, Kd = w3.numel() // Cn, wd.numel() // Cn
+    if K3 % 8 or Kd % 8 or out3.numel() < views * Cn * K3 or outd.numel() < views * Cn * Kd or bias.numel() < views * Cn or \
+            min(scale3.numel(), shift3.numel(), scaled.numel(), shiftd.numel()) < views * Cn:
+        raise ValueError("linbn_scale_banks: size mismatch")
+    with _prof("linbn_small", 0.0, _sz(dtype) * (1 + views) * Cn * (K3 + Kd)):
+        check(_lib.load().sm3_linbn_scale_banks(dtype, _ptr(w3), K3, _ptr(scale3), _ptr(shift3), _ptr(out3), _ptr(wd), Kd,
+                                                _ptr(scaled), _ptr(shiftd), _ptr(outd), _ptr(bias), Cn, views, _stream()),
+              "sm3_linbn_scale_banks")
 
 
 def linbn_stats(dtype, P, w_fwd, mean, invstd, gamma, reduce_ws, groups, lsums, dgamma, dbeta, count, coef, Cn, p, views=1):

@@ -99,7 +99,9 @@ def test_engine_dry_run_sequences_and_bucket_schedule(model, linbn):
     # the 12 blocks without a downsample branch also run conv3 -> bn3 -> +identity -> ReLU as ONE launch, bn3's statistics
     # from the moments of conv3's input (no join pass, no pre-BatchNorm tensor)
     nfused = 48 if linbn else 0
-    assert calls["sm3_linbn_fwd_stats"] == nfused and calls["sm3_conv_bn_act_fused"] == nfused
+    assert calls["sm3_linbn_fwd_stats"] == nfused + 2 * nds and calls["sm3_conv_bn_act_fused"] == nfused
+    # ... and the 4 with one run the whole join (conv3, bn3, downsample conv, its BatchNorm, add, ReLU) as one two-segment GEMM
+    assert calls["sm3_conv_seg_act"] == nds and calls["sm3_linbn_scale_banks"] == nds
     if linbn:
         # no backward-apply pass for bn3 nor for the downsample BatchNorms (the stem's is fused into its weight gradient)
         assert calls["sm3_bn_bwd_apply2"] == 0 and calls["sm3_bn_bwd_apply"] == 230 - 4 - 64 - 16
@@ -108,7 +110,7 @@ def test_engine_dry_run_sequences_and_bucket_schedule(model, linbn):
         assert calls["sm3_bn_bwd_apply2"] == 4 * 4 and calls["sm3_bn_bwd_apply"] == 230 - 2 * 16 - 4
     # ... and its forward apply, except where the consumer applies it: the 16 downsample BatchNorms inside their
     # block's join (sm3_bn_add_bn_act), the 4 stem BatchNorms inside the fused BN + ReLU + max-pool pass
-    assert calls["sm3_bn_add_bn_act"] == 16 and calls["sm3_bn_act"] + calls["sm3_bn_act_colsum"] == 230 - 16 - 16 - 4 - nfused
+    assert calls["sm3_bn_add_bn_act"] == 16 - nds and calls["sm3_bn_act"] + calls["sm3_bn_act_colsum"] == 230 - 16 - 16 - 4 - nfused
     assert calls["sm3_ntxent_fused"] == 4 and calls["sm3_adamw"] == 1
     assert calls["sm3_stem_conv_fwd"] == 4 and calls["sm3_stem_im2col"] == 0
     assert calls["sm3_bn_relu_maxpool_fwd"] == 4 and calls["sm3_maxpool_bn_bwd"] == 4

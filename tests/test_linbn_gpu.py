@@ -446,3 +446,67 @@ def test_two_segment_gemm_without_a_fused_batchnorm(case, addend, dt):
             ref = ref + add[sl].double()
         sc = ref.abs().max().item()
         assert (y[sl].double().cpu() - ref).abs().max().item() < 1.5 * tol(dt) * sc
+
+
+@pytest.mark.parametrize("dt", DTS, ids=IDS)
+@pytest.mark.parametrize("case", [(1, 640, 256, 64, 128), (2, 512, 512, 128, 256), (2, 128, 2048, 512, 1024)])
+def test_join_of_a_downsample_block_by_linearity(case, dt):
+    """The forward join of a Bottleneck with a downsample branch (resnet.py:162-172) as the engine's join_fused runs it:
+    batch statistics of bn3 and of the downsample BatchNorm from the moments of their convolutions' inputs
+    (sm3_linbn_fwd_stats), scales folded into the banks (sm3_linbn_scale_banks), one two-segment GEMM with ReLU + mask
+    (sm3_conv_seg_act) -- against fp64 train-mode BatchNorm of the two explicit convolutions, per view."""
+    ops = _ops()
+    V, Mv, C, p, Cin = case
+    M = V * Mv
+    g = torch.Generator().manual_seed(M + C + p + Cin)
+    y2 = torch.relu(torch.randn(M, p, generator=g) + 0.3).to(dt)
+    xin = torch.relu(torch.randn(M, Cin, generator=g)).to(dt)
+    w3 = (torch.randn(C, p, generator=g) / math.sqrt(p)).to(dt)
+    wd = (torch.randn(C, Cin, generator=g) / math.sqrt(Cin)).to(dt)
+    gam3, bet3 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    gamd, betd = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    code = ops.dtype_code(dt)
+    D = dev()
+    scales, shifts, means = [], [], []
+    for x, w, K, gam, bet in ((y2, w3, p, gam3, bet3), (xin, wd, Cin, gamd, betd)):
+        xd = x.to(D)
+        slabs = torch.empty(64 * V * K * K, device=D)
+        ns = ops.conv_wgrad_slabs(ops.fwd_desc(code, V, Mv, 1, K, K, 1, 1, 0), xd, xd, slabs, views=V)
+        G = torch.empty(V * K * K, device=D)
+        crow = ops.subsample_colsum_rows(code, Mv, K)
+        cs = torch.empty(V * crow * K, device=D)
+        ops.subsample_colsum(code, xd, None, cs, V, Mv, 1, K, 1, V)
+        s = torch.empty(V * K, dtype=torch.float64, device=D)
+        ops.linbn_moments(slabs, ns, K * K, G, views=V, colsum=cs, colsum_rows=crow, s_out=s, p=K)
+        Tm = torch.empty(V * C * K, device=D)
+        groups = K // 32
+        ws = torch.empty(V * groups * 2 * C, dtype=torch.float64, device=D)
+        ops.linbn_fwd_stats(code, G, w.t().contiguous().to(D), w.to(D), s, Tm, ws, C, K, V)
+        sc, sh = torch.empty(V * C, device=D), torch.empty(V * C, device=D)
+        mean, invstd = torch.empty(V * C, device=D), torch.empty(V * C, device=D)
+        ops.bn_finalize(ws, Mv, C, gam.to(D), bet.to(D), 1e-5, 0.1, None, None, None, sc, sh, mean, invstd, groups=groups,
+                        views=V)
+        scales.append(sc); shifts.append(sh); means.append(mean)
+    w3s = torch.empty(V * C * p, dtype=dt, device=D)
+    wds = torch.empty(V * C * Cin, dtype=dt, device=D)
+    bias = torch.empty(V * C, device=D)
+    ops.linbn_scale_banks(code, w3.to(D), scales[0], shifts[0], w3s, wd.to(D), scales[1], shifts[1], wds, bias, C, V)
+    out = torch.empty(M, C, dtype=dt, device=D)
+    mask = torch.empty(M * C // 8, dtype=torch.uint8, device=D)
+    ops.conv_seg_act(ops.fwd_desc(code, V, Mv, 1, p, C, 1, 1, 0), y2.to(D), w3s, xin.to(D), wds, bias, out, mask, True,
+                     views=V, w_view_stride=C * p, w1_view_stride=C * Cin)
+    torch.cuda.synchronize()
+    t = tol(dt)
+    for v in range(V):
+        sl = slice(v * Mv, (v + 1) * Mv)
+        ref = 0
+        for x, w, gam, bet, mean in ((y2, w3, gam3, bet3, means[0]), (xin, wd, gamd, betd, means[1])):
+            z = x[sl].double() @ w.double().t()
+            mu, var = z.mean(0), z.var(0, unbiased=False)
+            assert torch.allclose(mean.view(V, C)[v].double().cpu(), mu, rtol=1e-4, atol=1e-4 * z.abs().max().item())
+            ref = ref + (z - mu) / torch.sqrt(var + 1e-5) * gam.double() + bet.double()
+        ref = torch.relu(ref)
+        got = out[sl].double().cpu()
+        assert (got - ref).abs().max().item() < 3 * t * ref.abs().max().item()
+        bits = ((mask.cpu().reshape(M, C // 8, 1) >> torch.arange(8, dtype=torch.uint8)) & 1).reshape(M, C)[sl].bool()
+        assert torch.equal(bits, out[sl].cpu() > 0)
