@@ -26,16 +26,16 @@ namespace {
 
 // 32 x 32 tile of W G on the exact-f32 MFMA, operands straight from L2 (a few hundred KB): lane (i = l & 31, kk = l >> 5)
 // feeds A[i][k] = wd[k][co0 + i] (the data-gradient bank [p][C]: contiguous over i) and B[k][j] = G[k][ci0 + j] for
-// k = 2 t + kk; the loads of 8 steps are issued before the first MFMA of the batch.  acc[r] = (W G)[co0 + row(r)][ci0 + i],
+// k = 2 t + kk; the loads of 8 steps are issued before the first MFMA of the batch; K is split over the block's 4 waves.  acc[r] = (W G)[co0 + row(r)][ci0 + i],
 // row(r) = (r & 3) + 8 (r >> 2) + 4 kk.
 template <typename T>
 __device__ __forceinline__ void tile_wg(const T* __restrict__ wd, int C, const float* __restrict__ G, int p, int co0, int ci0,
-                                        int lane, f32x16& acc) {
+                                        int lane, int wave, f32x16& acc) {
     const int i = lane & 31, kk = lane >> 5;
     const T* ap = wd + (long)kk * C + co0 + i;
     const float* bp = G + (long)kk * p + ci0 + i;
     constexpr int U = 8;
-    for (int t = 0; t < p / 2; t += U) {
+    for (int t = wave * U; t < p / 2; t += 4 * U) {  // the block's 4 waves take every fourth batch of K-steps
         float a[U], b[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -44,6 +44,18 @@ __device__ __forceinline__ void tile_wg(const T* __restrict__ wd, int C, const f
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+    }
+}
+
+// The four waves' partial tiles added up in a fixed order; wave w leaves with accumulator registers 4 w .. 4 w + 3 of the sum.
+__device__ __forceinline__ void reduce4(const f32x16& acc, float* red, int wave, int lane, float out[4]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = wave * 4 + q;
+        out[q] = (red[r * 64 + lane] + red[(16 + r) * 64 + lane]) + (red[(32 + r) * 64 + lane] + red[(48 + r) * 64 + lane]);
     }
 }
 
@@ -110,31 +122,34 @@ __global__ __launch_bounds__(256) void linbn_moments_kernel(const float* __restr
 }
 
 // ---- sm3_linbn_fwd_stats --------------------------------------------------------------------------------------------
-// one wave per (view, 32 channels co, 32 columns ci): Tm[v][co][ci] = (W G_v)[co][ci], and the tile's share of the batch
-// sums of x = y W^T:  ws[v][cit][co] = sum_{ci in tile} W[co][ci] s_v[ci],  ws[v][cit][C + co] = sum_{ci} Tm W[co][ci]
-// -- the [views][groups = p/32][2C] fp64 layout sm3_bn_finalize sums over.
+// one block per (view, 32 channels co, 32 columns ci), K split over its 4 waves: Tm[v][co][ci] = (W G_v)[co][ci], and the
+// tile's share of the batch sums of x = y W^T:  ws[v][cit][co] = sum_{ci in tile} W[co][ci] s_v[ci],  ws[v][cit][C + co] =
+// sum_{ci} Tm W[co][ci] -- the [views][groups = p/32][2C] fp64 layout sm3_bn_finalize sums over.
 template <typename T>
 __global__ __launch_bounds__(256) void linbn_fwd_stats_kernel(const float* __restrict__ G, const T* __restrict__ wd,
                                                               const T* __restrict__ w, const double* __restrict__ s,
                                                               float* __restrict__ Tm, double* __restrict__ ws, int C,
                                                               int p, int views) {
-    const int lane = threadIdx.x & 63, i = lane & 31, kk = lane >> 5;
+    __shared__ float red[4 * 16 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, kk = lane >> 5;
     const int pt = p / 32, ct = C / 32;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= views * ct * pt) return;
+    const int tile = blockIdx.x;
     const int v = tile / (ct * pt), rem = tile - v * ct * pt;
     const int co0 = (rem / pt) * 32, cit = rem % pt, ci0 = cit * 32;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    tile_wg<T>(wd, C, G + (long)v * p * p, p, co0, ci0, lane, acc);
+    tile_wg<T>(wd, C, G + (long)v * p * p, p, co0, ci0, lane, wave, acc);
+    float t4[4];
+    reduce4(acc, red, wave, lane, t4);
     const double sv = s[(long)v * p + ci0 + i];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int q = 0; q < 4; ++q) {
+        const int r = wave * 4 + q;
         const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-        Tm[((long)v * C + co) * p + ci0 + i] = acc[r];
+        Tm[((long)v * C + co) * p + ci0 + i] = t4[q];
         const double wv = (double)ElemTraits<T>::load(w + (long)co * p + ci0 + i);
-        const double s1 = half_sum(wv * sv), s2 = half_sum(wv * (double)acc[r]);
+        const double s1 = half_sum(wv * sv), s2 = half_sum(wv * (double)t4[q]);
         if (i == 0) {
             double* o = ws + ((long)v * pt + cit) * 2 * C;
             o[co] = s1;
@@ -274,11 +289,11 @@ __global__ __launch_bounds__(256) void linbn_post_kernel(const T* __restrict__ w
                                                          const float* __restrict__ G, const float* __restrict__ Tm,
                                                          const double* __restrict__ s, const float4* __restrict__ coef,
                                                          float* __restrict__ dw, int C, int p, int views, int h_tiles) {
-    const int lane = threadIdx.x & 63, i = lane & 31, kk = lane >> 5;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ float red[4 * 16 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, kk = lane >> 5;
+    const int tile = blockIdx.x;  // one 32 x 32 tile per block, K split over its 4 waves
     const int pt = p / 32;
     if (tile < h_tiles) {
-        if (tile >= views * pt * pt) return;  // padding of the last H block
         const int v = tile / (pt * pt), rem = tile - v * pt * pt;
         const int k0 = (rem / pt) * 32, c0 = (rem % pt) * 32;
         const T* ap = wbn + ((long)v * p + k0 + i) * C + 8 * kk;
@@ -287,7 +302,7 @@ __global__ __launch_bounds__(256) void linbn_post_kernel(const T* __restrict__ w
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         constexpr int U = 8;  // K-steps of 16 channels per batch of loads (C is a multiple of 128)
-        for (int c = 0; c < C; c += 16 * U) {
+        for (int c = wave * 16 * U; c < C; c += 4 * 16 * U) {
             uint4 fa[U], fb[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -304,45 +319,52 @@ __global__ __launch_bounds__(256) void linbn_post_kernel(const T* __restrict__ w
                                                                  __builtin_bit_cast(f16x8, fb[u]), acc, 0, 0, 0);
             }
         }
+        float t4[4];
+        reduce4(acc, red, wave, lane, t4);
         T* out = hn + ((long)v * p + k0) * p + c0 + i;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int q = 0; q < 4; ++q) {
+            const int r = wave * 4 + q;
             const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
-            if constexpr (__is_same(T, bf16_t)) out[(long)row * p].v = f32_to_bf16(acc[r]);
-            else out[(long)row * p].v = f32_to_f16(acc[r]);
+            if constexpr (__is_same(T, bf16_t)) out[(long)row * p].v = f32_to_bf16(t4[q]);
+            else out[(long)row * p].v = f32_to_f16(t4[q]);
         }
         return;
     }
     const int ft = tile - h_tiles;
-    if (ft >= (C / 32) * pt) return;
     const int co0 = (ft / pt) * 32, ci0 = (ft % pt) * 32;
-    float tot[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) tot[r] = 0.f;
+    float tot[4] = {0.f, 0.f, 0.f, 0.f};
     for (int v = 0; v < views; ++v) {
-        f32x16 acc;
+        float t4[4];
         if (Tm) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                acc[r] = Tm[((long)v * C + co0 + (r & 3) + 8 * (r >> 2) + 4 * kk) * p + ci0 + i];
+            for (int q = 0; q < 4; ++q) {
+                const int r = wave * 4 + q;
+                t4[q] = Tm[((long)v * C + co0 + (r & 3) + 8 * (r >> 2) + 4 * kk) * p + ci0 + i];
+            }
         } else {
+            f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            tile_wg<T>(wd, C, G + (long)v * p * p, p, co0, ci0, lane, acc);
+            tile_wg<T>(wd, C, G + (long)v * p * p, p, co0, ci0, lane, wave, acc);
+            if (v) __syncthreads();  // the previous view's partial tiles have been read
+            reduce4(acc, red, wave, lane, t4);
         }
         const float sv = (float)s[(long)v * p + ci0 + i];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int q = 0; q < 4; ++q) {
+            const int r = wave * 4 + q;
             const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-            const float4 q = coef[(long)v * C + co];  // (a, b, m1, mu)
+            const float4 c4 = coef[(long)v * C + co];  // (a, b, m1, mu)
             const float pv = P[((long)v * C + co) * p + ci0 + i];
-            tot[r] += q.x * (pv - q.z * sv) - q.y * (acc[r] - q.w * sv);
+            tot[q] += c4.x * (pv - c4.z * sv) - c4.y * (t4[q] - c4.w * sv);
         }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int q = 0; q < 4; ++q) {
+        const int r = wave * 4 + q;
         const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-        dw[(long)co * p + ci0 + i] += tot[r];
+        dw[(long)co * p + ci0 + i] += tot[q];
     }
 }
 
@@ -367,7 +389,7 @@ extern "C" int sm3_linbn_fwd_stats(int dtype, const float* G, const void* w_dgra
     if (!G || !w_dgrad || !w_fwd || !s || !Tm || !sums_ws || C <= 0 || p <= 0 || views < 1) return SM3_EINVAL;
     if (!lin16(dtype)) return SM3_EDTYPE;
     if (C % 32 || p % 32) return SM3_EALIGN;
-    const unsigned blocks = (unsigned)((views * (C / 32) * (p / 32) + 3) / 4);
+    const unsigned blocks = (unsigned)(views * (C / 32) * (p / 32));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SM3_BF16)
         hipLaunchKernelGGL(linbn_fwd_stats_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, G, (const bf16_t*)w_dgrad,
@@ -449,8 +471,8 @@ extern "C" int sm3_linbn_post(int dtype, const void* wbn, const void* w_dgrad, v
     if (!lin16(dtype)) return SM3_EDTYPE;
     if (C % 128 || p % 32) return SM3_EALIGN;
     const int pt = p / 32, h_tiles = views * pt * pt, f_tiles = (C / 32) * pt;
-    const int h_pad = (h_tiles + 3) / 4 * 4;  // a block is all-H or all-finish
-    const unsigned blocks = (unsigned)(h_pad / 4 + (f_tiles + 3) / 4);
+    const int h_pad = h_tiles;  // one tile per block
+    const unsigned blocks = (unsigned)(h_tiles + f_tiles);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SM3_BF16)
         hipLaunchKernelGGL(linbn_post_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)wbn, (const bf16_t*)w_dgrad,

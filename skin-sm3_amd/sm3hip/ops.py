@@ -511,6 +511,12 @@ def conv_wgrad_slabs(desc, x, dy, slabs, views=1):
     return used.value
 
 
+def _lin_tag(name, a, b):
+    if _PROFILER is not None and getattr(_PROFILER, "detail", False):
+        return f"linbn_small|{name[6:]}_{a}_{b}"
+    return "linbn_small"
+
+
 def linbn_moments(slabs, nslabs, n, out, views=1, colsum=None, colsum_rows=0, s_out=None, p=0):
     """out[v] = sum of view v's nslabs slabs (fixed order); with colsum partial rows also s_out[v] = their sum
     (sm3_linbn_moments)."""
@@ -520,7 +526,7 @@ def linbn_moments(slabs, nslabs, n, out, views=1, colsum=None, colsum_rows=0, s_
         raise ValueError("linbn_moments: size mismatch")
     if colsum is not None and (s_out is None or colsum.numel() < views * colsum_rows * p or s_out.numel() < views * p):
         raise ValueError("linbn_moments: colsum / s_out size mismatch")
-    with _prof("linbn_small", 0.0, 4.0 * views * n * (nslabs + 1)):
+    with _prof(_lin_tag("linbn_moments", n, nslabs), 0.0, 4.0 * views * n * (nslabs + 1)):
         check(_lib.load().sm3_linbn_moments(_ptr(slabs), nslabs, n, _ptr(out), _ptr(colsum), colsum_rows, _ptr(s_out), p,
                                             views, _stream()), "sm3_linbn_moments")
 
@@ -534,7 +540,7 @@ def linbn_fwd_stats(dtype, G, w_dgrad, w_fwd, s, Tm, sums_ws, Cn, p, views=1):
     if Cn % 32 or p % 32 or G.numel() < views * p * p or w_dgrad.numel() != p * Cn or w_fwd.numel() != Cn * p or \
             s.numel() < views * p or Tm.numel() < views * Cn * p or sums_ws.numel() < views * (p // 32) * 2 * Cn:
         raise ValueError("linbn_fwd_stats: size mismatch")
-    with _prof("linbn_small", 2.0 * views * Cn * p * p, 4.0 * views * (Cn * p + p * p) + _sz(dtype) * 2 * Cn * p):
+    with _prof(_lin_tag("linbn_fwd_stats", Cn, p), 2.0 * views * Cn * p * p, 4.0 * views * (Cn * p + p * p) + _sz(dtype) * 2 * Cn * p):
         check(_lib.load().sm3_linbn_fwd_stats(dtype, _ptr(G), _ptr(w_dgrad), _ptr(w_fwd), _ptr(s), _ptr(Tm), _ptr(sums_ws),
                                               Cn, p, views, _stream()), "sm3_linbn_fwd_stats")
     return p // 32
@@ -553,7 +559,7 @@ def linbn_scale_banks(dtype, w3, scale3, shift3, out3, wd, scaled, shiftd, outd,
     if K3 % 8 or Kd % 8 or out3.numel() < views * Cn * K3 or outd.numel() < views * Cn * Kd or bias.numel() < views * Cn or \
             min(scale3.numel(), shift3.numel(), scaled.numel(), shiftd.numel()) < views * Cn:
         raise ValueError("linbn_scale_banks: size mismatch")
-    with _prof("linbn_small", 0.0, _sz(dtype) * (1 + views) * Cn * (K3 + Kd)):
+    with _prof(_lin_tag("linbn_scale_banks", Cn, K3 + Kd), 0.0, _sz(dtype) * (1 + views) * Cn * (K3 + Kd)):
         check(_lib.load().sm3_linbn_scale_banks(dtype, _ptr(w3), K3, _ptr(scale3), _ptr(shift3), _ptr(out3), _ptr(wd), Kd,
                                                 _ptr(scaled), _ptr(shiftd), _ptr(outd), _ptr(bias), Cn, views, _stream()),
               "sm3_linbn_scale_banks")
@@ -570,7 +576,7 @@ def linbn_stats(dtype, P, w_fwd, mean, invstd, gamma, reduce_ws, groups, lsums, 
             lsums.numel() < views * 2 * Cn or reduce_ws.numel() < views * groups * 2 * Cn or \
             (count > 0 and (coef is None or coef.numel() < views * 4 * Cn)):
         raise ValueError("linbn_stats: size mismatch")
-    with _prof("linbn_small", 0.0, 4.0 * views * Cn * p):
+    with _prof(_lin_tag("linbn_stats", Cn, p), 0.0, 4.0 * views * Cn * p):
         check(_lib.load().sm3_linbn_stats(dtype, _ptr(P), _ptr(w_fwd), _ptr(mean), _ptr(invstd), _ptr(gamma),
                                           _ptr(reduce_ws), groups, _ptr(lsums), _ptr(dgamma), _ptr(dbeta), float(count),
                                           _ptr(coef), Cn, p, views, _stream()), "sm3_linbn_stats")
@@ -593,7 +599,7 @@ def linbn_banks(dtype, w_dgrad, coef, wa, wbn, col_const, Cn, p, views=1):
     if w_dgrad.numel() != p * Cn or wa.numel() < views * p * Cn or wbn.numel() < views * p * Cn or \
             col_const.numel() < views * p or coef.numel() < views * 4 * Cn:
         raise ValueError("linbn_banks: size mismatch")
-    with _prof("linbn_small", 0.0, _sz(dtype) * p * Cn * (1 + 2 * views)):
+    with _prof(_lin_tag("linbn_banks", Cn, p), 0.0, _sz(dtype) * p * Cn * (1 + 2 * views)):
         check(_lib.load().sm3_linbn_banks(dtype, _ptr(w_dgrad), _ptr(coef), _ptr(wa), _ptr(wbn), _ptr(col_const), Cn, p,
                                           views, _stream()), "sm3_linbn_banks")
 
@@ -613,7 +619,7 @@ def linbn_post(dtype, wbn, w_dgrad, hn, P, G, Tm, s, coef, dw, Cn, p, views=1):
             coef.numel() < views * 4 * Cn or dw.numel() != Cn * p or Cn % 128 or p % 32:
         raise ValueError("linbn_post: size mismatch")
     flops = 2.0 * views * p * p * Cn * (1 if Tm is not None else 2)
-    with _prof("linbn_small", flops, 4.0 * Cn * p * (2 + views) + _sz(dtype) * p * Cn * (1 + views)):
+    with _prof(_lin_tag("linbn_post", Cn, p), flops, 4.0 * Cn * p * (2 + views) + _sz(dtype) * p * Cn * (1 + views)):
         check(_lib.load().sm3_linbn_post(dtype, _ptr(wbn), _ptr(w_dgrad), _ptr(hn), _ptr(P), _ptr(G), _ptr(Tm), _ptr(s),
                                          _ptr(coef), _ptr(dw), Cn, p, views, _stream()), "sm3_linbn_post")
 
