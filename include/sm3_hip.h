@@ -292,6 +292,9 @@ int sm3_linbn_coef(const double* global_sums, double count, const float* gamma, 
  * col_const [views][p] = (b mu - a m1) W, summed over the rounded products. */
 int sm3_linbn_banks(int dtype, const void* w_dgrad, const float* coef, void* wa, void* wbn, float* col_const, int C, int p,
                     int views, void* stream);
+/* out[v][e] = sum over the `groups` partial rows of sums_ws [views][groups][n] (n = 2C), fixed order: what a data-parallel
+ * run exchanges between ranks (then sm3_bn_finalize with groups = 1). */
+int sm3_linbn_fold(const double* sums_ws, int groups, int n, int views, double* out, void* stream);
 /* out3[v][c][:] = scale3[v][c] w3[c][:] ([C][K3] banks), outd[v][c][:] = scaled[v][c] wd[c][:] ([C][Kd]), and
  * bias[v][c] = shift3[v][c] + shiftd[v][c]: what sm3_conv_seg_act needs to run conv3 + bn3 + downsample conv + its BatchNorm
  * + add + ReLU as one two-segment GEMM. */

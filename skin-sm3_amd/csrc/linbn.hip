@@ -158,6 +158,20 @@ __global__ __launch_bounds__(256) void linbn_fwd_stats_kernel(const float* __res
     }
 }
 
+// ---- sm3_linbn_fold -------------------------------------------------------------------------------------------------
+// out[v][e] = sum_g ws[v][g][e] in a fixed order: the partial rows sm3_linbn_fwd_stats left, folded BEFORE a data-parallel
+// exchange so that ranks trade [views][2C] sums per BatchNorm, not [views][p/32][2C].
+__global__ __launch_bounds__(256) void linbn_fold_kernel(const double* __restrict__ ws, int groups, int n, int views,
+                                                         double* __restrict__ out) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)views * n) return;
+    const int v = (int)(e / n);
+    const double* src = ws + (long)v * groups * n + (e - (long)v * n);
+    double a = 0.0;
+    for (int g = 0; g < groups; ++g) a += src[(long)g * n];
+    out[e] = a;
+}
+
 // ---- sm3_linbn_stats ------------------------------------------------------------------------------------------------
 // one wave per (view, channel): S1 = sum over the `groups` rows stage A of sm3_bn_stats_reduce left in ws (its stage B,
 // folded in here), S2 = invstd (rowdot(W[co], P_v[co]) - mu S1); lsums[v] = (S1 | S2); dgamma += S2, dbeta += S1.
@@ -397,6 +411,14 @@ extern "C" int sm3_linbn_fwd_stats(int dtype, const float* G, const void* w_dgra
     else
         hipLaunchKernelGGL(linbn_fwd_stats_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, G, (const f16_t*)w_dgrad,
                            (const f16_t*)w_fwd, s, Tm, sums_ws, C, p, views);
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_linbn_fold(const double* sums_ws, int groups, int n, int views, double* out, void* stream) {
+    if (!sums_ws || !out || groups < 1 || n <= 0 || views < 1) return SM3_EINVAL;
+    hipLaunchKernelGGL(linbn_fold_kernel, dim3((unsigned)(((long)views * n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       sums_ws, groups, n, views, out);
     SM3_CHECK_LAUNCH();
     return 0;
 }

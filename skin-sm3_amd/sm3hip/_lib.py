@@ -61,6 +61,7 @@ SIGNATURES = {
     "sm3_conv_dgrad_seg_bnfuse": [_DESC, _P, _P, _P, _P, _P, _P, _P],
     "sm3_conv_gather_gemm_seg": [_DESC, _P, _P, _P, _P, _P, _P],
     "sm3_conv_seg_act": [_DESC, _P, _P, _P, _I, _P, _P, _P],
+    "sm3_linbn_fold": [_P, _I, _I, _I, _P, _P],
     "sm3_linbn_scale_banks": [_I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P],
     "sm3_subsample_colsum_rows": [_L, _I, _I],
     "sm3_subsample_colsum": [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

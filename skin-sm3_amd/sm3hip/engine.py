@@ -160,6 +160,9 @@ class BNUnit:
         self.name, self.C, self.affine = name, C, affine
 
 
+_LANE_SKEW = int(_os.environ.get("SM3_LANE_SKEW", "0"))
+
+
 class Rec:
     """What one conv+BN(+act) application saves for backward."""
     __slots__ = ("cu", "bu", "N", "H", "W", "Ho", "Wo", "x_in", "xo", "mean", "invstd", "y", "relu", "mask", "V",
@@ -402,6 +405,8 @@ class SM3Engine:
                 self.ctx.__enter__()
                 self.pin = ops.stream_scope()  # the lane's raw stream handle, looked up once per lane entry
                 self.pin.__enter__()
+                if _LANE_SKEW and self.key.startswith("clinic"):  # experiment: phase shift between the two lanes
+                    torch.cuda._sleep(_LANE_SKEW)
             return self
 
         def __exit__(self, *exc):
@@ -698,7 +703,11 @@ class SM3Engine:
         ops.linbn_fwd_stats(self.dtype, r2.gram, cu.w_dgrad, cu.w_fwd, r2.colsum, Tm, ws, C, p, V)
         count = rows_v
         if self.stat_sync is not None:
-            self.stat_sync(ws[: V * groups * 2 * C])  # SyncBatchNorm: the partial rows add up over ranks like the sums
+            # SyncBatchNorm: fold the partial rows first, so that ranks exchange [V][2C] sums as the two-pass form does
+            gs = self._work("linbn_fold", 2 * V * 2 * C, torch.float64)
+            ops.linbn_fold(ws, groups, 2 * C, gs, views=V)
+            self.stat_sync(gs[: V * 2 * C])
+            ws, groups = gs, 1
             count = rows_v * self.world_size
         scale, shift = self._work("scale", 2 * 2048), self._work("shift", 2 * 2048)
         mean = torch.empty(V * C, dtype=torch.float32, device=dev)
@@ -761,12 +770,19 @@ class SM3Engine:
         ops.linbn_fwd_stats(self.dtype, r2.gram, c3.w_dgrad, c3.w_fwd, r2.colsum, Tm3, ws[:n3], C, p, V)
         ops.linbn_fwd_stats(self.dtype, Gd, cd.w_dgrad, cd.w_fwd, sd, Tmd, ws[n3: n3 + nd], C, Cin, V)
         count = rows_v
+        units = ((b3, ws[:n3], g3, ""), (bd, ws[n3: n3 + nd], gd, "_d"))
         if self.stat_sync is not None:
-            self.stat_sync(ws[: n3 + nd])  # SyncBatchNorm: one exchange for the two units
+            # SyncBatchNorm: partial rows folded first, then ONE exchange of [bn3 | downsample][V][2C] sums for the two units
+            nf = V * 2 * C
+            gs = self._work("linbn_fold", 2 * nf, torch.float64)
+            ops.linbn_fold(ws[:n3], g3, 2 * C, gs[:nf], views=V)
+            ops.linbn_fold(ws[n3: n3 + nd], gd, 2 * C, gs[nf: 2 * nf], views=V)
+            self.stat_sync(gs[: 2 * nf])
+            units = ((b3, gs[:nf], 1, ""), (bd, gs[nf: 2 * nf], 1, "_d"))
             count = rows_v * self.world_size
         track = not self.__dict__.get("_no_stat_update", False)
         out = []
-        for bu, wsl, groups, tag in ((b3, ws[:n3], g3, ""), (bd, ws[n3: n3 + nd], gd, "_d")):
+        for bu, wsl, groups, tag in units:
             scale, shift = self._work("scale" + tag, 2 * 2048), self._work("shift" + tag, 2 * 2048)
             mean = torch.empty(V * C, dtype=torch.float32, device=dev)
             invstd = torch.empty(V * C, dtype=torch.float32, device=dev)

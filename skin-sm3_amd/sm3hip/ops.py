@@ -546,6 +546,15 @@ def linbn_fwd_stats(dtype, G, w_dgrad, w_fwd, s, Tm, sums_ws, Cn, p, views=1):
     return p // 32
 
 
+def linbn_fold(sums_ws, groups, n, out, views=1):
+    """out[v] = sum of the `groups` partial rows of sums_ws [views][groups][n] (sm3_linbn_fold)."""
+    _chk(sums_ws, torch.float64, "sums_ws"); _chk(out, torch.float64, "out")
+    if sums_ws.numel() < views * groups * n or out.numel() < views * n:
+        raise ValueError("linbn_fold: size mismatch")
+    with _prof(_lin_tag("linbn_fold", n, groups), 0.0, 8.0 * views * n * (groups + 1)):
+        check(_lib.load().sm3_linbn_fold(_ptr(sums_ws), groups, n, views, _ptr(out), _stream()), "sm3_linbn_fold")
+
+
 def linbn_scale_banks(dtype, w3, scale3, shift3, out3, wd, scaled, shiftd, outd, bias, Cn, views=1):
     """out3[v] = diag(scale3[v]) w3, outd[v] = diag(scaled[v]) wd, bias[v] = shift3[v] + shiftd[v] (sm3_linbn_scale_banks)."""
     tdt = TORCH_DTYPE[dtype]

@@ -48,8 +48,10 @@ class _AllGatherRows(torch.autograd.Function):
         return g[r * ctx.n:(r + 1) * ctx.n]
 
 
-def _rank_main(rank, world, port, q, Bl=4, global_neg=False):
+def _rank_main(rank, world, port, q, Bl=4, global_neg=False, dt="f32", linbn=None):
     try:
+        if linbn is not None:
+            os.environ["SM3_LINBN"] = "1" if linbn else "0"
         for p in (ROOT, os.path.join(ROOT, "skin-sm3_amd"), os.path.join(ROOT, "tests")):
             if p not in sys.path:
                 sys.path.insert(0, p)
@@ -81,13 +83,15 @@ def _rank_main(rank, world, port, q, Bl=4, global_neg=False):
         dev = torch.device("cuda:0")
         model = SimCLRSkinV32("resnet50", None, 128, T)
         model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
-        model.sm3_dtype = torch.float32
+        model.sm3_dtype = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[dt]
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model).to(dev)
         tr = SM3Trainer(model, lr=lr, global_negatives=global_neg)
         assert tr.dp and tr.sync_bn and tr.world == world
         loss = tr.step([torch.from_numpy(a[sl]).to(dev) for a in derm_np], [torch.from_numpy(a[sl]).to(dev) for a in clinic_np])
         torch.cuda.synchronize()
         eng = tr._engine()
+        if linbn is not None:
+            assert eng.linbn == bool(linbn)
         assert eng.pair_ok(Bl, size, size) == (Bl % 32 == 0)  # 32 per rank: both views of a branch as one batch
         names = eng.store.names
         g = torch.cat([v.reshape(-1).double().cpu() for v in eng.store.grad_views()]) / world  # AdamW applies 1/world
@@ -97,6 +101,7 @@ def _rank_main(rank, world, port, q, Bl=4, global_neg=False):
         out = {
             "loss": float(loss), "loss_ref": float(loss_ref),
             "grad_rel": float((g - gref).norm() / gref.norm()),
+            "grad_cos": float(g @ gref / (g.norm() * gref.norm())),
             "rm_err": max(float((sd[k].double().cpu() - Bf[k]).abs().max()) for k in Bf if k.endswith("running_mean")),
             "rv_rel": max(float(((sd[k].double().cpu() - Bf[k]).abs() / Bf[k].abs().clamp_min(1e-3)).max())
                           for k in Bf if k.endswith("running_var")),
@@ -159,3 +164,42 @@ def test_two_rank_global_negatives_match_the_oracle():
         assert abs(o["loss"] - o["loss_ref"]) < 1e-3, o
         assert o["grad_rel"] < 6e-2, o
     assert abs(res[0]["param_sum"] - res[1]["param_sum"]) < 1e-6 * abs(res[0]["param_sum"]) + 1e-6
+
+
+def _spawn2(args):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q) + args) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, ok, payload = q.get(timeout=900)
+        assert ok, f"rank {r} failed:\n{payload}"
+        res[r] = payload
+    for p in procs:
+        p.join(timeout=60)
+    return res
+
+
+def test_two_rank_dp_bf16_batchnorm_by_linearity_syncs_like_the_two_pass_form():
+    """The 16-bit default runs conv3 / downsample BatchNorms by linearity (csrc/linbn.hip): in a data-parallel run their
+    forward statistics are exchanged as folded [views][2C] moment sums (sm3_linbn_fold) and their backward sums through
+    linbn_stats / linbn_coef.  Two ranks on real kernels, bf16, both views in one batch -- against the same run with
+    SM3_LINBN=0 (the two-pass SyncBN form the f32 test above validates against the sharded oracle): running statistics
+    are those of the GLOBAL batch, replicas stay in sync, and the distance to the fp64 sharded oracle is no larger."""
+    on = _spawn2((32, False, "bf16", True))
+    off = _spawn2((32, False, "bf16", False))
+    for res in (on, off):
+        assert abs(res[0]["param_sum"] - res[1]["param_sum"]) < 1e-6 * abs(res[0]["param_sum"]) + 1e-6
+        for r in (0, 1):
+            assert res[r]["nbt"] == 2
+    for r in (0, 1):
+        a, b = on[r], off[r]
+        print(f"rank {r}: linear {a}\n        two-pass {b}")
+        assert abs(a["loss"] - a["loss_ref"]) < max(1.5 * abs(b["loss"] - b["loss_ref"]), 0.1), (a, b)
+        assert a["rm_err"] < 1.5 * b["rm_err"] + 1e-3 and a["rv_rel"] < 1.5 * b["rv_rel"] + 1e-2, (a, b)
+        # bf16 at this random-init state: gradient cosine against fp64 is ~0.12-0.17 for torch's own autocast too (see
+        # test_config_gpu.py T2), so only "no worse than the two-pass form" is asked
+        assert a["grad_cos"] > b["grad_cos"] - 0.1 and a["grad_cos"] > 0.05, (a, b)

@@ -184,12 +184,23 @@ def test_bf16_path_T1(golden_dir):
             feats[dt] = model.extract(derm[0], clinic[0])[0].double()
     rel = (feats[torch.bfloat16] - feats[torch.float32]).norm() / feats[torch.float32].norm()
     assert float(rel) < 3e-2, float(rel)
-    model = _build(seed, torch.bfloat16)
-    tr = SM3Trainer(model, lr=1e-3, style=style)
-    loss = tr.step(derm, clinic)
-    torch.cuda.synchronize()
-    assert np.isfinite(float(loss)) and abs(float(loss) - float(g["loss"])) < 1.0
-    assert bool(torch.isfinite(tr._engine().store.flat_g).all())
+    # The training step against the reference's fp64 goldens at B = 8 (style 1) and B = 32 (style 0).  NOT at the B = 4
+    # golden: with 4 pairs the deepest BatchNorms normalise over 16 rows and the loss moves by O(1) with the placement of
+    # 16-bit roundings -- measured there (golden 5.360): bf16 5.349 / 4.843 / 4.231 and fp16 6.346 / 6.341 / 6.160 for the
+    # two-pass BatchNorm form / conv3 by linearity / + the downsample join (scratch/t1_variants.py), i.e. the *more*
+    # precise fp16 type is off by 1.0 in every form.  From B = 8 on the 16-bit steps sit within 0.02-0.35 of fp64.
+    for tag, bound16 in (("b8_s64_style1_f64", 0.5), ("b32_s64_f64", 0.5)):
+        g = _load(golden_dir, tag)
+        batch, size, seed, style = [int(v) for v in g["meta"]]
+        derm, clinic = _batch(batch, size, seed)
+        for dt, bound in ((torch.bfloat16, bound16), (torch.float16, 0.15)):
+            model = _build(seed, dt)
+            tr = SM3Trainer(model, lr=1e-3, style=style, init_scale=1024.0)
+            loss = tr.step(derm, clinic)
+            torch.cuda.synchronize()
+            assert np.isfinite(float(loss)) and abs(float(loss) - float(g["loss"])) < bound, (tag, dt, float(loss), float(g["loss"]))
+            assert bool(torch.isfinite(tr._engine().store.flat_g).all())
+            del tr, model
 
 
 def test_batch_permutation_invariance_224():

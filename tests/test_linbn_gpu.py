@@ -186,7 +186,8 @@ def _unit_reference(y, W, gamma, beta, dz, eps=1e-5):
 
 
 @pytest.mark.parametrize("dt", DTS, ids=IDS)
-@pytest.mark.parametrize("case", [(1, 1280, 256, 64), (2, 1024, 256, 64), (2, 640, 512, 128), (2, 256, 1024, 256)])
+@pytest.mark.parametrize("case", [(1, 1280, 256, 64), (2, 1024, 256, 64), (2, 640, 512, 128), (2, 256, 1024, 256),
+                                  (1, 16, 2048, 512), (1, 64, 1024, 256), (1, 48, 256, 64)])
 def test_conv_bn_by_linearity_matches_fp64_autograd(case, dt):
     """The launch sequences of SM3Engine.conv3_bn3_fused / conv3_backward_linbn on one conv3 -> bn3 unit against fp64
     PyTorch of conv1x1 -> BatchNorm2d(train) (-> + identity -> ReLU) (src/models/resnet.py:162-172) on the same (rounded)
@@ -449,7 +450,8 @@ def test_two_segment_gemm_without_a_fused_batchnorm(case, addend, dt):
 
 
 @pytest.mark.parametrize("dt", DTS, ids=IDS)
-@pytest.mark.parametrize("case", [(1, 640, 256, 64, 128), (2, 512, 512, 128, 256), (2, 128, 2048, 512, 1024)])
+@pytest.mark.parametrize("case", [(1, 640, 256, 64, 128), (2, 512, 512, 128, 256), (2, 128, 2048, 512, 1024),
+                                  (1, 16, 2048, 512, 1024), (1, 64, 1024, 256, 512)])
 def test_join_of_a_downsample_block_by_linearity(case, dt):
     """The forward join of a Bottleneck with a downsample branch (resnet.py:162-172) as the engine's join_fused runs it:
     batch statistics of bn3 and of the downsample BatchNorm from the moments of their convolutions' inputs
