@@ -160,9 +160,6 @@ class BNUnit:
         self.name, self.C, self.affine = name, C, affine
 
 
-_LANE_SKEW = int(_os.environ.get("SM3_LANE_SKEW", "0"))
-
-
 class Rec:
     """What one conv+BN(+act) application saves for backward."""
     __slots__ = ("cu", "bu", "N", "H", "W", "Ho", "Wo", "x_in", "xo", "mean", "invstd", "y", "relu", "mask", "V",
@@ -405,8 +402,6 @@ class SM3Engine:
                 self.ctx.__enter__()
                 self.pin = ops.stream_scope()  # the lane's raw stream handle, looked up once per lane entry
                 self.pin.__enter__()
-                if _LANE_SKEW and self.key.startswith("clinic"):  # experiment: phase shift between the two lanes
-                    torch.cuda._sleep(_LANE_SKEW)
             return self
 
         def __exit__(self, *exc):
