@@ -40,8 +40,8 @@ int sm3_abi_version(void);
 /* ------------------------------------------------------------------------------------------
  * Gather-GEMM convolution: forward conv, data-gradient of a conv, and bias-free Linear.
  *   replaces nn.Conv2d forward/backward-data  (src/models/resnet.py:49-67 conv3x3/conv1x1, used at
- *   :144-148,:260; the 7x7 stem :208-210 runs on sm3_stem_conv_fwd straight from the images in the 16-bit modes and
- *   through sm3_stem_im2col + this GEMM in the exact-f32 parity mode) and nn.Linear(bias=False)
+ *   :144-148,:260; the 7x7 stem :208-210 runs on sm3_stem_conv_fwd straight from the images in all three arithmetic
+ *   modes -- sm3_stem_im2col + this GEMM remain as the SM3_DIRECT_STEM=0 A/B path) and nn.Linear(bias=False)
  *   (src/models/simclr.py:17-27).
  *
  *   y[n, oy*osy+ooy, ox*osx+oox, co] = sum_t sum_ci x[n, oy*sy+dy[t], ox*sx+dx[t], ci]
@@ -313,8 +313,8 @@ int sm3_linbn_post(int dtype, const void* wbn, const void* w_dgrad, void* hn, co
 /* 7x7/2 pad-3 im2col of an NCHW fp32 image batch into rows [N*Ho*Wo, Kpad] of dtype,
  * k = (kh*7+kw)*3 + c for k < 147, zero for 147 <= k < Kpad. */
 int sm3_stem_im2col(int dtype, const float* x_nchw, void* cols, int N, int H, int W, int Kpad, void* stream);
-/* Direct stem (bf16 only; the exact-f32 parity mode keeps sm3_stem_im2col + sm3_conv_gather_gemm): the 7x7/2 pad-3
- * convolution straight from the NCHW fp32 images, no im2col matrix in HBM.
+/* Direct stem (bf16 / fp16 on the 16-bit MFMA; SM3_F32 on v_mfma_f32_32x32x2_f32, fp32 patch fragments and filter bank):
+ * the 7x7/2 pad-3 convolution straight from the NCHW fp32 images, no im2col matrix in HBM.
  *   w_stem: dtype [64][176] from sm3_stem_weight_prep (K order (kh, c, kw padded to 8); master is [64][kh][kw][c]);
  *   y: [N*Ho*Wo, 64] dtype; stat_partials (nullable): [sm3_stem_partial_rows][2][64], one row per tile of <= 128
  *   output pixels of one output row -- tiles are image-major, so a view's rows are contiguous. */

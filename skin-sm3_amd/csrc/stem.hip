@@ -351,6 +351,221 @@ __global__ void stem_weight_prep_kernel(const float* __restrict__ w, T* __restri
     out[i].v = (uint16_t)pack2<T>(v, 0.f);
 }
 
+
+// ---- exact-f32 mode: the same two kernels on v_mfma_f32_32x32x2_f32 ------------------------------------------------
+// K is still ordered (group g, kw padded to 8); one sm3conv::mma_frag<float> call (four MFMAs, K = 8) covers exactly one
+// group: lane (pixel px, half h) supplies patch row g, columns 2 px + 4 h + {0..3}; the filter bank is fp32 [64][176] in
+// the same order, kept in LDS at a pitch of 172 floats (the 16 rows of a ds_read_b128 group fall on 16 distinct 16-byte
+// slots).  The output tile goes from the accumulators straight to HBM (32 consecutive channels = 128 B per lane group):
+// 128 pixels x 64 fp32 do not fit the patch's LDS.
+constexpr int WPF = 172;
+
+__global__ __launch_bounds__(256, 2) void stem_fwd_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              float* __restrict__ y, float* __restrict__ partials, int N,
+                                                              int H, int W, int Ho, int Wo, int xblocks, long tiles) {
+    __shared__ __attribute__((aligned(16))) float patch[NG * PW];
+    __shared__ float sStat[4][64][2];
+    __shared__ __attribute__((aligned(16))) float sW[64 * WPF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    for (int i = tid; i < 64 * (NG * 8 / 4); i += 256) {  // 168 floats per filter, 16 bytes at a time
+        const int co = i / (NG * 2), c4 = i - co * (NG * 2);
+        *reinterpret_cast<float4*>(&sW[co * WPF + c4 * 4]) = *reinterpret_cast<const float4*>(w + (long)co * KPAD + c4 * 4);
+    }
+    const float* wlane = &sW[col * WPF + 4 * h];
+
+    PatchRegs pre;
+    if ((long)blockIdx.x < tiles) {
+        load_patch(pre, x, decode_tile(blockIdx.x, xblocks, Ho), H, W);
+        store_patch(patch, pre);
+    }
+    __syncthreads();
+    for (long t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const StemTile tl = decode_tile(t, xblocks, Ho);
+        const long tn = t + gridDim.x;
+        if (tn < tiles) load_patch(pre, x, decode_tile(tn, xblocks, Ho), H, W);  // lands during this tile's compute
+        f32x16 acc[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+        const int px = 32 * wave + col;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const float2* src = reinterpret_cast<const float2*>(patch + g * PW + 2 * px + 4 * h);
+            const float2 v0 = src[0], v1 = src[1];
+            const uint4 a = make_uint4(__float_as_uint(v0.x), __float_as_uint(v0.y), __float_as_uint(v1.x), __float_as_uint(v1.y));
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                sm3conv::mma_frag<float>(a, *reinterpret_cast<const uint4*>(wlane + nb * 32 * WPF + g * 8), acc[nb]);
+        }
+        const long pix0 = ((long)tl.n * Ho + tl.oy) * Wo + tl.x0;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (tl.x0 + row < Wo) {
+                    const float v = acc[nb][r];
+                    y[(pix0 + row) * 64 + nb * 32 + col] = v;
+                    s1 += v;
+                    s2 += v * v;
+                }
+            }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 32) {
+                sStat[wave][nb * 32 + lane][0] = s1;
+                sStat[wave][nb * 32 + lane][1] = s2;
+            }
+        }
+        __syncthreads();  // statistics visible; everyone is done reading the patch
+        if (partials && tid < 128) {
+            const int c = tid & 63, st = tid >> 6;
+            partials[(t * 2 + st) * 64 + c] = (sStat[0][c][st] + sStat[1][c][st]) + (sStat[2][c][st] + sStat[3][c][st]);
+        }
+        if (tn < tiles) store_patch(patch, pre);
+        __syncthreads();
+    }
+}
+
+// dW[co][k] = sum_pixels dxo[pix][co] patch[pix][k], pixel axis as the MFMA K (8 pixels per mma_frag<float>); the dxo
+// tile is fp32 [128 pixels][64 co] in LDS, written with the BatchNorm-backward apply on the fly as in the 16-bit kernel.
+__global__ __launch_bounds__(256, 2) void stem_wgrad_f32_kernel(const StemWgradParams p) {
+    __shared__ __attribute__((aligned(16))) float patch[NG * PW];
+    __shared__ __attribute__((aligned(16))) float sD[128 * 64];
+    __shared__ __attribute__((aligned(16))) float sCoef[3][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cb = wave & 1, kb0 = 3 * (wave >> 1);  // this wave: co block cb, k blocks kb0 .. kb0+2
+    const int r = lane & 31, h = lane >> 5;
+
+    if (blockIdx.x == 0 && tid < 64 && p.lsums) {  // parameter gradients of bn1 from the LOCAL sums, once
+        for (int v = 0; v < p.views; ++v) {
+            if (p.dbeta) atomicAdd(&p.dbeta[tid], (float)p.lsums[v * 128 + tid]);
+            if (p.dgamma) atomicAdd(&p.dgamma[tid], (float)p.lsums[v * 128 + 64 + tid]);
+        }
+    }
+    f32x16 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+
+    const int v16 = tid & 15, r0 = tid >> 4;  // staging role: channels 4 v16 .. +3 of rows r0 + 16 k
+    int cur_view = -1;
+    const float* dzf = reinterpret_cast<const float*>(p.dz);
+    const float* xof = reinterpret_cast<const float*>(p.xo);
+    PatchRegs pre;
+    auto store_tile = [&](const StemTile& tl) {
+        const int view = tl.n / p.n_per_view;
+        if (view != cur_view) {  // block-uniform
+            cur_view = view;
+            if (tid < 64) {
+                const int c = tid;
+                const float is = p.invstd[view * 64 + c];
+                const float g = p.gamma ? p.gamma[c] : 1.f;
+                const float k0c = g * is;
+                const float k1c = (float)(p.gsums[view * 128 + c] * p.inv_count);
+                const float qc = k0c * is * (float)(p.gsums[view * 128 + 64 + c] * p.inv_count);
+                sCoef[0][c] = k0c;
+                sCoef[1][c] = qc;
+                sCoef[2][c] = qc * p.mean[view * 64 + c] - k0c * k1c;
+            }
+            __syncthreads();
+        }
+        store_patch(patch, pre);
+        const float4 cA = *reinterpret_cast<const float4*>(&sCoef[0][v16 * 4]);
+        const float4 cB = *reinterpret_cast<const float4*>(&sCoef[1][v16 * 4]);
+        const float4 cC = *reinterpret_cast<const float4*>(&sCoef[2][v16 * 4]);
+        const long pix0 = ((long)tl.n * p.Ho + tl.oy) * p.Wo + tl.x0;
+#pragma unroll
+        for (int kb = 0; kb < 8; kb += 4) {  // four rows in flight
+            float4 gv[4], xv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = r0 + 16 * (kb + k);
+                const bool ok = tl.x0 + row < p.Wo;
+                gv[k] = ok ? *reinterpret_cast<const float4*>(dzf + (pix0 + row) * 64 + v16 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                xv[k] = ok ? *reinterpret_cast<const float4*>(xof + (pix0 + row) * 64 + v16 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = r0 + 16 * (kb + k);
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (tl.x0 + row < p.Wo) {
+                    o.x = cA.x * gv[k].x - cB.x * xv[k].x + cC.x;
+                    o.y = cA.y * gv[k].y - cB.y * xv[k].y + cC.y;
+                    o.z = cA.z * gv[k].z - cB.z * xv[k].z + cC.z;
+                    o.w = cA.w * gv[k].w - cB.w * xv[k].w + cC.w;
+                }
+                *reinterpret_cast<float4*>(&sD[row * 64 + v16 * 4]) = o;
+            }
+        }
+    };
+    if ((long)blockIdx.x < p.tiles) {
+        const StemTile t0 = decode_tile(blockIdx.x, p.xblocks, p.Ho);
+        load_patch(pre, p.x, t0, p.H, p.W);
+        store_tile(t0);
+    }
+    for (long t = blockIdx.x; t < p.tiles; t += gridDim.x) {
+        const long tn = t + gridDim.x;
+        StemTile nx = {0, 0, 0};
+        if (tn < p.tiles) {
+            nx = decode_tile(tn, p.xblocks, p.Ho);
+            load_patch(pre, p.x, nx, p.H, p.W);  // in flight during this tile's MFMA loop
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {  // 8 pixels per step: lane (r, h) holds pixels 8 s + 4 h + {0..3}
+            const int pb = 8 * s + 4 * h;
+            const float* ap = sD + pb * 64 + cb * 32 + r;
+            const uint4 fa = make_uint4(__float_as_uint(ap[0]), __float_as_uint(ap[64]), __float_as_uint(ap[128]),
+                                        __float_as_uint(ap[192]));
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int k = 32 * (kb0 + j) + r;
+                const int g = k >> 3, kw = k & 7;
+                uint4 fb = make_uint4(0, 0, 0, 0);
+                if (g < NG) {
+                    const float* src = patch + g * PW + 2 * pb + kw;
+                    fb = make_uint4(__float_as_uint(src[0]), __float_as_uint(src[2]), __float_as_uint(src[4]),
+                                    __float_as_uint(src[6]));
+                }
+                sm3conv::mma_frag<float>(fa, fb, acc[j]);
+            }
+        }
+        __syncthreads();  // everyone is done reading this tile's operands
+        if (tn < p.tiles) store_tile(nx);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int k = 32 * (kb0 + j) + r;
+        const int g = k >> 3, kw = k & 7;
+        if (g >= NG || kw >= 7) continue;
+        const int kh = g / 3, c = g - 3 * kh;
+        const int kcol = (kh * 7 + kw) * 3 + c;  // master layout [co][kh][kw][c]
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int co = cb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            atomicAdd(p.dw + co * 147 + kcol, acc[j][q]);
+        }
+    }
+}
+
+__global__ void stem_weight_prep_f32_kernel(const float* __restrict__ w, float* __restrict__ out, const int* __restrict__ only_if) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 64 * KPAD || (only_if && *only_if == 0)) return;
+    const int co = i / KPAD, k = i - co * KPAD;
+    const int g = k >> 3, kw = k & 7;
+    float v = 0.f;
+    if (g < NG && kw < 7) {
+        const int kh = g / 3, c = g - 3 * kh;
+        v = w[co * 147 + (kh * 7 + kw) * 3 + c];
+    }
+    out[i] = v;
+}
+
 int stem_geometry(int N, int H, int W, int& Ho, int& Wo, int& xblocks, long& tiles) {
     if (N <= 0 || H <= 0 || W <= 0) return SM3_EINVAL;
     Ho = (H - 1) / 2 + 1;
@@ -378,6 +593,9 @@ extern "C" int sm3_stem_weight_prep_if(int dtype, const float* w_master, void* w
     else if (dtype == SM3_F16)
         hipLaunchKernelGGL(stem_weight_prep_kernel<f16_t>, dim3((64 * KPAD + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                            w_master, (f16_t*)w_stem, only_if);
+    else if (dtype == SM3_F32)
+        hipLaunchKernelGGL(stem_weight_prep_f32_kernel, dim3((64 * KPAD + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                           w_master, (float*)w_stem, only_if);
     else
         return SM3_EDTYPE;
     SM3_CHECK_LAUNCH();
@@ -391,10 +609,17 @@ extern "C" int sm3_stem_weight_prep(int dtype, const float* w_master, void* w_st
 extern "C" int sm3_stem_conv_fwd(int dtype, const float* x_nchw, const void* w_stem, void* y, float* stat_partials, int N,
                                  int H, int W, void* stream) {
     if (!x_nchw || !w_stem || !y) return SM3_EINVAL;
-    if (dtype != SM3_BF16 && dtype != SM3_F16) return SM3_EDTYPE;  // the exact-f32 parity mode keeps im2col + gather-GEMM
+    if (dtype != SM3_BF16 && dtype != SM3_F16 && dtype != SM3_F32) return SM3_EDTYPE;
     int Ho, Wo, xb;
     long tiles;
     if (int rc = stem_geometry(N, H, W, Ho, Wo, xb, tiles)) return rc;
+    if (dtype == SM3_F32) {  // exact-f32 parity mode: two workgroups per CU (68 KB of LDS each)
+        const unsigned gridf = (unsigned)(tiles < 512 ? tiles : 512);
+        hipLaunchKernelGGL(stem_fwd_f32_kernel, dim3(gridf), dim3(256), 0, (hipStream_t)stream, x_nchw, (const float*)w_stem,
+                           (float*)y, stat_partials, N, H, W, Ho, Wo, xb, tiles);
+        SM3_CHECK_LAUNCH();
+        return 0;
+    }
     const unsigned grid = (unsigned)(tiles < 768 ? tiles : 768);  // persistent: 3 workgroups per CU (136 VGPRs)
     if (dtype == SM3_BF16)
         hipLaunchKernelGGL(stem_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x_nchw,
@@ -412,13 +637,19 @@ extern "C" int sm3_stem_wgrad_bn(int dtype, const float* x_nchw, const void* dz,
                                  int views, void* stream) {
     if (!x_nchw || !dz || !xo || !mean || !invstd || !global_sums || !dw || count <= 0 || views < 1 || N % views)
         return SM3_EINVAL;
-    if (dtype != SM3_BF16 && dtype != SM3_F16) return SM3_EDTYPE;
+    if (dtype != SM3_BF16 && dtype != SM3_F16 && dtype != SM3_F32) return SM3_EDTYPE;
     StemWgradParams p;
     if (int rc = stem_geometry(N, H, W, p.Ho, p.Wo, p.xblocks, p.tiles)) return rc;
     p.x = x_nchw; p.dz = (const char*)dz; p.xo = (const char*)xo;
     p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.gsums = global_sums; p.lsums = local_sums;
     p.dgamma = dgamma; p.dbeta = dbeta; p.dw = dw; p.inv_count = 1.0 / count;
     p.N = N; p.H = H; p.W = W; p.n_per_view = N / views; p.views = views;
+    if (dtype == SM3_F32) {
+        const unsigned gridf = (unsigned)(p.tiles < 512 ? p.tiles : 512);
+        hipLaunchKernelGGL(stem_wgrad_f32_kernel, dim3(gridf), dim3(256), 0, (hipStream_t)stream, p);
+        SM3_CHECK_LAUNCH();
+        return 0;
+    }
     const unsigned grid = (unsigned)(p.tiles < 768 ? p.tiles : 768);
     if (dtype == SM3_BF16)
         hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);

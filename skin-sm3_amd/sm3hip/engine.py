@@ -284,8 +284,9 @@ class SM3Engine:
         self.two_streams = True
         self._streams, self._streams_dev = None, None
         # 7x7 stem straight from the NCHW images (csrc/stem.hip): no im2col matrix, BN-backward apply fused into the
-        # stem weight gradient.  bf16 only; the exact-f32 parity mode keeps im2col + gather-GEMM.
-        self.direct_stem = self.dtype in (SM3_BF16, SM3_F16) and _os.environ.get("SM3_DIRECT_STEM", "1") != "0"
+        # stem weight gradient; 16-bit MFMA in the throughput modes, v_mfma_f32_32x32x2_f32 in the exact-f32 mode
+        # (SM3_DIRECT_STEM=0: the round-1 im2col + gather-GEMM path, kept for A/B runs).
+        self.direct_stem = _os.environ.get("SM3_DIRECT_STEM", "1") != "0"  # all three arithmetic modes (csrc/stem.hip)
         # BatchNorm backward by linearity for conv3 -> bn3 of every Bottleneck (csrc/linbn.hip): no bn3 backward-apply
         # pass and no backward read of conv3's output.  16-bit modes only; the exact-f32 parity mode keeps two passes.
         self.linbn = self.dtype in (SM3_BF16, SM3_F16) and _os.environ.get("SM3_LINBN", "1") != "0"
@@ -1293,7 +1294,7 @@ class SM3Engine:
             pair = (self.pair_views and train and not split and len(imgs) == 2 and imgs[0].shape == imgs[1].shape
                     and self.pair_ok(B, imgs[0].shape[2], imgs[0].shape[3])
                     # the kernels address a tensor with 32-bit buffer offsets below 3 GB; the largest one is the stem's
-                    # im2col matrix (exact-f32 mode) or the 256-channel layer1 maps (direct stem)
+                    # im2col matrix (SM3_DIRECT_STEM=0) or the stem / layer1 maps (direct stem)
                     and 2 * B * ((imgs[0].shape[2] - 1) // 2 + 1) * ((imgs[0].shape[3] - 1) // 2 + 1)
                     * (64 if self.direct_stem else STEM_KPAD) * ops._sz(self.dtype) < 0xC0000000)
             if pair:  # both views as one batch of 2B images (BatchNorm statistics still per view)

@@ -956,7 +956,7 @@ def stem_weight_prep(dtype, w_master, w_stem, only_if=None):
 
 
 def stem_conv_fwd(dtype, x_nchw, w_stem, y, partials=None):
-    """Direct 7x7/2 stem convolution from the NCHW fp32 batch (sm3_stem_conv_fwd; bf16 only)."""
+    """Direct 7x7/2 stem convolution from the NCHW fp32 batch (sm3_stem_conv_fwd; bf16 / fp16 / exact f32)."""
     _chk(x_nchw, torch.float32, "x"); _chk(w_stem, TORCH_DTYPE[dtype], "w_stem"); _chk(y, TORCH_DTYPE[dtype], "y")
     _chk(partials, torch.float32, "partials")
     N, Cc, H, W = x_nchw.shape
@@ -972,7 +972,7 @@ def stem_conv_fwd(dtype, x_nchw, w_stem, y, partials=None):
 
 
 def stem_wgrad_bn(dtype, x_nchw, dz, xo, mean, invstd, gamma, gsums, count, lsums, dgamma, dbeta, dw, views=1):
-    """Stem weight gradient with bn1's backward apply fused into the operand load (sm3_stem_wgrad_bn; bf16 only)."""
+    """Stem weight gradient with bn1's backward apply fused into the operand load (sm3_stem_wgrad_bn; bf16 / fp16 / exact f32)."""
     tdt = TORCH_DTYPE[dtype]
     _chk(x_nchw, torch.float32, "x"); _chk(dz, tdt, "dz"); _chk(xo, tdt, "xo"); _chk(dw, torch.float32, "dw")
     for t in (mean, invstd, gamma, dgamma, dbeta):

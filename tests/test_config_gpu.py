@@ -2,7 +2,7 @@
 
   * config 2 at its own size -- B = 256 pairs, 224x224, bf16, both views of a branch in one batch (512 images per
     launch, the largest tensors of the path): identical forward / running statistics to per-view passes, loss against
-    the exact-f32 mode on the same inputs (which still goes through the 2.47 GB stem im2col tensor), finite gradients;
+    the exact-f32 mode on the same inputs (direct stem there too since round 3: no im2col tensor), finite gradients;
   * T2: bf16 vs exact-f32 at random init and from a trained state, with PyTorch's own bf16 autocast of
     the same network (CPU oracle) as the yardstick -- loss, logits, gradient direction;
   * the B = 32 golden generated from the reference itself (oracle/gen_golden.py b32): BatchNorm1d over 32 / 64
@@ -87,7 +87,7 @@ def test_config2_b256_224_bf16():
         runs[key] = (loss, float(gflat.double().norm()), stats)
         del tr, eng, model, gflat
         torch.cuda.empty_cache()
-    # both views as ONE batch of 512 images (2.47 GB im2col tensor, 82 % of the 32-bit-offset limit) == two passes of
+    # both views as ONE batch of 512 images == two passes of
     # 256: forward arithmetic is tile for tile the same -> running statistics bit-identical, loss equal up to the
     # order of the four float-atomic loss terms; weight gradients differ by the summation order of the pixel axis
     assert abs(runs["bf16_pair"][0] - runs["bf16_views"][0]) < 1e-5, (runs["bf16_pair"][0], runs["bf16_views"][0])

@@ -745,10 +745,10 @@ def test_stem_bn_relu_maxpool_fused_equals_separate_kernels(dt, geom):
     assert torch.allclose(s_new, s_ref, rtol=1e-4, atol=1e-3 * float(s_ref.abs().max()))
 
 
-@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32], ids=["bf16", "f16", "f32"])
 @pytest.mark.parametrize("geom", [(3, 30, 26, 1), (4, 64, 64, 2), (2, 45, 270, 1)])
 def test_direct_stem_forward_and_fused_weight_gradient(geom, dt):
-    """csrc/stem.hip (bf16): sm3_stem_conv_fwd against F.conv2d(7x7/2/3) in fp64 on bf16-rounded operands, its BatchNorm
+    """csrc/stem.hip (bf16 / fp16 on the 16-bit MFMA, exact f32 on v_mfma_f32_32x32x2_f32): sm3_stem_conv_fwd against F.conv2d(7x7/2/3) in fp64 on bf16-rounded operands, its BatchNorm
     partial sums against the stored output; sm3_stem_wgrad_bn against conv2d_weight of the BatchNorm input gradient
     computed in fp64 from the same (dz, xo, sums).  Odd sizes, two views, and an image wider than one 128-pixel tile."""
     ops = _ops()
