@@ -37,8 +37,35 @@ namespace {
 //      3 = 2 + the fused BatchNorm-backward phase 1 (ReLU mask, sum dz, sum dz*xhat) of the data-gradient launches.
 //      2 / 3 round the GEMM result to 16 bits BEFORE the addend is added in fp32 -- what autocast does with a convolution
 //      output that is then accumulated -- and keep twice the bytes of 0 in flight per workgroup with half its barriers.
+#ifdef SM3_STAMP
+// Diagnostic build only (scratch/stamp_conv.py builds a second library with -DSM3_STAMP; in the product library no stamp
+// executes): s_memtime at the segment boundaries of the K loop, summed per wave, one 12-word record per wave written to
+// a buffer of its own (sm3_debug_set_stamps) -- no output value depends on a stamp.
+__device__ unsigned long long* g_stamp_buf = nullptr;
+__device__ long g_stamp_cap = 0;
+struct StampRec {
+    unsigned long long t_entry, r_entry, t_loop0 = 0, t_loop1 = 0, seg[4] = {0, 0, 0, 0};
+    int nsteps = 0;
+    __device__ StampRec() : t_entry(__builtin_amdgcn_s_memtime()), r_entry(__builtin_amdgcn_s_memrealtime()) {}
+    __device__ ~StampRec() {
+        const unsigned long long t_exit = __builtin_amdgcn_s_memtime();
+        const long wave = ((long)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x / 64) + (threadIdx.x >> 6);
+        if ((threadIdx.x & 63) == 0 && g_stamp_buf && wave < g_stamp_cap) {
+            unsigned long long* o = g_stamp_buf + wave * 12;
+            o[0] = t_entry; o[1] = t_loop0; o[2] = t_loop1; o[3] = t_exit;
+            o[4] = seg[0]; o[5] = seg[1]; o[6] = seg[2]; o[7] = seg[3];
+            o[8] = (unsigned long long)nsteps; o[9] = blockIdx.x; o[10] = r_entry; o[11] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+};
+#define SM3_STAMP_NOW() __builtin_amdgcn_s_memtime()
+#endif
+
 template <typename T, int BM, int BN, int WM, int WN, int STAGES, int EPI, bool SEG = false>
 __global__ __launch_bounds__(WM* WN * 64, (EPI == 3 ? 4 : 2)) void conv_igemm_kernel(const ConvParams p) {  // EPI 3: 130 -> 128 registers, 4 workgroups per CU
+#ifdef SM3_STAMP
+    StampRec stamp;
+#endif
     constexpr bool LEAN = EPI >= 1;
     static_assert(!(SEG && EPI == 1) && !(SEG && STAGES > 2), "segments: data-gradient epilogues, 1 or 2 stages");
     constexpr int NT = WM * WN * 64;
@@ -225,15 +252,38 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI == 3 ? 4 : 2)) void conv_igemm_ke
     } else if constexpr (STAGES == 2) {
         dma_drain();
         __syncthreads();  // publishes the stage
+#ifdef SM3_STAMP
+        stamp.t_loop0 = SM3_STAMP_NOW();
+        stamp.nsteps = nsteps;
+#endif
         for (int s = 0; s < nsteps; ++s) {
+#ifdef SM3_STAMP
+            const unsigned long long q0 = SM3_STAMP_NOW();
+#endif
             if (s + 1 < nsteps) {
                 advance();
                 dma_stage((s + 1) & 1, (uint32_t)kc * 128u, wtap_off + (uint32_t)kc * 128u);
             }
+#ifdef SM3_STAMP
+            const unsigned long long q1 = SM3_STAMP_NOW();
+#endif
             compute(s & 1);
+#ifdef SM3_STAMP
+            const unsigned long long q2 = SM3_STAMP_NOW();
+#endif
             dma_drain();      // this wave's part of stage s+1 has landed
+#ifdef SM3_STAMP
+            const unsigned long long q3 = SM3_STAMP_NOW();
+#endif
             __syncthreads();  // everyone's has; and everyone is done reading stage s
+#ifdef SM3_STAMP
+            const unsigned long long q4 = SM3_STAMP_NOW();
+            stamp.seg[0] += q1 - q0; stamp.seg[1] += q2 - q1; stamp.seg[2] += q3 - q2; stamp.seg[3] += q4 - q3;
+#endif
         }
+#ifdef SM3_STAMP
+        stamp.t_loop1 = SM3_STAMP_NOW();
+#endif
     } else {
         dma_drain();
         __syncthreads();  // publishes the stage
@@ -918,6 +968,15 @@ extern "C" int sm3_conv_gather_gemm_seg(const sm3_conv_desc* d, const void* x0, 
     if (!seg) return SM3_EINVAL;
     return conv_gather_gemm_impl(d, x0, w0, y, addend, nullptr, nullptr, stream, nullptr, seg);
 }
+
+#ifdef SM3_STAMP
+extern "C" int sm3_debug_set_stamps(void* buf, long capacity_waves) {
+    unsigned long long* b = (unsigned long long*)buf;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &b, sizeof(b)) != hipSuccess) return SM3_EINVAL;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_cap), &capacity_waves, sizeof(long)) != hipSuccess) return SM3_EINVAL;
+    return 0;
+}
+#endif
 
 extern "C" int sm3_conv_seg_act(const sm3_conv_desc* d, const void* x0, const void* w0, const sm3_conv_seg* seg, int relu,
                                 void* y, uint8_t* relu_mask, void* stream) {
