@@ -457,7 +457,13 @@ def main():
         local_rank = int(os.environ["SM3_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # SM3_BENCH_FORCE_DP=1 with one rank: the whole data-parallel path (RCCL communicators per lane, SyncBN statistic
+    # all-reduces between the kernels, bucketed gradient all-reduces) on a one-GPU box -- every collective is the identity,
+    # what is measured is their launch cost on the critical path (rehearsal knob, not a bench configuration)
+    force_dp = world == 1 and os.environ.get("SM3_BENCH_FORCE_DP") == "1"
+    if force_dp:
+        os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
         tmo = datetime.timedelta(seconds=120)  # a rank that never arrives fails the run in two minutes, not in thirty
@@ -476,7 +482,8 @@ def main():
     model.sm3_dtype = tdt
     model.to(dev)
     trainer = SM3Trainer(model, lr=1e-6, weight_decay=5e-2, eps=1e-5, style=0,  # run.sh:6 lr
-                         global_negatives=args.global_negatives, target_momentum=args.target_momentum)
+                         global_negatives=args.global_negatives, target_momentum=args.target_momentum,
+                         data_parallel=True if force_dp else None)
 
     g = torch.Generator(device=dev).manual_seed(3407 + rank)
     B, S = args.batch, args.img
@@ -619,7 +626,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, S, args.cpu_steps)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dp:
         dist.destroy_process_group()
 
 

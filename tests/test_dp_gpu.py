@@ -203,3 +203,67 @@ def test_two_rank_dp_bf16_batchnorm_by_linearity_syncs_like_the_two_pass_form():
         # bf16 at this random-init state: gradient cosine against fp64 is ~0.12-0.17 for torch's own autocast too (see
         # test_config_gpu.py T2), so only "no worse than the two-pass form" is asked
         assert a["grad_cos"] > b["grad_cos"] - 0.1 and a["grad_cos"] > 0.05, (a, b)
+
+
+def _rccl_world1_main(port, q):
+    """World-size-1 run over the REAL RCCL backend (`nccl` on ROCm): every collective of the data-parallel path is issued
+    -- per-lane communicators, fp64 SyncBN statistic all-reduces between the kernels, bucketed async gradient all-reduces --
+    and with one rank each of them must be the identity, so the step equals the non-DP step."""
+    try:
+        for p in (ROOT, os.path.join(ROOT, "skin-sm3_amd"), os.path.join(ROOT, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        from oracle import procedural
+        from sm3hip.trainer import SM3Trainer
+        from src.models.simclr import SimCLRSkinV32
+        dev = torch.device("cuda:0")
+        state = procedural.make_state_dict(seed=21)
+        derm_np, clinic_np = procedural.make_pair_batch(32, 64, 21)
+        derm = [torch.from_numpy(a).to(dev) for a in derm_np]
+        clinic = [torch.from_numpy(a).to(dev) for a in clinic_np]
+        out = {}
+        for dt in (torch.float32, torch.bfloat16):
+            res = []
+            for dp in (False, True):
+                model = SimCLRSkinV32("resnet50", None, 128, 0.1)
+                model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+                model.sm3_dtype = dt
+                if dp:
+                    model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+                model.to(dev)
+                tr = SM3Trainer(model, lr=1e-3, data_parallel=dp, sync_bn=dp)
+                losses = [float(tr.step(derm, clinic)) for _ in range(2)]
+                torch.cuda.synchronize()
+                eng = tr._engine()
+                assert (eng.stat_sync is not None) == dp
+                res.append((losses, float(eng.store.flat_p.double().sum()),
+                            float(model.state_dict()["derm_backbone.encoder.layer4.2.bn3.running_var"].double().sum())))
+                del tr, model, eng
+            out[str(dt)] = res
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((True, out))
+    except Exception:
+        q.put((False, traceback.format_exc()))
+
+
+def test_rccl_world1_runs_every_collective_of_the_dp_path():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_main, args=(port, q))
+    p.start()
+    ok, payload = q.get(timeout=600)
+    p.join(timeout=60)
+    assert ok, payload
+    for dt, (plain, dp) in payload.items():
+        tol = 1e-4 if "float32" in dt else 5e-2  # bf16: the DP path reduces the statistics in a different launch order
+        print(dt, plain, dp)
+        for a, b in zip(plain[0], dp[0]):
+            assert abs(a - b) < tol * max(1.0, abs(a)), (dt, plain, dp)
+        # parameters after two AdamW steps: the normalised update lr * m / (sqrt(v) + eps) of an element whose gradient is
+        # at the noise floor flips with the last bit of that gradient, so the SUM over 81.65 M parameters only agrees to ~1e-4
+        assert abs(plain[1] - dp[1]) < 3e-4 * abs(plain[1]), (dt, plain, dp)
+        assert abs(plain[2] - dp[2]) < (1e-4 if "float32" in dt else 2e-2) * abs(plain[2]), (dt, plain, dp)
