@@ -514,6 +514,24 @@ int sm3_mlc_kmeans_assign(const float* emb, const float* centroids, int64_t* ass
                           int K, void* stream);
 int sm3_mlc_kmeans_update(float* centroids, const float* sums, const int* counts, int K, int D, void* stream);
 
+/* ---- peer-to-peer SyncBatchNorm statistics exchange on one node (csrc/p2p.hip; opt-in, RCCL is the default) ----------------
+ * Replaces the all-reduce torch.nn.SyncBatchNorm performs per BatchNorm and direction (tools/backbone_train.py:510) for the
+ * fp64 [views][2C] sums of sm3_bn_stats_reduce / sm3_linbn_fold / sm3_linbn_stats.
+ * sm3_p2p_alloc: a zeroed mailbox of sm3_p2p_mailbox_bytes() in device memory + its 64-byte hipIpc handle (to be sent to the
+ * peers by any means); sm3_p2p_open / _close: map / unmap a peer's mailbox; sm3_p2p_free: release one's own.
+ * sm3_p2p_allreduce_f64: buf[0..n) += the same range of every other rank, in place, ONE launch on `stream`, result
+ * bit-identical on all ranks (contributions added in rank order).  mailboxes: host array of `world` device pointers indexed by
+ * rank (one's own included); seq: 1, 2, 3, ... -- the same value on every rank for the same exchange, per mailbox set;
+ * n <= sm3_p2p_max_elems(); err_flag (device int): set to 1 when a peer's contribution did not arrive within timeout_s. */
+int sm3_p2p_mailbox_bytes(void);
+int sm3_p2p_max_elems(void);
+int sm3_p2p_alloc(void** ptr, void* ipc_handle_64);
+int sm3_p2p_open(const void* ipc_handle_64, void** ptr);
+int sm3_p2p_close(void* ptr);
+int sm3_p2p_free(void* ptr);
+int sm3_p2p_allreduce_f64(double* buf, int n, void* const* mailboxes, int rank, int world, uint64_t seq, int* err_flag,
+                          double timeout_s, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

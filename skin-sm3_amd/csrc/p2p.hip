@@ -1,0 +1,137 @@
+// Peer-to-peer exchange of SyncBatchNorm statistic sums between the ranks of ONE node (the reference's
+// exchange is torch.nn.SyncBatchNorm's all_gather of (mean, invstd, count), tools/backbone_train.py:510 -- here the fp64
+// [views][2C] sums the BatchNorm kernels already produce).
+//
+// Why not RCCL for this: a step issues 110 such exchanges per execution lane, each a few KB and each on the critical path
+// (the next kernel of the lane needs the result).  Through torch.distributed every one of them costs two cross-stream event
+// dependencies plus a collective launch (measured with one rank, where the collective itself is the identity: 62.3 -> 70.0
+// ms per step, bench.py SM3_BENCH_FORCE_DP=1).  Here the exchange is ONE kernel on the lane's own stream:
+//
+//   every rank owns a mailbox (device memory, opened by all peers through hipIpc); slot = seq & 1, per source rank a data
+//   area of kMaxN doubles, per (slot, source, block) a 64-bit flag.
+//   block b of rank r:  (1) stores its chunk of r's sums into mailbox[p][slot][r] of every rank p (self included),
+//                       (2) __threadfence_system(), then flag[p][slot][r][b] = seq  (release, system scope),
+//                       (3) waits until flag[r][slot][q][b] == seq for every source q  (acquire, system scope; wall-clock
+//                           timeout -> *err = 1 and the kernel returns: no wave spins forever),
+//                       (4) adds the world's chunks in RANK ORDER (system-scope loads) and writes the result in place:
+//                           bit-identical on every rank.
+//   Two slots suffice: a rank can enter exchange i + 2 (same slot as i) only after every peer has raised its flag for
+//   i + 1, which a peer does only after it has finished reading exchange i (stream order).
+//
+// Opt-in (SM3_SYNCBN_P2P=1, sm3hip/p2p.py), RCCL stays the default: two processes sharing one GPU exercise every line of
+// this file (tests/test_p2p_gpu.py), but the xGMI path between devices has never run -- this pool has one-GPU boxes only.
+#include <cstring>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxWorld = 8;
+constexpr int kMaxN = 16384 + 64;  // doubles per message: [bn3 | downsample][2 views][2 x 2048 channels]
+constexpr int kChunk = 1024;       // doubles per block
+constexpr int kMaxBlocks = (kMaxN + kChunk - 1) / kChunk;
+
+struct Mailbox {
+    double data[2][kMaxWorld][kMaxN];
+    unsigned long long flag[2][kMaxWorld][kMaxBlocks];
+};
+
+struct Peers {
+    Mailbox* box[kMaxWorld];
+};
+
+__global__ __launch_bounds__(256) void p2p_allreduce_kernel(double* __restrict__ buf, int n, Peers peers, int rank, int world,
+                                                            unsigned long long seq, int* __restrict__ err,
+                                                            unsigned long long timeout_ticks) {
+    const int b = blockIdx.x, slot = (int)(seq & 1);
+    const int i0 = b * kChunk, i1 = min(n, i0 + kChunk);
+    // (1) my chunk into everybody's mailbox
+    for (int p = 0; p < world; ++p) {
+        double* dst = peers.box[p]->data[slot][rank];
+        for (int i = i0 + threadIdx.x; i < i1; i += 256)
+            __hip_atomic_store(dst + i, buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __syncthreads();
+    // (2) raise my flag everywhere
+    if ((int)threadIdx.x < world)
+        __hip_atomic_store(&peers.box[threadIdx.x]->flag[slot][rank][b], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (3) wait for everybody's flag in MY mailbox
+    __shared__ int s_bad;
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < world) {
+        const unsigned long long* f = &peers.box[rank]->flag[slot][threadIdx.x][b];
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz wall clock
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
+                s_bad = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    if (s_bad) {
+        if (threadIdx.x == 0) atomicExch(err, 1);
+        return;
+    }
+    __threadfence_system();
+    // (4) the world's chunks, added in rank order
+    const Mailbox* mine = peers.box[rank];
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+        double a = 0.0;
+        for (int q = 0; q < world; ++q)
+            a += __hip_atomic_load(&mine->data[slot][q][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        buf[i] = a;
+    }
+}
+
+}  // namespace
+
+extern "C" int sm3_p2p_mailbox_bytes(void) { return (int)sizeof(Mailbox); }
+extern "C" int sm3_p2p_max_elems(void) { return kMaxN; }
+
+extern "C" int sm3_p2p_alloc(void** ptr, void* ipc_handle_64) {
+    if (!ptr || !ipc_handle_64) return SM3_EINVAL;
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, sizeof(Mailbox));
+    if (e != hipSuccess) return (int)e;
+    e = hipMemset(p, 0, sizeof(Mailbox));
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipIpcGetMemHandle((hipIpcMemHandle_t*)ipc_handle_64, p);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return (int)e;
+    }
+    *ptr = p;
+    return 0;
+}
+
+extern "C" int sm3_p2p_open(const void* ipc_handle_64, void** ptr) {
+    if (!ptr || !ipc_handle_64) return SM3_EINVAL;
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, ipc_handle_64, sizeof(h));
+    hipError_t e = hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int sm3_p2p_close(void* ptr) { return ptr ? (int)hipIpcCloseMemHandle(ptr) : SM3_EINVAL; }
+extern "C" int sm3_p2p_free(void* ptr) { return ptr ? (int)hipFree(ptr) : SM3_EINVAL; }
+
+extern "C" int sm3_p2p_allreduce_f64(double* buf, int n, void* const* mailboxes, int rank, int world, uint64_t seq, int* err_flag,
+                                     double timeout_s, void* stream) {
+    if (!buf || !mailboxes || !err_flag || n <= 0 || n > kMaxN || world < 1 || world > kMaxWorld || rank < 0 || rank >= world ||
+        seq == 0)
+        return SM3_EINVAL;
+    Peers peers;
+    for (int p = 0; p < kMaxWorld; ++p) peers.box[p] = p < world ? (Mailbox*)mailboxes[p] : nullptr;
+    for (int p = 0; p < world; ++p)
+        if (!peers.box[p]) return SM3_EINVAL;
+    const unsigned long long ticks = (unsigned long long)((timeout_s > 0 ? timeout_s : 10.0) * 1e8);
+    hipLaunchKernelGGL(p2p_allreduce_kernel, dim3((n + kChunk - 1) / kChunk), dim3(256), 0, (hipStream_t)stream, buf, n, peers,
+                       rank, world, (unsigned long long)seq, err_flag, ticks);
+    SM3_CHECK_LAUNCH();
+    return 0;
+}

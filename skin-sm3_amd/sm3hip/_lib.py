@@ -62,6 +62,13 @@ SIGNATURES = {
     "sm3_conv_gather_gemm_seg": [_DESC, _P, _P, _P, _P, _P, _P],
     "sm3_conv_seg_act": [_DESC, _P, _P, _P, _I, _P, _P, _P],
     "sm3_linbn_fold": [_P, _I, _I, _I, _P, _P],
+    "sm3_p2p_mailbox_bytes": [],
+    "sm3_p2p_max_elems": [],
+    "sm3_p2p_alloc": [_P, _P],
+    "sm3_p2p_open": [_P, _P],
+    "sm3_p2p_close": [_P],
+    "sm3_p2p_free": [_P],
+    "sm3_p2p_allreduce_f64": [_P, _I, _P, _I, _I, C.c_uint64, _P, _D, _P],
     "sm3_linbn_scale_banks": [_I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P],
     "sm3_subsample_colsum_rows": [_L, _I, _I],
     "sm3_subsample_colsum": [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -669,8 +669,8 @@ class SM3Engine:
     def _slab_buf(self, n, V):
         """Workspace for a plain-store split-K launch (ops.conv_wgrad_slabs): up to SLAB_CAP slabs of n floats per view,
         at most 64 MB per view."""
-        cap = max(1, min(ops.SLAB_CAP, (1 << 24) // n))
-        return self._work("linbn_slabs", V * cap * n)
+        cap = max(1, min(ops.SLAB_CAP, (1 << 24) // n))  # a function of n alone: the partition must not depend on V
+        return self._work("linbn_slabs", V * cap * n), cap
 
     def _lin_conv_desc(self, dtype, N, H, W, Ci, Co):
         """Descriptor of a 1x1 / stride-1 convolution Ci -> Co over an [N, H, W] map (weight-gradient-kernel launches
@@ -752,8 +752,8 @@ class SM3Engine:
         else:
             in_s = torch.empty(M, Cin, dtype=self.tdt, device=dev)
             ops.subsample_colsum(self.dtype, cur, in_s, csd, N, h, w, Cin, cd.stride, V)
-        slabs = self._slab_buf(Cin * Cin, V)
-        ns = ops.conv_wgrad_slabs(self._lin_conv_desc(self.dtype, N, h2, w2, Cin, Cin), in_s, in_s, slabs, views=V)
+        slabs, cap = self._slab_buf(Cin * Cin, V)
+        ns = ops.conv_wgrad_slabs(self._lin_conv_desc(self.dtype, N, h2, w2, Cin, Cin), in_s, in_s, slabs, views=V, cap=cap)
         Gd = torch.empty(V * Cin * Cin, dtype=torch.float32, device=dev)
         sd = torch.empty(V * Cin, dtype=torch.float64, device=dev)
         ops.linbn_moments(slabs, ns, Cin * Cin, Gd, views=V, colsum=csd, colsum_rows=crow, s_out=sd, p=Cin)
@@ -814,8 +814,8 @@ class SM3Engine:
         """P = dz^T y_in [V][C][Cin] of an expanding 1x1 conv unit over compact pixels: plain-store split-K slabs of the
         weight-gradient kernel, summed in a fixed order."""
         C, p = cu.Co, cu.Ci
-        slabs = self._slab_buf(C * p, V)
-        ns = ops.conv_wgrad_slabs(self._lin_conv_desc(self.dtype, N, Hs, Ws, p, C), y_in, dz, slabs, views=V)
+        slabs, cap = self._slab_buf(C * p, V)
+        ns = ops.conv_wgrad_slabs(self._lin_conv_desc(self.dtype, N, Hs, Ws, p, C), y_in, dz, slabs, views=V, cap=cap)
         P = self._work("linbn_P" + tag, V * C * p)
         ops.linbn_moments(slabs, ns, C * p, P, views=V)
         return P
@@ -883,9 +883,9 @@ class SM3Engine:
                 else:
                     in_s = torch.empty(M, Cin, dtype=self.tdt, device=dz.device)
                     ops.subsample_colsum(self.dtype, rd.x_in, in_s, csd, rd.N, rd.H, rd.W, Cin, cd.stride, V)
-                slabs = self._slab_buf(Cin * Cin, V)
+                slabs, cap = self._slab_buf(Cin * Cin, V)
                 ns = ops.conv_wgrad_slabs(self._lin_conv_desc(self.dtype, rd.N, rd.Ho, rd.Wo, Cin, Cin), in_s, in_s, slabs,
-                                          views=V)
+                                          views=V, cap=cap)
                 Gd = self._work("linbn_Gd", V * Cin * Cin)
                 sd = self._work("linbn_sd", V * Cin, torch.float64)
                 ops.linbn_moments(slabs, ns, Cin * Cin, Gd, views=V, colsum=csd, colsum_rows=crow, s_out=sd, p=Cin)
@@ -1083,8 +1083,8 @@ class SM3Engine:
                 cs = self._work("linbn_cs", Vt * crow * pp)
             y2, h2, w2 = self.conv_bn(blk["c2"], blk["b2"], y1, N, h1, w1, True, None, train, br, colsum=cs)
             if lin:
-                slabs = self._slab_buf(pp * pp, Vt)
-                ns = ops.conv_wgrad_slabs(self._lin_conv_desc(self.dtype, N, h2, w2, pp, pp), y2, y2, slabs, views=Vt)
+                slabs, cap = self._slab_buf(pp * pp, Vt)
+                ns = ops.conv_wgrad_slabs(self._lin_conv_desc(self.dtype, N, h2, w2, pp, pp), y2, y2, slabs, views=Vt, cap=cap)
                 br[1].gram = torch.empty(Vt * pp * pp, dtype=torch.float32, device=x.device)
                 br[1].colsum = torch.empty(Vt * pp, dtype=torch.float64, device=x.device)
                 ops.linbn_moments(slabs, ns, pp * pp, br[1].gram, views=Vt, colsum=cs, colsum_rows=crow,

@@ -486,7 +486,7 @@ def conv_wgrad_cat(desc, x, dy, dw, dy1=None, dw1=None, views=1):
 SLAB_CAP = 256  # slabs per view a plain-store split-K launch may use (sm3_conv_wgrad_slabs)
 
 
-def conv_wgrad_slabs(desc, x, dy, slabs, views=1):
+def conv_wgrad_slabs(desc, x, dy, slabs, views=1, cap=None):
     """dy_v^T x_v without atomics: every pixel slice stores its partial [Co][taps*Ci] product into a slab of its own
     (sm3_conv_wgrad_slabs).  slabs: fp32 with room for views * SLAB_CAP slabs.  Returns the slabs used per view; the slabs
     of view v are slabs[(v * used + j) * Co * taps * Ci ...]."""
@@ -497,8 +497,12 @@ def conv_wgrad_slabs(desc, x, dy, slabs, views=1):
     if x.numel() != desc.N * desc.Hi * desc.Wi * desc.Ci or dy.numel() != M * desc.Co or M % views or \
             desc.w_row_stride != desc.ntaps * desc.Ci:
         raise ValueError("conv_wgrad_slabs: operand size does not match descriptor")
-    cap = min(SLAB_CAP, slabs.numel() // (views * n))
-    if cap < 1:
+    # cap: slabs per view the launch may use.  It takes part in the partition of the pixel axis, so a caller that wants a view's
+    # slabs to add up to the same bits in every launch configuration passes a cap that depends on n only (engine._slab_buf) --
+    # the default, derived from the buffer's size, moves with whatever else grew a shared workspace.
+    room = slabs.numel() // (views * n)
+    cap = min(SLAB_CAP, room) if cap is None else int(cap)
+    if cap < 1 or cap > room or cap > SLAB_CAP:
         raise ValueError("conv_wgrad_slabs: slab buffer too small")
     used = C.c_int(0)
     sz = _sz(desc.dtype)

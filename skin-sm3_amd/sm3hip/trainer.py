@@ -7,6 +7,8 @@
 Equivalent to tools/backbone_train.py:98-127 of the reference (loss composition :99-121, AdamW :525-527);
 no autograd graph, no logits tensors, no host synchronisation inside the step.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -70,7 +72,15 @@ class SM3Trainer:
             self._groups = {k: dist.new_group() for k in lanes}
         if self.dp and self.sync_bn and eng.__dict__.get("_explicit_sync") is None:
             eng.world_size = self.world
-            eng.stat_sync = lambda t: dist.all_reduce(t, group=self._groups[eng._lane])
+            if os.environ.get("SM3_SYNCBN_P2P", "0") == "1":
+                # opt-in: the statistics exchange as one kernel on the lane's own stream through hipIpc-mapped mailboxes
+                # (csrc/p2p.hip) instead of an RCCL all-reduce; single node, at most 8 ranks
+                from .p2p import P2PStatSync
+                dev = eng.store.flat_p.device if eng.store is not None else torch.device("cuda", torch.cuda.current_device())
+                self._p2p = P2PStatSync([k for k in self._groups if k != "grads"], dev)
+                eng.stat_sync = lambda t: self._p2p(eng._lane, t)
+            else:
+                eng.stat_sync = lambda t: dist.all_reduce(t, group=self._groups[eng._lane])
             eng.__dict__["_explicit_sync"] = True
         return eng
 

@@ -265,5 +265,5 @@ def test_rccl_world1_runs_every_collective_of_the_dp_path():
             assert abs(a - b) < tol * max(1.0, abs(a)), (dt, plain, dp)
         # parameters after two AdamW steps: the normalised update lr * m / (sqrt(v) + eps) of an element whose gradient is
         # at the noise floor flips with the last bit of that gradient, so the SUM over 81.65 M parameters only agrees to ~1e-4
-        assert abs(plain[1] - dp[1]) < 3e-4 * abs(plain[1]), (dt, plain, dp)
+        assert abs(plain[1] - dp[1]) < (3e-4 if "float32" in dt else 3e-3) * abs(plain[1]), (dt, plain, dp)
         assert abs(plain[2] - dp[2]) < (1e-4 if "float32" in dt else 2e-2) * abs(plain[2]), (dt, plain, dp)

@@ -133,7 +133,12 @@ def test_spherical_kmeans_matches_the_reference_algorithm():
 
 def test_mlc_train_tool_runs_and_learns(tmp_path):
     """tools/mlc_train.py end to end on synthetic data: frozen HIP extractor (eval mode), memory bank, per-epoch spherical
-    k-means, pseudo-label training of the heads; the loss must fall, the checkpoint must hold the reference's keys."""
+    k-means, pseudo-label training of the heads.  Every epoch's loss is finite, the heads move between the first and the last
+    epoch while the frozen extractor does not, the checkpoint holds the reference's keys.  (The epoch-mean losses are NOT
+    compared with each other: the pseudo-labels are re-clustered every epoch, mlc_train.py:116-189, so a cluster's index -- and
+    with it the cross-entropy against the previous epoch's prototypes -- is permuted between epochs; a last-bit change of the
+    extractor's features reorders the history, e.g. 0.999 / 3.212 / 1.195.  That the heads LEARN is pinned where labels are
+    fixed: test_heads_training_matches_torch_autograd above.)"""
     import importlib.util
     import os
     tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "skin-sm3_amd", "tools")
@@ -142,10 +147,17 @@ def test_mlc_train_tool_runs_and_learns(tmp_path):
     spec.loader.exec_module(mt)
     args = mt.get_parser().parse_args(["--data-name", "synthetic", "--epochs", "3", "-b", "32", "--num-samples", "96",
                                        "--img-sz", "64", "64", "--log-path", str(tmp_path), "--temperature", "1",
-                                       "--mlc-proj-dim", "128", "--sa-dim-ff", "64", "--sa-dropout", "0.1", "-lr", "1e-3"])
+                                       "--mlc-proj-dim", "128", "--sa-dim-ff", "64", "--sa-dropout", "0.1", "-lr", "1e-3",
+                                       "--save-freq", "1"])
     args.world_size = 1
     hist = mt.main(0, args)
-    assert len(hist) == 3 and all(math.isfinite(v) for v in hist) and hist[-1] < hist[0]
+    assert len(hist) == 3 and all(math.isfinite(v) and 0.0 < v < 20.0 for v in hist), hist
+    first = torch.load(os.path.join(str(tmp_path), "ckp_0.pth"), map_location="cpu", weights_only=False)["state_dict"]
+    last = torch.load(os.path.join(str(tmp_path), "ckp_2.pth"), map_location="cpu", weights_only=False)["state_dict"]
+    moved = [k for k in first if k.startswith(("mlc_sa.", "prototypes.", "projectors.")) and first[k].is_floating_point()
+             and not torch.equal(first[k], last[k])]
+    frozen = [k for k in first if k.startswith("extractor.") and not torch.equal(first[k], last[k])]
+    assert len(moved) > 10 and not frozen, (len(moved), frozen[:4])
     ck = torch.load(os.path.join(str(tmp_path), "checkpoint.pth.tar"), map_location="cpu", weights_only=False)
     assert {"epoch", "state_dict", "optimizer"} <= set(ck)
     keys = list(ck["state_dict"].keys())
