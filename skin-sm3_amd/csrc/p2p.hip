@@ -3,18 +3,19 @@
 // [views][2C] sums the BatchNorm kernels already produce).
 //
 // Why not RCCL for this: a step issues 110 such exchanges per execution lane, each a few KB and each on the critical path
-// (the next kernel of the lane needs the result).  Through torch.distributed every one of them costs two cross-stream event
-// dependencies plus a collective launch (measured with one rank, where the collective itself is the identity: 62.3 -> 70.0
-// ms per step, bench.py SM3_BENCH_FORCE_DP=1).  Here the exchange is ONE kernel on the lane's own stream:
+// (the next kernel of the lane needs the result).  Through torch.distributed every one of them is two cross-stream event
+// dependencies plus a collective launch (8 us with ONE rank, where the collective is the identity; an all-reduce of a few
+// KB between devices is a multiple of that).  Here the exchange is ONE kernel on the lane's own stream (5.5 us on one rank;
+// profiles/r03b_bench_force_dp_world1.txt):
 //
 //   every rank owns a mailbox (device memory, opened by all peers through hipIpc); slot = seq & 1, per source rank a data
 //   area of kMaxN doubles, per (slot, source, block) a 64-bit flag.
 //   block b of rank r:  (1) stores its chunk of r's sums into mailbox[p][slot][r] of every rank p (self included),
-//                       (2) __threadfence_system(), then flag[p][slot][r][b] = seq  (release, system scope),
-//                       (3) waits until flag[r][slot][q][b] == seq for every source q  (acquire, system scope; wall-clock
-//                           timeout -> *err = 1 and the kernel returns: no wave spins forever),
-//                       (4) adds the world's chunks in RANK ORDER (system-scope loads) and writes the result in place:
-//                           bit-identical on every rank.
+//                       (2) waits for those stores to be acknowledged, then flag[p][slot][r][b] = seq,
+//                       (3) waits until flag[r][slot][q][b] == seq for every source q  (wall-clock timeout -> *err = 1 and
+//                           the kernel returns: no wave spins forever),
+//                       (4) adds the world's chunks in RANK ORDER and writes the result in place: bit-identical on every
+//                           rank.  (Every mailbox access is a system-scope relaxed atomic; no fences -- see the kernel.)
 //   Two slots suffice: a rank can enter exchange i + 2 (same slot as i) only after every peer has raised its flag for
 //   i + 1, which a peer does only after it has finished reading exchange i (stream order).
 //
@@ -45,17 +46,22 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(double* __restrict__
                                                             unsigned long long timeout_ticks) {
     const int b = blockIdx.x, slot = (int)(seq & 1);
     const int i0 = b * kChunk, i1 = min(n, i0 + kChunk);
+    // Every access to a mailbox is a system-scope atomic (relaxed): such stores write through and such loads read past the
+    // caches, so no release / acquire FENCE is needed (a system-scope fence writes back and invalidates the whole L2, paid by
+    // the NEXT kernel of the lane).  Ordering comes from the in-order issue of a wave plus
+    // s_waitcnt vmcnt(0): the data stores are acknowledged before the flag store is issued, and the data loads are issued
+    // after the flag load has returned.
     // (1) my chunk into everybody's mailbox
     for (int p = 0; p < world; ++p) {
         double* dst = peers.box[p]->data[slot][rank];
         for (int i = i0 + threadIdx.x; i < i1; i += 256)
             __hip_atomic_store(dst + i, buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // (2) raise my flag everywhere
     if ((int)threadIdx.x < world)
-        __hip_atomic_store(&peers.box[threadIdx.x]->flag[slot][rank][b], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&peers.box[threadIdx.x]->flag[slot][rank][b], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // (3) wait for everybody's flag in MY mailbox
     __shared__ int s_bad;
     if (threadIdx.x == 0) s_bad = 0;
@@ -63,7 +69,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(double* __restrict__
     if ((int)threadIdx.x < world) {
         const unsigned long long* f = &peers.box[rank]->flag[slot][threadIdx.x][b];
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz wall clock
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
             if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
                 s_bad = 1;
                 break;
@@ -71,12 +77,12 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(double* __restrict__
             __builtin_amdgcn_s_sleep(8);
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (s_bad) {
         if (threadIdx.x == 0) atomicExch(err, 1);
         return;
     }
-    __threadfence_system();
     // (4) the world's chunks, added in rank order
     const Mailbox* mine = peers.box[rank];
     for (int i = i0 + threadIdx.x; i < i1; i += 256) {
