@@ -584,7 +584,7 @@ def main():
         del trainer, model, eng
         torch.cuda.empty_cache()
         other_modes = {}
-        for name, odt, nw, ns in (("f16", torch.float16, 3, 10), ("f32", torch.float32, 1, 3)):
+        for name, odt, nw, ns in (("f16", torch.float16, 6, 15), ("f32", torch.float32, 1, 3)):
             torch.manual_seed(3407)
             om = SimCLRSkinV32("resnet50", None, 128, 0.1)
             om.sm3_dtype = odt

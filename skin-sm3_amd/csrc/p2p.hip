@@ -4,8 +4,8 @@
 //
 // Why not RCCL for this: a step issues 110 such exchanges per execution lane, each a few KB and each on the critical path
 // (the next kernel of the lane needs the result).  Through torch.distributed every one of them is two cross-stream event
-// dependencies plus a collective launch (8 us with ONE rank, where the collective is the identity; an all-reduce of a few
-// KB between devices is a multiple of that).  Here the exchange is ONE kernel on the lane's own stream (5.5 us on one rank;
+// dependencies plus a collective launch (7 us with ONE rank, where the collective is the identity; an all-reduce of a few
+// KB between devices is a multiple of that).  Here the exchange is ONE kernel on the lane's own stream (3 us on one rank;
 // profiles/r03b_bench_force_dp_world1.txt):
 //
 //   every rank owns a mailbox (device memory, opened by all peers through hipIpc); slot = seq & 1, per source rank a data

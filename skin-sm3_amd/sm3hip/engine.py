@@ -160,6 +160,58 @@ class BNUnit:
         self.name, self.C, self.affine = name, C, affine
 
 
+
+_LANE_POOL = {}
+
+
+def lane_stream_pool(device, n):
+    """n HIP streams that really run concurrently with the stream that is current now AND with each other.
+
+    HIP multiplexes its streams onto a few hardware queues (4 by default, the null stream included): two streams that land
+    on the same queue execute one after the other.  Which queue a new stream gets depends on how many streams the process
+    created before (RCCL's, another engine's, the caller's) -- measured here: the second trainer created in a process ran
+    11 % slower than the first and the third, its lanes serialised behind the main stream's queue.  So the lane streams are
+    picked by measurement, once per device and process (every engine shares them: a stream is only an order), with
+    torch.cuda._sleep as the probe: two spins on streams of one queue take twice as long as one.  SM3_STREAM_CALIBRATE=0
+    falls back to the first n new streams."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    pool = _LANE_POOL.setdefault(idx, [])
+    if len(pool) >= n:
+        return pool[:n]
+    if _os.environ.get("SM3_STREAM_CALIBRATE", "1") == "0":
+        pool.extend(torch.cuda.Stream(device=device) for _ in range(n - len(pool)))
+        return pool[:n]
+    import time
+    main = torch.cuda.current_stream(device)
+    cyc = 1_000_000
+
+    def spin(a, b):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        with torch.cuda.stream(a):
+            torch.cuda._sleep(cyc)
+        if b is not None:
+            with torch.cuda.stream(b):
+                torch.cuda._sleep(cyc)
+        torch.cuda.synchronize(device)
+        return time.perf_counter() - t0
+
+    spin(main, None)
+    one = min(spin(main, None) for _ in range(3))
+    concurrent = lambda a, b: min(spin(a, b) for _ in range(2)) < 1.5 * one
+    cands = [torch.cuda.Stream(device=device) for _ in range(12)]
+    rest = []
+    for c in cands:
+        if len(pool) >= n:
+            break
+        if concurrent(main, c) and all(concurrent(c, s) for s in pool):
+            pool.append(c)
+        else:
+            rest.append(c)
+    pool.extend(rest[: max(0, n - len(pool))])  # fewer independent queues than lanes: take what there is
+    return pool[:n]
+
+
 class Rec:
     """What one conv+BN(+act) application saves for backward."""
     __slots__ = ("cu", "bu", "N", "H", "W", "Ho", "Wo", "x_in", "xo", "mean", "invstd", "y", "relu", "mask", "V",
@@ -382,9 +434,10 @@ class SM3Engine:
         if not self.two_streams or len(self.branches) < 2 or device.type != "cuda":
             return None
         if self._streams is None or self._streams_dev != device:
-            self._streams = {k: torch.cuda.Stream(device=device) for k in self.branches}
+            keys = list(self.branches)
             if self.view_lanes:  # second view of every branch on a lane of its own
-                self._streams.update({k + "#1": torch.cuda.Stream(device=device) for k in self.branches})
+                keys += [k + "#1" for k in self.branches]
+            self._streams = dict(zip(keys, lane_stream_pool(device, len(keys))))
             self._streams_dev = device
         return self._streams
 
