@@ -1007,7 +1007,10 @@ class SM3Engine:
             return None
         st = self._side.get(self._lane)
         if st is None:
-            st = torch.cuda.Stream(device=self.store.flat_p.device)
+            # behind the lane streams in the measured pool (needs GPU_MAX_HW_QUEUES >= 6 to get queues of their own)
+            dev = self.store.flat_p.device
+            nl = len(self._streams or {}) or len(self.branches)
+            st = lane_stream_pool(dev, nl + len(self._side) + 1)[nl + len(self._side)]
             self._side[self._lane] = st
         return st
 

@@ -193,9 +193,9 @@ def test_T2_loss_trajectories_and_linear_probe_auroc():
     # chance = 0.5): what is pinned is that the three arithmetic modes end at the same place
     assert aucs["f32"] > 0.53
     # 512 held-out samples: the AUROC estimate itself has a standard error of ~0.02, and the f32 run is not bit-reproducible
-    # (float-atomic weight gradients); measured differences 0.002 .. 0.022
-    assert abs(aucs["f16"] - aucs["f32"]) < 3e-2, aucs
-    assert abs(aucs["bf16"] - aucs["f32"]) < 3e-2, aucs
+    # (float-atomic weight gradients); measured differences over eight runs 0.002 .. 0.036 -> bound = 2.5 standard errors
+    assert abs(aucs["f16"] - aucs["f32"]) < 5e-2, aucs
+    assert abs(aucs["bf16"] - aucs["f32"]) < 5e-2, aucs
 
 
 def test_momentum_target_step_against_its_fp64_oracle():
