@@ -178,7 +178,7 @@ def lane_stream_pool(device, n):
     pool = _LANE_POOL.setdefault(idx, [])
     if len(pool) >= n:
         return pool[:n]
-    if _os.environ.get("SM3_STREAM_CALIBRATE", "1") == "0":
+    if _os.environ.get("SM3_STREAM_CALIBRATE", "1") == "0" or not hasattr(torch.cuda, "_sleep"):
         pool.extend(torch.cuda.Stream(device=device) for _ in range(n - len(pool)))
         return pool[:n]
     import time
