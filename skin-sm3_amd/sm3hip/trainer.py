@@ -88,12 +88,25 @@ class SM3Trainer:
         """Gradients of the parameters whose names start with first..last are final: all-reduce that slice of
         the flat gradient buffer now, on RCCL's stream, while backward continues."""
         st = eng.store
+        a, b = self._bucket_range(eng, first, last)
+        self._handles.append(dist.all_reduce(st.flat_g[a:b], async_op=True, group=self._groups["grads"]))
+
+    def _bucket_range(self, eng, first, last):
+        st = eng.store
         names = st.names
         lo = next(i for i, n in enumerate(names) if n.startswith(first))
         hi = max(i for i, n in enumerate(names) if n.startswith(last))
         a = st.offsets[names[lo]]
         b = st.offsets[names[hi]] + (st._view(st.flat_g, names[hi]).numel() + 15) // 16 * 16
-        self._handles.append(dist.all_reduce(st.flat_g[a:b], async_op=True, group=self._groups["grads"]))
+        return a, min(b, st.total)
+
+    def _bucket_adamw(self, eng, first, last):
+        """AdamW over the slice of the flat buffers whose gradients just became final (current = that lane's stream)."""
+        st = eng.store
+        a, b = self._bucket_range(eng, first, last)
+        ops.adamw(st.flat_p[a:b], st.flat_g[a:b], self.m[a:b], self.v[a:b], self.lr, self.betas[0], self.betas[1], self.eps,
+                  self.wd, self.step_count, 1.0)
+        self._covered += b - a
 
     # ---- global negatives: all-gather of the projection embeddings (north_star; opt-in) ---------------------------
     def _ntxent_global(self, eng, name, z, T, weight, loss, dz_out, dz_scale):
@@ -243,12 +256,25 @@ class SM3Trainer:
                 dmeta += dd[Bm:]
             dz["meta"] = dmeta
         self._handles = []
-        eng.grad_ready = (lambda f, l: self._bucket_ready(eng, f, l)) if self.dp else None
+        # Single rank, no loss scaling: AdamW runs bucket by bucket as the gradients become final, on the lane that finished
+        # them -- the other lane's backward hides it (one launch over all 81.65 M parameters at the end of the step is 0.45 ms
+        # during which nothing else runs).  Data parallel: the buckets are all-reduced instead and AdamW follows the last
+        # one; fp16: the overflow check needs every gradient first.
+        early = sc is None and not self.dp and os.environ.get("SM3_ADAMW_BUCKETS", "1") != "0"
+        if early:
+            self.step_count += 1
+            self._covered = 0
+            eng.grad_ready = lambda f, l: self._bucket_adamw(eng, f, l)
+        else:
+            eng.grad_ready = (lambda f, l: self._bucket_ready(eng, f, l)) if self.dp else None
         eng.backward(saved, dz)
         eng.grad_ready = None
         for h in self._handles:
             h.wait()
-        if sc is None:
+        if early:
+            if self._covered != st.total:  # every parameter belongs to exactly one bucket (tests/test_host_logic.py)
+                raise RuntimeError(f"gradient-ready notifications covered {self._covered} of {st.total} parameters")
+        elif sc is None:
             self.step_count += 1
             ops.adamw(st.flat_p, st.flat_g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
                       self.step_count, 1.0 / self.world)
