@@ -348,6 +348,7 @@ class SM3Engine:
         # ... and the downsample conv -> BatchNorm of a stage's first block in the backward pass
         self.linbn_ds = _os.environ.get("SM3_LINBN_DS", "1") != "0"
         self.linbn_join = _os.environ.get("SM3_LINBN_JOIN", "1") != "0"
+        self.lane_cross = _os.environ.get("SM3_LANE_CROSS", "1") != "0"  # cross-modal projector passes inside the lanes
 
     # ---- setup ---------------------------------------------------------------------------
     def _all_conv_units(self):
@@ -378,18 +379,23 @@ class SM3Engine:
             if b.device != device:
                 raise RuntimeError(f"buffer {name} is on {b.device}, expected {device}: call module.to(device) first")
 
-    def refresh_weights(self):
-        """fp32 master -> `dtype` filter banks (forward and data-gradient order); once per step, one launch.  The device
-        table of (master, bank) pointers is cached per master buffer (the online weights, and the momentum target's when
-        the trainer swaps store.flat_p for a target forward)."""
+    def refresh_weights(self, defer_lanes=False):
+        """fp32 master -> `dtype` filter banks (forward and data-gradient order); once per step.  The device tables of
+        (master, bank) pointers are cached per master buffer (the online weights, and the momentum target's when the trainer
+        swaps store.flat_p for a target forward): one table per branch encoder + in-modal projector, one for the rest.
+        defer_lanes (two-lane forward): only the shared part is laid out here; each branch's banks are left to
+        prep_lane(key), called at the head of that branch's lane -- the two launches then overlap instead of both lanes
+        waiting for one launch over everything."""
         key = (self.store.flat_p.data_ptr(), len(self.store.names), self.dtype)
         cache = self.__dict__.setdefault("_wprep_cache", {})
         if key not in cache:
-            items, stems = [], []
+            groups = {k: ([], []) for k in list(self.branches) + [None]}
             for cu in self._all_conv_units():
                 wname = cu.name + ".weight"
                 if wname not in self.store.offsets:
                     continue  # projector dropped by the caller (mlc_train.py:344-346 sets them to None)
+                owner = next((k for k in self.branches if k != "main" and wname.startswith(k + "_")), None)
+                items, stems = groups[owner]
                 m = self.store.flat2d(self.store.flat_p, wname)
                 if cu.stem and self.direct_stem:
                     stems.append((m, cu.w_fwd))
@@ -398,9 +404,9 @@ class SM3Engine:
                 else:
                     items.append((m, cu.w_fwd, cu.w_dgrad, cu.Co, cu.taps, cu.Ci, cu.taps * cu.Ci))
             dev = self.store.flat_p.device
-            cache[key] = (ops.weight_prep_table(items, dev), stems,
-                          torch.zeros(2, dtype=torch.int64, device=dev), torch.ones(1, dtype=torch.int32, device=dev))
-        table, stems, hstate, changed = cache[key]
+            tables = {k: (ops.weight_prep_table(items, dev) if items else None, stems) for k, (items, stems) in groups.items()}
+            cache[key] = (tables, torch.zeros(2, dtype=torch.int64, device=dev), torch.ones(1, dtype=torch.int32, device=dev))
+        tables, hstate, changed = cache[key]
         # Frozen masters (linear probe, multi-label heads, inference: the same encoders forward after forward) keep their
         # banks.  Whether they changed is decided ON THE DEVICE from a hash of the flat buffer -- torch's version counters
         # miss `p.data` writes and raw-pointer kernels, a stale bank would be a silent error.  A caller that knows it just
@@ -414,9 +420,24 @@ class SM3Engine:
         else:
             self._hash_tracks_banks = False  # unconditional re-layout: the remembered hash no longer describes the banks
         self._wprep_key, self.weights_dirty = key, False
-        ops.weight_prep_batch(self.dtype, table, only_if)
+        self._lane_prep = {}
+        for k, (table, stems) in tables.items():
+            if defer_lanes and k is not None:
+                self._lane_prep[k] = (table, stems, only_if)
+            else:
+                self._prep(table, stems, only_if)
+
+    def _prep(self, table, stems, only_if):
+        if table is not None:
+            ops.weight_prep_batch(self.dtype, table, only_if)
         for m, w in stems:
             ops.stem_weight_prep(self.dtype, m, w, only_if)
+
+    def prep_lane(self, key):
+        """The filter banks of branch `key`, on the current (= that branch's lane) stream; see refresh_weights."""
+        job = self.__dict__.get("_lane_prep", {}).pop(key, None)
+        if job is not None:
+            self._prep(*job)
 
     def _work(self, key, numel, dtype=torch.float32):
         """Stream-ordered scratch; one set per execution lane (branch stream) so concurrent branches never share."""
@@ -1331,14 +1352,25 @@ class SM3Engine:
         first = next(iter(views.values()))[0]
         dev = first.device
         self.prepare(dev)
-        self.refresh_weights()
+        self.refresh_weights(defer_lanes=self._lane_streams(dev) is not None and self.lane_cross)
         B = first.shape[0]
         saved = {"B": B, "style": style} if want_grad else None
         sv = (lambda: []) if want_grad else (lambda: None)
         zs, feats = OrderedDict(), {}
         streams = self._lane_streams(dev)
+        # Cross-modal projectors (simclr.py:290-322): cross_proj[0] only ever sees dermoscopy features and cross_proj[1]
+        # clinical ones, so each runs at the end of its modality's lane, hidden behind the other lane's encoder, instead of
+        # on the main stream after the join (4 projector passes = ~50 small dependent launches in series).
+        lane_cross = (self.cross is not None and streams is not None and set(self.branches) == {"derm", "clinic"}
+                      and not self.view_lanes and self.lane_cross)
+        pairs = self.cross_pairs(style) if self.cross is not None else []
+        zc = [self._share(torch.empty(2 * B, self.module.proj_dim, dtype=torch.float32, device=dev), streams) for _ in pairs] \
+            if lane_cross else []
+        cross_recs = {}
         for key, (plan, proj) in self.branches.items():
             imgs = views[key]
+            with self.lane(key, streams):
+                self.prep_lane(key)  # this branch's filter banks (deferred by refresh_weights), overlapping the other lane's
             for im in imgs:
                 self._share(im, streams)
             f32 = self._share(torch.empty(2 * B, plan.out_dim, dtype=torch.float32, device=dev), streams)
@@ -1375,11 +1407,25 @@ class SM3Engine:
                     z = torch.empty(2 * B, self.module.proj_dim, dtype=torch.float32, device=dev)
                     self.projector_forward(proj, ft, 2 * B, train, z, precs)
                     zs[key] = self._share(z, streams)
+                if lane_cross:
+                    side = 0 if key == "derm" else 1
+                    for ci, ab in enumerate(pairs):
+                        rec = sv()
+                        self.projector_forward(self.cross[side], ft[ab[side] * B:(ab[side] + 1) * B], B, train,
+                                               zc[ci][side * B:(side + 1) * B], rec)
+                        cross_recs[(ci, side)] = rec
             if want_grad:
                 saved[key] = {"enc": ctxs, "proj": precs[0] if proj is not None else None}
         self._join(streams)
+        for k in list(self.__dict__.get("_lane_prep", {})):
+            self.prep_lane(k)  # (a branch whose lane never ran)
         cross_saved = []
-        if self.cross is not None:  # cross-modal: each projector sees its own B rows (simclr.py:293)
+        if lane_cross:
+            for ci, (a, b) in enumerate(pairs):
+                zs[f"cross{ci}"] = zc[ci]
+                if want_grad:
+                    cross_saved.append((a, b, cross_recs[(ci, 0)][0], cross_recs[(ci, 1)][0]))
+        elif self.cross is not None:  # cross-modal: each projector sees its own B rows (simclr.py:293)
             for ci, (a, b) in enumerate(self.cross_pairs(style)):
                 z = torch.empty(2 * B, self.module.proj_dim, dtype=torch.float32, device=dev)
                 pa, pb = sv(), sv()
@@ -1426,6 +1472,10 @@ class SM3Engine:
         streams = self._lane_streams(dev)
         for t in dz.values():
             self._share(t, streams)
+        # mirror of forward(): each cross-modal projector's backward inside its modality's lane (no join, no main-stream pass)
+        lane_cross = (self.cross is not None and streams is not None and set(self.branches) == {"derm", "clinic"}
+                      and not self.view_lanes and self.lane_cross and bool(saved.get("cross")) and all(f"cross{ci}" in dz
+                                                                                 for ci in range(len(saved["cross"]))))
         for key, (plan, proj) in self.branches.items():
             extra = dfeat.get(key) if dfeat is not None else None
             self._share(extra, streams)
@@ -1437,18 +1487,28 @@ class SM3Engine:
                 else:
                     dfe[key] = torch.zeros(2 * B, plan.out_dim, dtype=self.tdt, device=dev)
                 self._share(dfe[key], streams)
+                if lane_cross:  # this modality's cross-projector passes, then its projector buckets are final
+                    side = 0 if key == "derm" else 1
+                    for ci, rec in enumerate(saved["cross"]):
+                        ab = rec[side]
+                        self.projector_backward(rec[2 + side], dz[f"cross{ci}"][side * B:(side + 1) * B],
+                                                into=dfe[key][ab * B:(ab + 1) * B])
+                    if proj is not None:
+                        self._notify(proj.prefix, proj.prefix)
+                    self._notify(self.cross[side].prefix, self.cross[side].prefix)
                 self._sync_side()
-        self._join(streams)
-        for ci, (a, b, pa, pb) in enumerate(saved["cross"]):
-            d = dz[f"cross{ci}"]
-            self.projector_backward(pa, d[:B], into=dfe["derm"][a * B:(a + 1) * B])
-            self.projector_backward(pb, d[B:], into=dfe["clinic"][b * B:(b + 1) * B])
-        # all projector gradients are final here
-        for key, (plan, proj) in self.branches.items():
-            if proj is not None:
-                self._notify(proj.prefix, proj.prefix)
-        if self.cross is not None:
-            self._notify(self.cross[0].prefix, self.cross[-1].prefix)
+        if not lane_cross:
+            self._join(streams)
+            for ci, (a, b, pa, pb) in enumerate(saved["cross"]):
+                d = dz[f"cross{ci}"]
+                self.projector_backward(pa, d[:B], into=dfe["derm"][a * B:(a + 1) * B])
+                self.projector_backward(pb, d[B:], into=dfe["clinic"][b * B:(b + 1) * B])
+            # all projector gradients are final here
+            for key, (plan, proj) in self.branches.items():
+                if proj is not None:
+                    self._notify(proj.prefix, proj.prefix)
+            if self.cross is not None:
+                self._notify(self.cross[0].prefix, self.cross[-1].prefix)
         if self.meta is not None:
             if "meta" in dz and saved.get("meta") is not None:
                 self.projector_backward(saved["meta"], dz["meta"])
