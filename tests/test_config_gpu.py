@@ -134,7 +134,9 @@ def test_b512_both_views_one_batch(dt):
                       {k: v.clone() for k, v in model.state_dict().items() if "running" in k})
         del tr, eng, model
         torch.cuda.empty_cache()
-    assert abs(runs[True][0] - runs[False][0]) < 1e-5, (runs[True][0], runs[False][0])
+    # the loss is four NT-Xent terms whose row sums are added with float atomics: equal up to that order (a few ulp of 22);
+    # the forward itself is pinned bit for bit by the running statistics below
+    assert abs(runs[True][0] - runs[False][0]) < 5e-5, (runs[True][0], runs[False][0])
     for k, v in runs[True][2].items():
         assert torch.equal(v, runs[False][2][k]), k
     assert abs(runs[True][1] - runs[False][1]) < 2e-3 * runs[False][1]
