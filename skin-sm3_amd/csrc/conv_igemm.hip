@@ -793,6 +793,13 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
             // per-row work on the read-back: an addend, ReLU bits, per-view affine, a strided output
             if (p.addend || p.ep_mask || !dense || (p.ep_scale && p.fz_view_tiles))
                 return launch_conv_epi<T, BM, BN, WM, WN, 2>(p, st, single, deep);
+            if constexpr (BN == 128 && WM == 2 && WN == 2) {
+                // 3x3 forward launches: 8 waves on the same 128 x 128 tile (64 x 32 wave tiles) -- each wave issues 4 of the
+                // stage's LDS-DMA pieces instead of 8, which is as long as its MFMA phase (profiles/r03b_smemtime_kloop_timeline.txt):
+                // +2 ... +8 % on these layers; the short-K 1x1 layers lose (their epilogue on 512 threads) and keep 4 waves.
+                static const bool w8 = !(getenv("SM3_CONV_W8") && atoi(getenv("SM3_CONV_W8")) == 0);
+                if (w8 && p.ntaps >= 9 && !single && !deep) return launch_conv_st<T, BM, BN, 2, 4, 2, 1>(p, st);
+            }
             return launch_conv_epi<T, BM, BN, WM, WN, 1>(p, st, single, deep);  // train-mode forward, conv + evalBN (+ReLU)
         }
     }
