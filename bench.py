@@ -557,7 +557,7 @@ def main():
                 "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "frac_in_timed_region_two_lanes": round(in_region["flops"] / max(in_region["ms"] * 1e-3, 1e-9) / 1e12 / peak, 4),
                 "by_regime": by_regime,
-                "kernel": f"conv_igemm_kernel<{ {'bf16': 'bf16_t', 'f16': 'f16_t', 'f32': 'float'}[args.dtype] },128,128,2,2,*>",
+                "kernel": f"conv_igemm_kernel<{ {'bf16': 'bf16_t', 'f16': 'f16_t', 'f32': 'float'}[args.dtype] },128,128,*>",
                 "algorithmic_bytes_per_launch": round(dom["bytes"] / max(dom["launches"], 1)),
                 "launches_per_step": dom["launches"],
                 "avg_launch_us": round(1e3 * dom["ms"] / max(dom["launches"], 1), 2),

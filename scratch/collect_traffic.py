@@ -13,7 +13,7 @@ def per_launch(d, counter):
 
 fetch, nf = per_launch(sys.argv[1], "FETCH_SIZE")
 write, nw = per_launch(sys.argv[2], "WRITE_SIZE")
-out = {"kernel": "conv_igemm_kernel<bf16_t,128,128,2,2,{1,2}>", "launches_fetch_pass": nf, "launches_write_pass": nw,
+out = {"kernel": "conv_igemm_kernel<bf16_t,128,128,*> (every wave-layout / stage / epilogue / segment instantiation)", "launches_fetch_pass": nf, "launches_write_pass": nw,
        "fetch_KiB_raw_per_launch": fetch / nf, "write_KiB_per_launch": write / nw,
        "hbm_bytes_per_launch": (2.0 * fetch / nf + write / nw) * 1024.0,
        "note": "FETCH_SIZE doubled (gfx950 reports half the bytes of 16-B/lane streaming reads); WRITE_SIZE exact; "
