@@ -315,22 +315,32 @@ def mlc_train_bench(args):
 
 
 def visible_gpus():
-    """Compute nodes the kernel driver exposes (KFD topology: a node with SIMDs is a GPU), read from sysfs -- the parent
-    of the rank processes never touches HIP.  None when the topology is not readable."""
+    """(count, source): compute nodes the kernel driver exposes (KFD topology: a node with SIMDs is a GPU), read from sysfs
+    -- the parent of the rank processes never touches HIP -- capped by the shortest of HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when one is set (a rank with LOCAL_RANK beyond that list would die in
+    set_device).  (None, reason) when nothing is readable."""
     import glob
+    n, src = None, "nothing readable"
     nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
-    if not nodes:
-        return None
-    n = 0
-    try:
-        for f in nodes:
-            for line in open(f):
-                k, _, v = line.partition(" ")
-                if k == "simd_count" and int(v) > 0:
-                    n += 1
-    except OSError:
-        return None
-    return n
+    if nodes:
+        try:
+            n = 0
+            for f in nodes:
+                for line in open(f):
+                    k, _, v = line.partition(" ")
+                    if k == "simd_count" and int(v) > 0:
+                        n += 1
+            src = "KFD topology in sysfs"
+        except (OSError, ValueError):
+            n, src = None, "KFD topology unreadable"
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        val = os.environ.get(var)
+        if val is None:
+            continue
+        listed = len([x for x in val.split(",") if x.strip() != ""])
+        if n is None or listed < n:
+            n, src = listed, f"{var}={val!r}"
+    return n, src
 
 
 def spawn_ranks(n, argv=None, extra_env=None, grace=5.0):
@@ -342,10 +352,10 @@ def spawn_ranks(n, argv=None, extra_env=None, grace=5.0):
     import socket
     import subprocess
     import threading
-    have = visible_gpus()
+    have, have_src = visible_gpus()
     if os.environ.get("SM3_FORCE_DEVICE") is None and os.environ.get("SM3_BENCH_DRYRUN") != "1" and have is not None \
             and have < n:
-        raise SystemExit(f"--gpus {n} but only {have} GPU(s) visible")
+        raise SystemExit(f"--gpus {n} but only {have} GPU(s) visible (from {have_src})")
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
@@ -421,15 +431,48 @@ def dry_run_rank(args):
             trainer.step(x[:2], x[2:])
         if world > 1:
             dist.barrier()
-        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        mine = time.perf_counter() - t0
+        el = torch.tensor([mine], dtype=torch.float64)
         if world > 1:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        witness = dp_witness(world, "gloo", torch.device("cpu"), mine, max(1, args.steps), trainer)
     if rank == 0:
         print(json.dumps({"metric": "SM3 pretrain images/sec (paired 224x224)", "dry_run": True, "value": None,
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "config": {"parallelism": f"dp{world}"}}), flush=True)
+                          "config": {"parallelism": f"dp{world}", "witness": witness}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def dp_witness(world, backend, dev, elapsed_s, steps, trainer=None):
+    """What a multi-rank record must be able to prove (rank 0 returns the dict, the other ranks take part in the
+    collectives): how many ranks the backend REALLY connected (an all-reduce of ones over the default group -- not
+    WORLD_SIZE echoed back), which library that was, how the SyncBN statistics travelled, and every rank's own ms/step."""
+    w = {"backend": backend, "rccl_ranks": None, "nccl_version": None, "syncbn_exchange": "none (single rank)",
+         "ms_per_step_per_rank": [round(1e3 * elapsed_s / max(steps, 1), 3)]}
+    if not (dist.is_available() and dist.is_initialized()):
+        return w
+    one = torch.ones(1, dtype=torch.float32, device=dev)
+    dist.all_reduce(one)
+    w["rccl_ranks"] = int(one.item())
+    if backend == "nccl":
+        try:
+            w["nccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:  # a build without the query: say so, never guess
+            w["nccl_version"] = f"unavailable ({type(e).__name__})"
+    mine = torch.tensor([1e3 * elapsed_s / max(steps, 1)], dtype=torch.float64, device=dev)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    per = [round(float(x), 3) for x in every]
+    w["ms_per_step_per_rank"] = per
+    w["ms_per_step_min"], w["ms_per_step_max"] = min(per), max(per)
+    p2p = getattr(trainer, "_p2p", None) if trainer is not None else None
+    if p2p is not None:
+        w["syncbn_exchange"] = "p2p"
+        w["p2p_mailbox_memory"] = p2p.memory_kind
+    elif trainer is not None and getattr(trainer, "sync_bn", False):
+        w["syncbn_exchange"] = "rccl" if backend == "nccl" else backend
+    return w
 
 
 def main():
@@ -513,11 +556,46 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.set_profiler(None)
     loss_val = float(loss)
+    witness = dp_witness(world, backend if (world > 1 or force_dp) else "none", dev, elapsed, args.steps, trainer)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t)
     pairs_per_s = world * B * args.steps / elapsed
+
+    # SM3_BENCH_AB_P2P=1 (multi-rank runs, opt-in): the same timed loop once more with the SyncBN statistics going through the
+    # hipIpc mailboxes (csrc/p2p.hip) instead of RCCL; rank 0 then prints a SECOND, line-compatible record after the
+    # contract's one -- the first multi-GPU run can A/B the two exchanges in one launch.  Never on by default.
+    ab_record = None
+    if os.environ.get("SM3_BENCH_AB_P2P") == "1" and (world > 1 or force_dp) and trainer.sync_bn \
+            and getattr(trainer, "_p2p", None) is None:
+        os.environ["SM3_SYNCBN_P2P"] = "1"
+        trainer._engine().__dict__["_explicit_sync"] = None
+        trainer._engine()  # re-wires the statistics exchange (maps the mailboxes: a collective over every rank)
+        for _ in range(args.warmup):
+            trainer.step(derm, clinic)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            loss2 = trainer.step(derm, clinic)
+        sync()
+        el2 = time.perf_counter() - t1
+        trainer.check()
+        w2 = dp_witness(world, backend, dev, el2, args.steps, trainer)
+        t2 = torch.tensor([el2], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        el2 = float(t2)
+        ab_record = {"metric": f"SM3 pretrain images/sec (paired {S}x{S})", "value": round(world * B * args.steps / el2, 2),
+                     "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                     "ms_per_step": round(1e3 * el2 / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+                     "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                     "config": {"workload": "as the first line; SyncBN statistics exchanged peer-to-peer (SM3_SYNCBN_P2P=1)",
+                                "global_batch": B * world, "parallelism": f"dp{world}", "loss": round(float(loss2), 5),
+                                "witness": w2}}
+        trainer.close()
+        os.environ["SM3_SYNCBN_P2P"] = "0"
+        trainer._engine()
 
     # The timed steps run the derm and clinic branches on two HIP streams, so a launch of the dominant kernel
     # shares the chip with the other lane's kernels and its event-bracketed duration there is NOT the kernel's own
@@ -618,7 +696,10 @@ def main():
                        "negatives": "global (all-gather)" if args.global_negatives else "local (reference)",
                        "extensions": {"metadata_dim": args.metadata_dim, "target_momentum": args.target_momentum},
                        "loss": round(loss_val, 5),
-                       "peak_hbm_allocated_gb": peak_gb},
+                       "peak_hbm_allocated_gb": peak_gb,
+                       # what ran, measured rather than echoed: ranks counted by an all-reduce of ones, the collective
+                       # library's version, how the SyncBN statistics travelled, every rank's own ms/step
+                       "witness": witness},
             "roofline": roofline,
         }
         if other_modes:
@@ -626,6 +707,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, S, args.cpu_steps)
         print(json.dumps(out), flush=True)
+        if ab_record is not None:
+            print(json.dumps(ab_record), flush=True)
     if world > 1 or force_dp:
         dist.destroy_process_group()
 

@@ -522,10 +522,15 @@ int sm3_mlc_kmeans_update(float* centroids, const float* sums, const int* counts
  * sm3_p2p_allreduce_f64: buf[0..n) += the same range of every other rank, in place, ONE launch on `stream`, result
  * bit-identical on all ranks (contributions added in rank order).  mailboxes: host array of `world` device pointers indexed by
  * rank (one's own included); seq: 1, 2, 3, ... -- the same value on every rank for the same exchange, per mailbox set;
- * n <= sm3_p2p_max_elems(); err_flag (device int): set to 1 when a peer's contribution did not arrive within timeout_s. */
+ * n <= sm3_p2p_max_elems(); err_flag (device int): set to 1 when a peer's contribution did not arrive within timeout_s --
+ * that exchange and EVERY later one with the same err_flag then writes NaN into buf and returns at once (no further waits),
+ * so the failure shows in whatever is computed from the sums even if the flag is never read.
+ * Mailboxes are fine-grained device memory (hipExtMallocWithFlags(hipDeviceMallocFinegrained), as RCCL's IPC buffers);
+ * *kind_out (nullable) = 1, or 0 when that allocation / its IPC export failed and plain hipMalloc memory was used instead
+ * (also forced by SM3_P2P_FINEGRAINED=0, for an A/B of the two). */
 int sm3_p2p_mailbox_bytes(void);
 int sm3_p2p_max_elems(void);
-int sm3_p2p_alloc(void** ptr, void* ipc_handle_64);
+int sm3_p2p_alloc(void** ptr, void* ipc_handle_64, int* kind_out);
 int sm3_p2p_open(const void* ipc_handle_64, void** ptr);
 int sm3_p2p_close(void* ptr);
 int sm3_p2p_free(void* ptr);

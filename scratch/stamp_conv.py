@@ -28,7 +28,7 @@ def run(name, N, H, W, Ci, Co, k, stats=True):
     y = torch.empty(M, Co, dtype=dt, device=dev)
     part = torch.empty(ops.conv_partial_rows(d) * 2 * Co, device=dev) if stats else None
     waves = ((M + 127) // 128) * ((Co + 127) // 128) * 4
-    buf = torch.zeros(waves * 12, dtype=torch.int64, device=dev)
+    buf = torch.zeros(waves * 24, dtype=torch.int64, device=dev)
     assert lib.sm3_debug_set_stamps(buf.data_ptr(), waves) == 0
     for _ in range(3):
         ops.conv_gemm(d, x, w, y, None, part)
@@ -44,7 +44,7 @@ def run(name, N, H, W, Ci, Co, k, stats=True):
         torch.cuda.synchronize()
         times.append(e0.elapsed_time(e1))
     lib.sm3_debug_set_stamps(None, 0)
-    r = buf.cpu().numpy().astype(np.uint64).reshape(waves, 12)
+    r = buf.cpu().numpy().astype(np.uint64).reshape(waves, 24)
     r = r[r[:, 3] > 0]
     ns = r[:, 8].astype(np.float64)
     ok = ns > 0

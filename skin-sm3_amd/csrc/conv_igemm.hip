@@ -38,36 +38,47 @@ namespace {
 //      2 / 3 round the GEMM result to 16 bits BEFORE the addend is added in fp32 -- what autocast does with a convolution
 //      output that is then accumulated -- and keep twice the bytes of 0 in flight per workgroup with half its barriers.
 #ifdef SM3_STAMP
-// Diagnostic build only (scratch/stamp_conv.py builds a second library with -DSM3_STAMP; in the product library no stamp
-// executes): s_memtime at the segment boundaries of the K loop, summed per wave, one 12-word record per wave written to
-// a buffer of its own (sm3_debug_set_stamps) -- no output value depends on a stamp.
+// Diagnostic build only (scratch/stamp_conv.py / stamp_phases.py build a second library with -DSM3_STAMP; in the product
+// library no stamp executes): s_memtime at the phase boundaries of the kernel (marks) and at the segment boundaries of the
+// 2-stage K loop (summed per wave), one 24-word record per wave written to a buffer of its own (sm3_debug_set_stamps) --
+// no output value depends on a stamp.
 __device__ unsigned long long* g_stamp_buf = nullptr;
 __device__ long g_stamp_cap = 0;
 struct StampRec {
-    unsigned long long t_entry, r_entry, t_loop0 = 0, t_loop1 = 0, seg[4] = {0, 0, 0, 0};
+    unsigned long long t_entry, r_entry, t_loop0 = 0, t_loop1 = 0, seg[4] = {0, 0, 0, 0}, mark[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int nsteps = 0;
     __device__ StampRec() : t_entry(__builtin_amdgcn_s_memtime()), r_entry(__builtin_amdgcn_s_memrealtime()) {}
     __device__ ~StampRec() {
         const unsigned long long t_exit = __builtin_amdgcn_s_memtime();
         const long wave = ((long)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x / 64) + (threadIdx.x >> 6);
         if ((threadIdx.x & 63) == 0 && g_stamp_buf && wave < g_stamp_cap) {
-            unsigned long long* o = g_stamp_buf + wave * 12;
+            unsigned long long* o = g_stamp_buf + wave * 24;
             o[0] = t_entry; o[1] = t_loop0; o[2] = t_loop1; o[3] = t_exit;
             o[4] = seg[0]; o[5] = seg[1]; o[6] = seg[2]; o[7] = seg[3];
             o[8] = (unsigned long long)nsteps; o[9] = blockIdx.x; o[10] = r_entry; o[11] = __builtin_amdgcn_s_memrealtime();
+            for (int i = 0; i < 8; ++i) o[12 + i] = mark[i];
+            o[20] = threadIdx.x >> 6;
         }
     }
 };
 #define SM3_STAMP_NOW() __builtin_amdgcn_s_memtime()
+#define SM3_MARK(i) (stamp.mark[i] = __builtin_amdgcn_s_memtime())
+#else
+#define SM3_MARK(i) ((void)0)
 #endif
 
-template <typename T, int BM, int BN, int WM, int WN, int STAGES, int EPI, bool SEG = false>
-__global__ __launch_bounds__(WM* WN * 64, (EPI == 3 ? 4 : 2)) void conv_igemm_kernel(const ConvParams p) {  // EPI 3: 130 -> 128 registers, 4 workgroups per CU
+// SPLIT (2-stage K loop only): the workgroup carries WM*WN extra LOADER waves (waves WM*WN ... 2*WM*WN-1).  They own the
+// tap bookkeeping and every LDS-DMA piece of the K loop and leave after it; the WM*WN CONSUMER waves (the only ones that
+// hold accumulators) issue nothing but ds_read_b128 + MFMA in the loop and run the epilogue alone.  Same stage ring,
+// same one barrier per K-step, same arithmetic in the same order: outputs are bit-identical to the unsplit kernel.
+template <typename T, int BM, int BN, int WM, int WN, int STAGES, int EPI, bool SEG = false, bool SPLIT = false>
+__global__ __launch_bounds__(WM* WN * 64 * (SPLIT ? 2 : 1), ((EPI == 3 || SPLIT) ? 4 : 2)) void conv_igemm_kernel(const ConvParams p) {  // EPI 3: 130 -> 128 registers, 4 workgroups per CU
 #ifdef SM3_STAMP
     StampRec stamp;
 #endif
     constexpr bool LEAN = EPI >= 1;
     static_assert(!(SEG && EPI == 1) && !(SEG && STAGES > 2), "segments: data-gradient epilogues, 1 or 2 stages");
+    static_assert(!SPLIT || STAGES == 2, "loader / consumer waves: 2-stage K loop");
     constexpr int NT = WM * WN * 64;
     constexpr int RPP = NT / 8;  // rows covered per loader pass
     constexpr int AI = BM / RPP, BI = BN / RPP;
@@ -85,8 +96,11 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI == 3 ? 4 : 2)) void conv_igemm_ke
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (LDS-DMA base goes to M0)
+    const int wave_all = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);  // provably wave-uniform
+    const bool is_loader = SPLIT && wave_all >= WM * WN;
+    // loader waves index the tile rows exactly like the unsplit kernel's waves do (tid 0 .. NT-1)
+    const int tid = SPLIT ? (int)threadIdx.x - (is_loader ? NT : 0) : (int)threadIdx.x, lane = tid & 63;
+    const int wave = SPLIT ? wave_all - (is_loader ? WM * WN : 0) : wave_all;  // (LDS-DMA base goes to M0)
     const int wm = wave / WN, wn = wave % WN;
 
     // XCD-aware block remap (bijective): blocks that share an A row-panel run on one XCD's L2.
@@ -198,6 +212,31 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI == 3 ? 4 : 2)) void conv_igemm_ke
 
     auto compute = [&](int stage) {
         const char* sS = smem + stage * STAGE;
+        if constexpr (SPLIT) {
+            // consumer waves: the fragments of K-quarter kk+1 are requested before the MFMAs of quarter kk are issued
+            // (a second fragment register set: the loop has them to spare, the epilogue sets the kernel's maximum)
+            uint4 fa[2][TM], fb[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const uint4*>(sS + fa_base[i]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const uint4*>(sS + fb_base[j]);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (kk < 3) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        fa[(kk + 1) & 1][i] = *reinterpret_cast<const uint4*>(sS + (fa_base[i] ^ ((kk + 1) << 5)));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        fb[(kk + 1) & 1][j] = *reinterpret_cast<const uint4*>(sS + (fb_base[j] ^ ((kk + 1) << 5)));
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) mma_frag<T>(fa[kk & 1][i], fb[kk & 1][j], acc[i][j]);
+            }
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             uint4 fa[TM], fb[TN];
@@ -214,6 +253,7 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI == 3 ? 4 : 2)) void conv_igemm_ke
 
     const int nsteps = SEG ? p.nsteps_seg : p.ntaps * p.kchunks;
     int t = 0, kc = 0;
+    SM3_MARK(0);
     set_tap(0);
     int kch = (SEG && cur_src) ? p.kchunks1 : p.kchunks;  // K-steps of the current tap
     uint32_t wtap_off = (uint32_t)p.wtap[0] * ((SEG && cur_src) ? row_bytes1 : row_bytes);
@@ -226,6 +266,29 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI == 3 ? 4 : 2)) void conv_igemm_ke
             wtap_off = (uint32_t)p.wtap[t] * ((SEG && cur_src) ? row_bytes1 : row_bytes);
         }
     };
+    if constexpr (SPLIT) {
+        if (is_loader) {
+            dma_stage(0, 0, wtap_off);
+            dma_drain();
+            __syncthreads();  // publishes stage 0
+            for (int s = 0; s < nsteps; ++s) {
+                if (s + 1 < nsteps) {
+                    advance();
+                    dma_stage((s + 1) & 1, (uint32_t)kc * 128u, wtap_off + (uint32_t)kc * 128u);
+                }
+                dma_drain();      // stage s+1 has landed (this wave's pieces)
+                __syncthreads();  // ... everyone's; the consumers are done reading stage s
+            }
+            return;  // a terminated wave no longer counts at s_barrier: the epilogue belongs to the consumers
+        }
+        if (p.dbg & 1) __builtin_amdgcn_s_setprio(1);
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            compute(s & 1);
+            __syncthreads();
+        }
+        if (p.dbg & 1) __builtin_amdgcn_s_setprio(0);
+    } else {
     dma_stage(0, 0, wtap_off);
     if constexpr (STAGES > 2) {
         // Deep pipeline for launches of at most one workgroup per CU (projector Linears: M = 256..512 rows, 32 K-steps):
@@ -254,6 +317,7 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI == 3 ? 4 : 2)) void conv_igemm_ke
         __syncthreads();  // publishes the stage
 #ifdef SM3_STAMP
         stamp.t_loop0 = SM3_STAMP_NOW();
+        stamp.mark[1] = stamp.t_loop0;
         stamp.nsteps = nsteps;
 #endif
         for (int s = 0; s < nsteps; ++s) {
@@ -287,6 +351,10 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI == 3 ? 4 : 2)) void conv_igemm_ke
     } else {
         dma_drain();
         __syncthreads();  // publishes the stage
+        SM3_MARK(1);
+#ifdef SM3_STAMP
+        stamp.nsteps = nsteps;
+#endif
         for (int s = 0; s < nsteps; ++s) {
             compute(0);
             __syncthreads();  // everyone is done reading the stage
@@ -298,6 +366,8 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI == 3 ? 4 : 2)) void conv_igemm_ke
             }
         }
     }
+    }  // !SPLIT
+    SM3_MARK(2);
 
     // ---- lean epilogue: bf16 forward convolution, dense output, no addend / BN-backward fusion ----------------
     // What the train-mode forward launches need, at a quarter of the general epilogue's VALU work (which, with 3-4
@@ -360,6 +430,7 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI == 3 ? 4 : 2)) void conv_igemm_ke
 #pragma unroll
             for (int k = 0; k < NEARLY; ++k) request(k);
         }
+        SM3_MARK(6);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float s1 = 0.f, s2 = 0.f;
@@ -410,6 +481,7 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI == 3 ? 4 : 2)) void conv_igemm_ke
             }
         }
         __syncthreads();
+        SM3_MARK(3);
         if (p.partials && tid < BN && n0 + tid < p.Co) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -435,6 +507,7 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI == 3 ? 4 : 2)) void conv_igemm_ke
                         stg16<true>(yp + k * ystep, *reinterpret_cast<const uint4*>(sp + k * RSTEP * LEAN_PITCH));
                 }
             }
+            SM3_MARK(4);
             return;
         } else {
             const bool epl2 = p.ep_scale != nullptr || p.ep_rv != nullptr;
@@ -494,6 +567,7 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI == 3 ? 4 : 2)) void conv_igemm_ke
                 }
                 stg16<true>(p.y + eoff[k], packed);
             }
+            SM3_MARK(4);
             if constexpr (EPI == 3) {
                 if (fz) {
                     const int fz_prow = tile_view ? p.fz_row_off1 + bm - p.fz_view_tiles : p.fz_row_off + bm;
@@ -511,6 +585,7 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI == 3 ? 4 : 2)) void conv_igemm_ke
                         for (int rl = 0; rl < NT / CPR; ++rl) a += sRed[(rl * CPR + col / 8) * 16 + stat * 8 + col % 8];
                         if (n0 + col < p.Co) p.fz_partials[((long)fz_prow * 2 + stat) * p.Co + n0 + col] = a;
                     }
+                    SM3_MARK(5);
                 }
             }
             return;
@@ -729,9 +804,13 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI == 3 ? 4 : 2)) void conv_igemm_ke
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int STAGES, int EPI, bool SEG = false>
+template <typename T, int BM, int BN, int WM, int WN, int STAGES, int EPI, bool SEG = false, bool SPLIT = false>
 int launch_conv_st(const ConvParams& p0, hipStream_t st) {
     ConvParams p = p0;
+    {
+        const char* dv = getenv("SM3_CONV_DBG");
+        p.dbg = dv ? atoi(dv) : 0;
+    }
     constexpr bool LEAN = EPI >= 1;
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int C_BYTES = LEAN ? BM * (BN * 2 + 16) : (BM / WM) * (BN + 4) * 4;
@@ -740,7 +819,7 @@ int launch_conv_st(const ConvParams& p0, hipStream_t st) {
     static_assert(MAIN >= 256 * 2 * 8 * 4, "reduction scratch of the fused BN-backward epilogue must fit");
     p.tilesM = (p.M + BM - 1) / BM;
     p.tilesN = (p.Co + BN - 1) / BN;
-    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, STAGES, EPI, SEG>;
+    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, STAGES, EPI, SEG, SPLIT>;
     // the dynamic-LDS limit is a per-device attribute of the function: set it once per (instantiation, device)
     static std::atomic<uint32_t> attr_set{0};  // bit d: done on device d
     int dev = 0;
@@ -753,15 +832,34 @@ int launch_conv_st(const ConvParams& p0, hipStream_t st) {
     }
     const long nblocks = (long)p.tilesM * p.tilesN;
     if (nblocks <= 0 || nblocks > 0x7fffffffL) return SM3_EINVAL;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(WM * WN * 64), LDS, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(WM * WN * 64 * (SPLIT ? 2 : 1)), LDS, st, p);
     SM3_CHECK_LAUNCH();
     return 0;
+}
+
+// SM3_CONV_SPLIT (A/B switch, read at every launch): loader / consumer waves in the 2-stage K loop of
+//   bit 0: the plain forward launches (EPI 1) with >= 4 K-steps per tap on 128-column tiles -- where it measures faster
+//          (profiles/r04a_split_ab.txt: +3 ... +17 % at Ci >= 256, nothing at Ci = 128, -12 % on the 64-column tiles),
+//   bit 1 / 2 / 3: EPI 2 / EPI 3 / two-segment launches, bit 4: bit 0 without the shape rule.
+static int conv_split_mode() {
+    const char* v = getenv("SM3_CONV_SPLIT");
+    return v ? atoi(v) : 0;  // default off: inside a step it equals the 8-wave variant on the 3x3 forward launches (+-0.5 %)
+}
+template <int EPI, int BN>
+static bool conv_split_wanted(const ConvParams& p) {
+    const int m = conv_split_mode();
+    if (EPI == 1) return (m & 16) || ((m & 1) && BN == 128 && p.kchunks >= 4);
+    return EPI == 2 ? (m & 2) : EPI == 3 ? (m & 4) : false;
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int EPI>
 int launch_conv_epi(const ConvParams& p, hipStream_t st, bool single, bool deep) {
     if (deep) return launch_conv_st<T, BM, BN, WM, WN, 4, EPI>(p, st);
-    return single ? launch_conv_st<T, BM, BN, WM, WN, 1, EPI>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, EPI>(p, st);
+    if (single) return launch_conv_st<T, BM, BN, WM, WN, 1, EPI>(p, st);
+    if constexpr (EPI >= 1) {
+        if (conv_split_wanted<EPI, BN>(p)) return launch_conv_st<T, BM, BN, WM, WN, 2, EPI, false, true>(p, st);
+    }
+    return launch_conv_st<T, BM, BN, WM, WN, 2, EPI>(p, st);
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -773,9 +871,15 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
     if (p.x1) {  // two K segments (16-bit types only: the exact-f32 parity mode never takes the linear BatchNorm backward)
         if constexpr (sizeof(T) == 2) {
             const bool one = p.nsteps_seg <= single_max;
-            if (lean && p.fz_partials)
+            const bool split = !one && (conv_split_mode() & 8);
+            if (lean && p.fz_partials) {
+                if (split) return launch_conv_st<T, BM, BN, WM, WN, 2, 3, true, true>(p, st);
                 return one ? launch_conv_st<T, BM, BN, WM, WN, 1, 3, true>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, 3, true>(p, st);
-            if (lean) return one ? launch_conv_st<T, BM, BN, WM, WN, 1, 2, true>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, 2, true>(p, st);
+            }
+            if (lean) {
+                if (split) return launch_conv_st<T, BM, BN, WM, WN, 2, 2, true, true>(p, st);
+                return one ? launch_conv_st<T, BM, BN, WM, WN, 1, 2, true>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, 2, true>(p, st);
+            }
             return one ? launch_conv_st<T, BM, BN, WM, WN, 1, 0, true>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, 0, true>(p, st);
         } else {
             return SM3_EDTYPE;
@@ -798,7 +902,7 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
                 // stage's LDS-DMA pieces instead of 8, which is as long as its MFMA phase (profiles/r03b_smemtime_kloop_timeline.txt):
                 // +2 ... +8 % on these layers; the short-K 1x1 layers lose (their epilogue on 512 threads) and keep 4 waves.
                 static const bool w8 = !(getenv("SM3_CONV_W8") && atoi(getenv("SM3_CONV_W8")) == 0);
-                if (w8 && p.ntaps >= 9 && !single && !deep) return launch_conv_st<T, BM, BN, 2, 4, 2, 1>(p, st);
+                if (w8 && p.ntaps >= 9 && !single && !deep && !conv_split_wanted<1, BN>(p)) return launch_conv_st<T, BM, BN, 2, 4, 2, 1>(p, st);
             }
             return launch_conv_epi<T, BM, BN, WM, WN, 1>(p, st, single, deep);  // train-mode forward, conv + evalBN (+ReLU)
         }

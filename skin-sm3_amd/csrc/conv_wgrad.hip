@@ -332,7 +332,9 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const WgradParams 
             }
 }
 
-static int g_last_slabs = 0;  // slabs per view of the most recent launch (sm3_conv_wgrad_slabs returns it)
+// slabs per view of this host thread's most recent launch (sm3_conv_wgrad_slabs returns it right after its own launch;
+// thread_local: launches from another host thread -- a second engine, an evaluation thread -- cannot get in between)
+static thread_local int g_last_slabs = 0;
 
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);

@@ -12,8 +12,9 @@
 //   area of kMaxN doubles, per (slot, source, block) a 64-bit flag.
 //   block b of rank r:  (1) stores its chunk of r's sums into mailbox[p][slot][r] of every rank p (self included),
 //                       (2) waits for those stores to be acknowledged, then flag[p][slot][r][b] = seq,
-//                       (3) waits until flag[r][slot][q][b] == seq for every source q  (wall-clock timeout -> *err = 1 and
-//                           the kernel returns: no wave spins forever),
+//                       (3) waits until flag[r][slot][q][b] == seq for every source q  (wall-clock timeout -> *err = 1, the
+//                           caller's sums become NaN and the kernel returns: no wave spins forever; once *err is set
+//                           every later exchange returns NaN at once),
 //                       (4) adds the world's chunks in RANK ORDER and writes the result in place: bit-identical on every
 //                           rank.  (Every mailbox access is a system-scope relaxed atomic; no fences -- see the kernel.)
 //   Two slots suffice: a rank can enter exchange i + 2 (same slot as i) only after every peer has raised its flag for
@@ -21,6 +22,7 @@
 //
 // Opt-in (SM3_SYNCBN_P2P=1, sm3hip/p2p.py), RCCL stays the default: two processes sharing one GPU exercise every line of
 // this file (tests/test_p2p_gpu.py), but the xGMI path between devices has never run -- this pool has one-GPU boxes only.
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -46,6 +48,13 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(double* __restrict__
                                                             unsigned long long timeout_ticks) {
     const int b = blockIdx.x, slot = (int)(seq & 1);
     const int i0 = b * kChunk, i1 = min(n, i0 + kChunk);
+    // An exchange that has already failed on this rank stays failed: no further waiting (a dead peer would cost its full
+    // timeout 220 times per step), and the caller's sums are replaced by NaN so that whatever is computed from them -- the
+    // BatchNorm statistics, the loss the trainer returns -- shows it, with or without a host read of *err.
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        for (int i = i0 + threadIdx.x; i < i1; i += 256) buf[i] = __longlong_as_double(0x7ff8000000000000LL);
+        return;
+    }
     // Every access to a mailbox is a system-scope atomic (relaxed): such stores write through and such loads read past the
     // caches, so no release / acquire FENCE is needed (a system-scope fence writes back and invalidates the whole L2, paid by
     // the NEXT kernel of the lane).  Ordering comes from the in-order issue of a wave plus
@@ -81,6 +90,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(double* __restrict__
     __syncthreads();
     if (s_bad) {
         if (threadIdx.x == 0) atomicExch(err, 1);
+        for (int i = i0 + threadIdx.x; i < i1; i += 256) buf[i] = __longlong_as_double(0x7ff8000000000000LL);
         return;
     }
     // (4) the world's chunks, added in rank order
@@ -98,20 +108,44 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(double* __restrict__
 extern "C" int sm3_p2p_mailbox_bytes(void) { return (int)sizeof(Mailbox); }
 extern "C" int sm3_p2p_max_elems(void) { return kMaxN; }
 
-extern "C" int sm3_p2p_alloc(void** ptr, void* ipc_handle_64) {
+// Mailboxes are FINE-GRAINED device memory (hipExtMallocWithFlags(hipDeviceMallocFinegrained), what RCCL uses for its own
+// IPC flag / data buffers): stores of another agent become visible to a kernel that is already running and polling, which
+// coarse-grained hipMalloc memory promises only at kernel boundaries.  Plain hipMalloc is the fallback when the
+// fine-grained allocation or its IPC export fails; *kind_out says which one this mailbox is (1 fine-grained, 0 plain) so a
+// run can record what it measured.
+static hipError_t alloc_export(void** p, hipIpcMemHandle_t* h, bool fine) {
+    hipError_t e = fine ? hipExtMallocWithFlags(p, sizeof(Mailbox), hipDeviceMallocFinegrained) : hipMalloc(p, sizeof(Mailbox));
+    if (e != hipSuccess) {
+        *p = nullptr;
+        return e;
+    }
+    e = hipMemset(*p, 0, sizeof(Mailbox));
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipIpcGetMemHandle(h, *p);
+    if (e != hipSuccess) {
+        (void)hipFree(*p);
+        *p = nullptr;
+    }
+    return e;
+}
+
+extern "C" int sm3_p2p_alloc(void** ptr, void* ipc_handle_64, int* kind_out) {
     if (!ptr || !ipc_handle_64) return SM3_EINVAL;
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+    const char* v = getenv("SM3_P2P_FINEGRAINED");  // 0: plain hipMalloc (A/B of the two memory types)
+    const bool want_fine = !(v && atoi(v) == 0);
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, sizeof(Mailbox));
-    if (e != hipSuccess) return (int)e;
-    e = hipMemset(p, 0, sizeof(Mailbox));
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipIpcGetMemHandle((hipIpcMemHandle_t*)ipc_handle_64, p);
-    if (e != hipSuccess) {
-        (void)hipFree(p);
-        return (int)e;
+    int kind = 0;
+    hipError_t e = hipErrorUnknown;
+    if (want_fine) {
+        e = alloc_export(&p, (hipIpcMemHandle_t*)ipc_handle_64, true);
+        if (e == hipSuccess) kind = 1;
+        else (void)hipGetLastError();  // the fallback below starts from a clean error state
     }
+    if (e != hipSuccess) e = alloc_export(&p, (hipIpcMemHandle_t*)ipc_handle_64, false);
+    if (e != hipSuccess) return (int)e;
     *ptr = p;
+    if (kind_out) *kind_out = kind;
     return 0;
 }
 

@@ -64,7 +64,7 @@ SIGNATURES = {
     "sm3_linbn_fold": [_P, _I, _I, _I, _P, _P],
     "sm3_p2p_mailbox_bytes": [],
     "sm3_p2p_max_elems": [],
-    "sm3_p2p_alloc": [_P, _P],
+    "sm3_p2p_alloc": [_P, _P, _P],
     "sm3_p2p_open": [_P, _P],
     "sm3_p2p_close": [_P],
     "sm3_p2p_free": [_P],

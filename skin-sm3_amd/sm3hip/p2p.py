@@ -23,15 +23,24 @@ class P2PStatSync:
         self.timeout_s = float(timeout_s)
         self.device = device
         self.err = torch.zeros(1, dtype=torch.int32, device=device)
+        self._err_host = torch.zeros(1, dtype=torch.int32).pin_memory()  # poll(): last value copied back, no host wait
+        self._err_event = None
         self._own, self._peers, self._boxes, self._seq = {}, {}, {}, {}
+        kinds = set()
         with torch.cuda.device(device):
             handles = {}
             for lane in lanes:
                 ptr = C.c_void_p()
                 h = (C.c_ubyte * 64)()
-                check(lib.sm3_p2p_alloc(C.byref(ptr), h), "sm3_p2p_alloc")
+                kind = C.c_int(-1)
+                check(lib.sm3_p2p_alloc(C.byref(ptr), h, C.byref(kind)), "sm3_p2p_alloc")
                 self._own[lane] = ptr.value
                 handles[lane] = bytes(h)
+                kinds.add(kind.value)
+        # what the mailboxes of THIS rank are made of: "finegrained" (hipExtMallocWithFlags, as RCCL's IPC buffers),
+        # "coarse" (plain hipMalloc: the fallback, or SM3_P2P_FINEGRAINED=0) -- bench.py records it next to its numbers
+        self.memory_kind = "finegrained" if kinds == {1} else ("coarse" if kinds == {0} else "mixed")
+        with torch.cuda.device(device):
             gathered = [None] * self.world
             dist.all_gather_object(gathered, handles)  # every rank's {lane: handle}
             for lane in lanes:
@@ -60,15 +69,33 @@ class P2PStatSync:
                                                 self._seq[lane], self.err.data_ptr(), self.timeout_s, _stream()),
               "sm3_p2p_allreduce_f64")
 
+    _MSG = ("P2PStatSync: a peer's statistics did not arrive in time (rank died or ranks out of step); every exchange "
+            "since then returned NaN")
+
     def check(self):
         """Raise if any exchange so far timed out (synchronises)."""
         if int(self.err.item()):
-            raise RuntimeError("P2PStatSync: a peer's statistics did not arrive in time (rank died or ranks out of step)")
+            raise RuntimeError(self._MSG)
 
-    def close(self):
+    def poll(self):
+        """The same without a host wait: raises if the flag copied back by the PREVIOUS poll() reads 1, then enqueues a new
+        copy on the current stream.  A trainer calls it once per step, so a failed exchange raises one step late at the
+        latest (the step's loss is NaN in the meantime: the kernel poisons the sums)."""
+        if self._err_event is not None and self._err_event.query() and int(self._err_host[0]):
+            raise RuntimeError(self._MSG)
+        if self._err_event is None or self._err_event.query():
+            self._err_host.copy_(self.err, non_blocking=True)
+            self._err_event = torch.cuda.Event()
+            self._err_event.record()
+
+    def close(self, barrier=True):
+        """Unmap the peers' mailboxes and free one's own.  barrier=False: at interpreter teardown or after a failed
+        exchange, when the peers can no longer be counted on to arrive."""
+        if not self._own:
+            return
         lib = _lib.load()
         torch.cuda.synchronize(self.device)
-        if dist.is_initialized():
+        if barrier and dist.is_initialized():
             dist.barrier()  # nobody unmaps while a peer may still write
         for lane, opened in self._peers.items():
             for p in opened:

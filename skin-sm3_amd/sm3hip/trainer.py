@@ -77,7 +77,8 @@ class SM3Trainer:
                 # (csrc/p2p.hip) instead of an RCCL all-reduce; single node, at most 8 ranks
                 from .p2p import P2PStatSync
                 dev = eng.store.flat_p.device if eng.store is not None else torch.device("cuda", torch.cuda.current_device())
-                self._p2p = P2PStatSync([k for k in self._groups if k != "grads"], dev)
+                self._p2p = P2PStatSync([k for k in self._groups if k != "grads"], dev,
+                                        timeout_s=float(os.environ.get("SM3_P2P_TIMEOUT_S", "20")))
                 eng.stat_sync = lambda t: self._p2p(eng._lane, t)
             else:
                 eng.stat_sync = lambda t: dist.all_reduce(t, group=self._groups[eng._lane])
@@ -106,7 +107,6 @@ class SM3Trainer:
         a, b = self._bucket_range(eng, first, last)
         ops.adamw(st.flat_p[a:b], st.flat_g[a:b], self.m[a:b], self.v[a:b], self.lr, self.betas[0], self.betas[1], self.eps,
                   self.wd, self.step_count, 1.0)
-        self._covered += b - a
 
     # ---- global negatives: all-gather of the projection embeddings (north_star; opt-in) ---------------------------
     def _ntxent_global(self, eng, name, z, T, weight, loss, dz_out, dz_scale):
@@ -181,7 +181,34 @@ class SM3Trainer:
         metadata (extension; model built with metadata_dim): [B, d] fp32 -- two more NT-Xent terms of weight 1/2 contrast
         meta_proj(metadata) with the cross-modal projections of the first derm / clinic views."""
         with ops.stream_scope():  # launches outside the lanes go to the stream that is current now
-            return self._step(derm_imgs, clinic_imgs, metadata)
+            loss = self._step(derm_imgs, clinic_imgs, metadata)
+            p2p = self.__dict__.get("_p2p")
+            if p2p is not None:
+                # a statistics exchange that timed out: the kernel has poisoned its sums (this step's loss is NaN), and
+                # the flag raises here no later than the next step -- without a host wait inside the step
+                p2p.poll()
+            return loss
+
+    def check(self):
+        """Raise if a peer-to-peer statistics exchange has failed so far (synchronises; no-op on the RCCL path)."""
+        p2p = self.__dict__.get("_p2p")
+        if p2p is not None:
+            p2p.check()
+
+    def close(self, barrier=True):
+        """Release the peer-to-peer mailboxes (SM3_SYNCBN_P2P=1); safe to call more than once."""
+        p2p = self.__dict__.pop("_p2p", None)
+        if p2p is not None:
+            eng = sm3_engine_for(self.model, self.kind)
+            eng.stat_sync = None
+            eng.__dict__["_explicit_sync"] = None
+            p2p.close(barrier=barrier)
+
+    def __del__(self):
+        try:
+            self.close(barrier=False)
+        except Exception:  # interpreter teardown: the device, the library or the process group may be gone already
+            pass
 
     def _step(self, derm_imgs, clinic_imgs, metadata=None):
         eng = self._engine()
@@ -261,9 +288,18 @@ class SM3Trainer:
         # during which nothing else runs).  Data parallel: the buckets are all-reduced instead and AdamW follows the last
         # one; fp16: the overflow check needs every gradient first.
         early = sc is None and not self.dp and os.environ.get("SM3_ADAMW_BUCKETS", "1") != "0"
-        if early:
+        # The bucket schedule (which gradient-ready notifications the backward pass emits) is a function of the engine, the
+        # style and the branches in use -- static.  It is verified ONCE per such configuration, on a step that still runs
+        # AdamW in one launch at the end: the notified ranges must tile [0, total) exactly, and a schedule that does not
+        # raises BEFORE any parameter has been touched (never after half of the in-place updates).
+        sched_key = (id(eng), self.style, metadata is not None, self.target_momentum is not None, st.total)
+        verify = early and self.__dict__.get("_sched_ok") != sched_key
+        if verify:
+            early = False
+            ranges = []
+            eng.grad_ready = lambda f, l: ranges.append(self._bucket_range(eng, f, l))
+        elif early:
             self.step_count += 1
-            self._covered = 0
             eng.grad_ready = lambda f, l: self._bucket_adamw(eng, f, l)
         else:
             eng.grad_ready = (lambda f, l: self._bucket_ready(eng, f, l)) if self.dp else None
@@ -271,9 +307,18 @@ class SM3Trainer:
         eng.grad_ready = None
         for h in self._handles:
             h.wait()
+        if verify:
+            pos = 0
+            for a, b in sorted(ranges):
+                if a != pos or b <= a:
+                    break
+                pos = b
+            if pos != st.total or len(ranges) == 0:
+                raise RuntimeError(f"gradient-ready notifications do not tile the {st.total} parameters exactly once "
+                                   f"(contiguous cover ends at {pos}, {len(ranges)} notifications)")
+            self._sched_ok = sched_key
         if early:
-            if self._covered != st.total:  # every parameter belongs to exactly one bucket (tests/test_host_logic.py)
-                raise RuntimeError(f"gradient-ready notifications covered {self._covered} of {st.total} parameters")
+            pass  # every bucket has had its AdamW launch on the lane that finished it
         elif sc is None:
             self.step_count += 1
             ops.adamw(st.flat_p, st.flat_g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,

@@ -119,12 +119,17 @@ def cluster_memory(args, prototype, K, local_index, local_emb, nmb_kmeans_iters=
     assignments = -100 * torch.ones(len(local_index) * world, dtype=torch.long, device=dev)
     centroids = torch.empty(K, local_emb.size(1), device=dev)
     if world > 1:
-        all_emb = [torch.empty_like(local_emb) for _ in range(world)] if rank == 0 else None
-        all_idx = [torch.empty_like(local_index) for _ in range(world)] if rank == 0 else None
-        dist.gather(local_emb.contiguous(), all_emb)
-        dist.gather(local_index, all_idx)
+        # gloo has no gather for device tensors (a rehearsal of this tool with two ranks on ONE GPU runs over gloo,
+        # tests/test_round4_gpu.py): the bank then goes through host copies; RCCL gathers the device tensors directly
+        via_host = dist.get_backend() == "gloo" and local_emb.is_cuda
+        src_emb = local_emb.contiguous().cpu() if via_host else local_emb.contiguous()
+        src_idx = local_index.cpu() if via_host else local_index
+        all_emb = [torch.empty_like(src_emb) for _ in range(world)] if rank == 0 else None
+        all_idx = [torch.empty_like(src_idx) for _ in range(world)] if rank == 0 else None
+        dist.gather(src_emb, all_emb)
+        dist.gather(src_idx, all_idx)
         if rank == 0:
-            all_emb, all_idx = torch.cat(all_emb, 0), torch.cat(all_idx, 0)
+            all_emb, all_idx = torch.cat(all_emb, 0).to(dev), torch.cat(all_idx, 0).to(dev)
     else:
         all_emb, all_idx = local_emb, local_index
     if rank == 0:
@@ -140,10 +145,13 @@ def cluster_memory(args, prototype, K, local_index, local_emb, nmb_kmeans_iters=
 def main(local_rank, args):
     world = args.world_size
     args.rank = local_rank
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # test knobs, as in bench.py (a 2-rank rehearsal on a one-GPU box: both ranks on device 0 over gloo)
+    dev_index = int(os.environ.get("SM3_FORCE_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{args.port}", world_size=world, rank=local_rank)
+        dist.init_process_group(os.environ.get("SM3_DIST_BACKEND", "nccl"), init_method=f"tcp://127.0.0.1:{args.port}",
+                                world_size=world, rank=local_rank)
     torch.manual_seed(args.seed)
     if args.data_name != "synthetic":
         raise SystemExit("only --data-name synthetic is available in this build (dataset pipeline is out of scope)")
@@ -164,7 +172,7 @@ def main(local_rank, args):
     feat_dim = extractor.derm_feat_dim + extractor.clinic_feat_dim
     model = Model(extractor, MultiLabelProjector4(feat_dim, args.mlc_proj_dim, args.num_labels), args.mlc_proj_dim,
                   args.l2_norm, args.num_heads, args.sa_dim_ff, args.sa_dropout).to(dev)
-    wrapped = nn.parallel.DistributedDataParallel(model, device_ids=[local_rank]) if world > 1 else model
+    wrapped = nn.parallel.DistributedDataParallel(model, device_ids=[dev_index]) if world > 1 else model
     parameters = [p for p in model.parameters() if p.requires_grad]
     optimizer = torch.optim.AdamW(parameters, lr=args.base_lr, weight_decay=args.wd)
     criterion = nn.CrossEntropyLoss(ignore_index=-100)
@@ -190,6 +198,9 @@ def main(local_rank, args):
         all_assignments = [cluster_memory(args, proto, proto.weight.size(0), local_memory_index,
                                           local_memory_embeddings[i % len(local_memory_embeddings)], generator=gk)
                            for i, proto in enumerate(model.prototypes)]
+        if getattr(args, "probe", None) is not None:  # tests: what every rank ended up with after the broadcast
+            args.probe["assignments"] = [a.cpu() for a in all_assignments]
+            args.probe["prototypes"] = [p.weight.detach().cpu().clone() for p in model.prototypes]
         if args.finetune_backbone:
             model.train()
         else:  # mlc_train.py:230-235
@@ -218,6 +229,8 @@ def main(local_rank, args):
             if local_rank == 0 and it % args.print_freq == 0:
                 print(f"Train epoch: [{epoch}][{it}/{n_batches}] Loss {float(loss.detach()):.4f}", flush=True)
         history.append(total / max(seen, 1))
+        if getattr(args, "probe", None) is not None:
+            args.probe["model"] = model
         if local_rank == 0:
             print(f"epoch {epoch}: loss {history[-1]:.4f}, {time.time() - t0:.1f} s", flush=True)
             state = {"epoch": epoch + 1, "state_dict": model.state_dict(), "optimizer": optimizer.state_dict()}

@@ -35,6 +35,11 @@ def test_two_ranks_end_to_end_dry_run():
     assert len(lines) == 1, pr.stdout          # ONE JSON line, from rank 0
     out = json.loads(lines[0])
     assert out["dry_run"] is True and out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2"
+    # the record proves what ran: ranks COUNTED by a collective (not WORLD_SIZE echoed), the backend, how the SyncBN
+    # statistics travelled, one ms/step per rank
+    w = out["config"]["witness"]
+    assert w["rccl_ranks"] == 2 and w["backend"] == "gloo" and w["syncbn_exchange"] == "gloo"
+    assert len(w["ms_per_step_per_rank"]) == 2 and w["ms_per_step_min"] <= w["ms_per_step_max"]
 
 
 def test_a_rank_that_dies_stops_the_run_quickly():
@@ -48,8 +53,25 @@ def test_a_rank_that_dies_stops_the_run_quickly():
 
 def test_gpu_count_comes_from_sysfs_not_from_hip():
     b = _bench()
-    n = b.visible_gpus()
-    assert n is None or isinstance(n, int)
+    n, source = b.visible_gpus()
+    assert (n is None or isinstance(n, int)) and isinstance(source, str)
     src = open(os.path.join(ROOT, "bench.py")).read()
     body = src[src.index("def spawn_ranks("):src.index("def dry_run_rank(")]
     assert "torch.cuda" not in body             # the parent of the ranks never touches the GPU runtime
+
+
+def test_visible_device_lists_cap_the_gpu_count(monkeypatch):
+    """the pre-check of `--gpus N` honours HIP_ / ROCR_ / CUDA_VISIBLE_DEVICES (a rank beyond the list would die in
+    set_device) and says which source the number came from."""
+    b = _bench()
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    base, _ = b.visible_gpus()
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")
+    n, source = b.visible_gpus()
+    assert n == (1 if base is None else min(base, 1)) or (base == 0 and n == 0)
+    if base is None or base >= 1:
+        assert "HIP_VISIBLE_DEVICES" in source
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "")
+    n, source = b.visible_gpus()
+    assert n == 0 and "ROCR_VISIBLE_DEVICES" in source

@@ -48,7 +48,7 @@ class _AllGatherRows(torch.autograd.Function):
         return g[r * ctx.n:(r + 1) * ctx.n]
 
 
-def _rank_main(rank, world, port, q, Bl=4, global_neg=False, dt="f32", linbn=None):
+def _rank_main(rank, world, port, q, Bl=4, global_neg=False, dt="f32", linbn=None, latent=False):
     try:
         if linbn is not None:
             os.environ["SM3_LINBN"] = "1" if linbn else "0"
@@ -62,7 +62,14 @@ def _rank_main(rank, world, port, q, Bl=4, global_neg=False, dt="f32", linbn=Non
         from src.models.simclr import SimCLRSkinV32
         size, seed, T, lr = 64, 21, 0.1, 1e-3
         state = procedural.make_state_dict(seed=seed)
-        derm_np, clinic_np = procedural.make_pair_batch(Bl * world, size, seed)
+        if latent:
+            # learnable pairs (tools/backbone_train.py's `latent` synthetic data: two views share a latent pattern) -- a
+            # better-conditioned state than pure noise for judging 16-bit gradients against fp64
+            from test_config_gpu import _latent_batch
+            d_l, c_l = _latent_batch(Bl * world, size, seed)
+            derm_np, clinic_np = [t.cpu().numpy() for t in d_l], [t.cpu().numpy() for t in c_l]
+        else:
+            derm_np, clinic_np = procedural.make_pair_batch(Bl * world, size, seed)
         sl = slice(rank * Bl, (rank + 1) * Bl)
         # --- oracle, sharded exactly like DDP + SyncBatchNorm (fp64) ---
         P, Bf = O.split_state(state, torch.float64)
@@ -127,7 +134,7 @@ def test_two_rank_dp_step_matches_sharded_oracle(Bl):
         p.start()
     res = {}
     for _ in range(2):
-        r, ok, payload = q.get(timeout=900)
+        r, ok, payload = q.get(timeout=300)
         assert ok, f"rank {r} failed:\n{payload}"
         res[r] = payload
     for p in procs:
@@ -154,7 +161,7 @@ def test_two_rank_global_negatives_match_the_oracle():
         p.start()
     res = {}
     for _ in range(2):
-        r, ok, payload = q.get(timeout=900)
+        r, ok, payload = q.get(timeout=300)
         assert ok, f"rank {r} failed:\n{payload}"
         res[r] = payload
     for p in procs:
@@ -175,7 +182,7 @@ def _spawn2(args):
         p.start()
     res = {}
     for _ in range(2):
-        r, ok, payload = q.get(timeout=900)
+        r, ok, payload = q.get(timeout=300)
         assert ok, f"rank {r} failed:\n{payload}"
         res[r] = payload
     for p in procs:
@@ -189,8 +196,8 @@ def test_two_rank_dp_bf16_batchnorm_by_linearity_syncs_like_the_two_pass_form():
     linbn_stats / linbn_coef.  Two ranks on real kernels, bf16, both views in one batch -- against the same run with
     SM3_LINBN=0 (the two-pass SyncBN form the f32 test above validates against the sharded oracle): running statistics
     are those of the GLOBAL batch, replicas stay in sync, and the distance to the fp64 sharded oracle is no larger."""
-    on = _spawn2((32, False, "bf16", True))
-    off = _spawn2((32, False, "bf16", False))
+    on = _spawn2((32, False, "bf16", True, True))
+    off = _spawn2((32, False, "bf16", False, True))
     for res in (on, off):
         assert abs(res[0]["param_sum"] - res[1]["param_sum"]) < 1e-6 * abs(res[0]["param_sum"]) + 1e-6
         for r in (0, 1):
@@ -200,9 +207,9 @@ def test_two_rank_dp_bf16_batchnorm_by_linearity_syncs_like_the_two_pass_form():
         print(f"rank {r}: linear {a}\n        two-pass {b}")
         assert abs(a["loss"] - a["loss_ref"]) < max(1.5 * abs(b["loss"] - b["loss_ref"]), 0.1), (a, b)
         assert a["rm_err"] < 1.5 * b["rm_err"] + 1e-3 and a["rv_rel"] < 1.5 * b["rv_rel"] + 1e-2, (a, b)
-        # bf16 at this random-init state: gradient cosine against fp64 is ~0.12-0.17 for torch's own autocast too (see
-        # test_config_gpu.py T2), so only "no worse than the two-pass form" is asked
-        assert a["grad_cos"] > b["grad_cos"] - 0.1 and a["grad_cos"] > 0.05, (a, b)
+        # on learnable pairs the rank-averaged bf16 gradient points where the fp64 sharded oracle's does (VERDICT r3 item
+        # 6c: an absolute floor that a wrong gradient fails, not 0.05), and the linear form is no worse than the two-pass one
+        assert a["grad_cos"] > b["grad_cos"] - 0.1 and a["grad_cos"] > 0.3, (a, b)
 
 
 def _rccl_world1_main(port, q):
@@ -255,7 +262,7 @@ def test_rccl_world1_runs_every_collective_of_the_dp_path():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_world1_main, args=(port, q))
     p.start()
-    ok, payload = q.get(timeout=600)
+    ok, payload = q.get(timeout=180)
     p.join(timeout=60)
     assert ok, payload
     for dt, (plain, dp) in payload.items():

@@ -86,6 +86,13 @@ def test_engine_dry_run_sequences_and_bucket_schedule(model, linbn):
 
         eng.backward = spy_backward
         try:
+            # first step of a configuration: the schedule is VERIFIED (ranges recorded, one AdamW launch at the end, a bad
+            # schedule raises before any update); from the second step on AdamW runs bucket by bucket
+            tr.step(x[:2], x[2:])
+            first = Counter(fake.calls)
+            assert first["sm3_adamw"] == 1 and len(ranges) > 4 and tr._sched_ok is not None
+            del fake.calls[:]
+            del ranges[:]
             tr.step(x[:2], x[2:])
         finally:
             del eng.backward  # the engine is cached on the (module-scoped) model
@@ -132,6 +139,33 @@ def test_engine_dry_run_sequences_and_bucket_schedule(model, linbn):
             covered[names[i]] += 1
     assert set(covered) == set(names)
     assert all(v == 1 for v in covered.values()), [k for k, v in covered.items() if v != 1][:5]
+
+
+def test_a_bucket_schedule_with_a_hole_raises_before_any_update(model):
+    """a gradient-ready schedule that does not cover every parameter must fail on the verification step, i.e.
+    BEFORE a single AdamW launch has modified the weights (it used to be detected after the bucket-wise updates)."""
+    from sm3hip.trainer import SM3Trainer
+    with installed() as fake:
+        model.sm3_dtype = torch.bfloat16
+        tr = SM3Trainer(model, lr=1e-3, data_parallel=False)
+        eng = tr._engine()
+        x = [torch.randn(2, 3, 32, 32) for _ in range(4)]
+        orig = eng._notify
+        dropped = []
+
+        def lossy(first, last):
+            if not dropped and "layer3" in first:
+                dropped.append((first, last))  # one stage's notification goes missing
+                return
+            orig(first, last)
+
+        eng._notify = lossy
+        try:
+            with pytest.raises(RuntimeError, match="do not tile"):
+                tr.step(x[:2], x[2:])
+        finally:
+            del eng._notify
+        assert dropped and Counter(fake.calls)["sm3_adamw"] == 0 and tr.step_count == 0
 
 
 def test_ops_reject_bad_shapes_on_host():

@@ -54,21 +54,40 @@ def _exchange_main(rank, world, port, q):
                 bad += int(not torch.equal(t, ref))
         # a peer that never shows up: the kernel gives up after its timeout instead of spinning forever
         late = P2PStatSync(["x"], dev, timeout_s=0.5)
+        after = {"nan": True, "ms": 0.0, "poll": True}
         if rank == 0:
             t = torch.ones(64, dtype=torch.float64, device=dev)
             late("x", t)
             torch.cuda.synchronize()
-            timed_out = False
+            timed_out = bool(torch.isnan(t).all())  # the failed exchange poisons its sums
             try:
                 late.check()
+                timed_out = False
             except RuntimeError:
-                timed_out = True
+                pass
+            # once failed, always failed and never waiting again: 100 more exchanges of the largest size return NaN at once
+            import time
+            ts = [torch.ones(late.max_elems, dtype=torch.float64, device=dev) for _ in range(100)]
+            t0 = time.perf_counter()
+            for u in ts:
+                late("x", u)
+            torch.cuda.synchronize()
+            after["ms"] = (time.perf_counter() - t0) * 1e3
+            after["nan"] = all(bool(torch.isnan(u).all()) for u in ts)
+            try:  # the non-blocking form a trainer uses: the second call sees what the first one copied back
+                late.poll()
+                torch.cuda.synchronize()
+                late.poll()
+                after["poll"] = False
+            except RuntimeError:
+                pass
         else:
             timed_out = True
         dist.barrier()
+        late.close()
         sync.close()
         dist.destroy_process_group()
-        q.put((rank, True, {"bad": bad, "timed_out": timed_out}))
+        q.put((rank, True, {"bad": bad, "timed_out": timed_out, "after": after, "kind": sync.memory_kind}))
     except Exception:
         q.put((rank, False, traceback.format_exc()))
 
@@ -82,7 +101,7 @@ def _spawn(fn, world=2, extra=()):
         p.start()
     res = {}
     for _ in range(world):
-        r, ok, payload = q.get(timeout=600)
+        r, ok, payload = q.get(timeout=180)
         assert ok, f"rank {r} failed:\n{payload}"
         res[r] = payload
     for p in procs:
@@ -96,6 +115,63 @@ def test_two_processes_exchange_sums_through_ipc_mailboxes():
     res = _spawn(_exchange_main)
     for r in (0, 1):
         assert res[r]["bad"] == 0 and res[r]["timed_out"], res[r]
+        assert res[r]["kind"] in ("finegrained", "coarse"), res[r]
+    print("mailbox memory:", res[0]["kind"], "| 100 exchanges after a timeout:", round(res[0]["after"]["ms"], 2), "ms")
+    assert res[0]["after"]["nan"] and res[0]["after"]["poll"], res[0]
+    assert res[0]["after"]["ms"] < 10.0, res[0]  # (one wait of the 0.5 s timeout alone would be 500 ms)
+
+
+def _missing_peer_main(rank, world, port, q):
+    try:
+        os.environ["SM3_SYNCBN_P2P"] = "1"
+        os.environ["SM3_P2P_TIMEOUT_S"] = "0.5"
+        _setup(rank, world, port)
+        from oracle import procedural
+        from sm3hip.trainer import SM3Trainer
+        from src.models.simclr import SimCLRSkinV32
+        dev = torch.device("cuda:0")
+        state = procedural.make_state_dict(seed=21)
+        derm_np, clinic_np = procedural.make_pair_batch(16, 64, 21)
+        model = SimCLRSkinV32("resnet50", None, 128, 0.1)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+        model.sm3_dtype = torch.bfloat16
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model).to(dev)
+        tr = SM3Trainer(model, lr=1e-3)
+        tr._engine()  # both ranks map each other's mailboxes ...
+        tr._bucket_ready = lambda *a: None  # (no gradient all-reduce: this is about the statistics exchange, and rank 1 is absent)
+        out = {"nan": True, "check": True, "step": True, "s": 0.0}
+        if rank == 0:  # ... but only rank 0 steps: its peer never raises a flag
+            import time
+            batch = ([torch.from_numpy(a).to(dev) for a in derm_np], [torch.from_numpy(a).to(dev) for a in clinic_np])
+            t0 = time.perf_counter()
+            loss = float(tr.step(*batch))
+            out["s"] = time.perf_counter() - t0
+            out["nan"] = loss != loss
+            try:
+                tr.check()
+                out["check"] = False
+            except RuntimeError:
+                pass
+            try:
+                tr.step(*batch)
+                out["step"] = False
+            except RuntimeError:
+                pass
+        dist.barrier()
+        tr.close(barrier=False)
+        dist.destroy_process_group()
+        q.put((rank, True, out))
+    except Exception:
+        q.put((rank, False, traceback.format_exc()))
+
+
+def test_trainer_step_with_a_missing_peer_fails_loudly():
+    """SM3_SYNCBN_P2P=1, rank 1 never steps: rank 0's first exchange runs into its timeout ONCE (0.5 s here), every later one
+    returns at once, the step's loss is NaN, SM3Trainer.check() raises and so does the next step() -- training cannot carry
+    on with un-reduced statistics."""
+    res = _spawn(_missing_peer_main)
+    assert res[0]["nan"] and res[0]["check"] and res[0]["step"], res[0]
+    assert res[0]["s"] < 15.0, res[0]  # 220 exchanges x 0.5 s would be 110 s
 
 
 def _step_main(rank, world, port, q, p2p):

@@ -1,0 +1,209 @@
+"""Round 4: BASELINE.json configs[3] -- tools/mlc_train.py at its own per-GPU size (batch 512 over 8 ranks = 64
+per GPU, 224 x 224, run.sh:39-47 settings) -- exercised on the one-GPU test box: the step of mlc_train.py:236-262 against an
+fp64 restatement of the heads on the same extractor features, and the same tool with TWO ranks through cluster_memory's
+gather -> rank-0 k-means -> broadcast (mlc_train.py:116-189)."""
+import importlib.util
+import math
+import os
+import socket
+import sys
+import traceback
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda:0"
+RUN_SH = ["--mlc-proj", "v4", "--mlc-proj-dim", "512", "--num-heads", "1", "--sa-dim-ff", "128", "--sa-dropout", "0.1",
+          "--temperature", "1", "-lr", "1e-4", "--num-labels", "8", "--extractor-proj-dim", "128"]  # run.sh:39-47
+
+
+def _tool():
+    spec = importlib.util.spec_from_file_location("sm3_mlc_train", os.path.join(ROOT, "skin-sm3_amd", "tools", "mlc_train.py"))
+    mt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mt)
+    return mt
+
+
+def _heads_fp64(P, feats, nhead=1):
+    """mlc_train.py:75-90 on given extractor features, fp64: 8 Linear label projectors -> one TransformerEncoderLayer over the
+    8 tokens (dropout inactive) -> 8 bias-free prototype heads."""
+    from oracle import sm3_oracle as O
+    tokens = torch.stack([F.linear(feats, P[f"projectors.projectors.{i}.0.weight"], P[f"projectors.projectors.{i}.0.bias"])
+                          for i in range(8)], dim=0)
+    sa = O.transformer_encoder_layer(tokens, P, "mlc_sa.", nhead)
+    return sa, [F.linear(sa[i % sa.shape[0]], P[f"prototypes.{i}.weight"]) for i in range(8)]
+
+
+def test_config4_mlc_train_step_b64_224_bf16_at_size():
+    """One rank's share of config 4: 64 pairs of 224 x 224 through the frozen bf16 encoders (eval mode, fused conv + BN
+    epilogues) and the training heads.  (a) with the attention layer's dropout inactive the head outputs, the loss and every
+    head gradient equal fp64 autograd of the restated heads on the SAME extractor features; (b) the step as run.sh runs it
+    (dropout 0.1 active, AdamW lr 1e-4): finite loss, every head tensor moves, the extractor does not."""
+    mt = _tool()
+    from src.models.projector import MultiLabelProjector4
+    from src.models.simclr import SimCLRSkinV32
+    torch.manual_seed(3407)
+    B, S = 64, 224
+    margs = mt.get_parser().parse_args(["-b", str(B)] + RUN_SH)
+    ex = SimCLRSkinV32(arch="resnet50", proj_dim=128)
+    ex.derm_backbone.projector = ex.clinic_backbone.projector = ex.cross_proj = None   # mlc_train.py:344-346
+    ex.sm3_dtype = torch.bfloat16
+    for p in ex.parameters():
+        p.requires_grad = False
+    m = mt.Model(ex, MultiLabelProjector4(4096, margs.mlc_proj_dim, 8), margs.mlc_proj_dim, False, margs.num_heads,
+                 margs.sa_dim_ff, margs.sa_dropout).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(7)
+    derm, clinic = mt.synthetic_split(B, (S, S), torch.device(DEV), 11)
+    assign = [torch.randint(0, n, (B,), device=DEV, generator=g) for n in mt.NUM_CLASSES]
+    crit = torch.nn.CrossEntropyLoss(ignore_index=-100)
+    before = {k: v.clone() for k, v in m.extractor.state_dict().items()}
+
+    # (a) parity, dropout inactive
+    m.eval()
+    with torch.no_grad():
+        feats = torch.cat(m.extractor.extract(derm, clinic), dim=1)
+    assert feats.shape == (B, 4096) and feats.dtype == torch.float32 and bool(torch.isfinite(feats).all())
+    sa, preds = m(derm, clinic)
+    loss = sum(crit(p / margs.temperature, a) for p, a in zip(preds, assign)) / 8
+    loss.backward()
+    torch.cuda.synchronize()
+    P = {k: v.detach().cpu().double().requires_grad_(True) for k, v in m.state_dict().items()
+         if k.startswith(("projectors.", "mlc_sa.", "prototypes.")) and v.is_floating_point()}
+    sa_ref, preds_ref = _heads_fp64(P, feats.cpu().double())
+    loss_ref = sum(F.cross_entropy(p / margs.temperature, a.cpu()) for p, a in zip(preds_ref, assign)) / 8
+    loss_ref.backward()
+    assert abs(float(loss) - float(loss_ref)) < 1e-5 * max(1.0, abs(float(loss_ref))), (float(loss), float(loss_ref))
+    assert float((sa.detach().cpu().double() - sa_ref.detach()).abs().max()) < 1e-4 * max(1.0, float(sa_ref.abs().max()))
+    for p, pr in zip(preds, preds_ref):
+        assert float((p.detach().cpu().double() - pr.detach()).abs().max()) < 1e-4 * max(1.0, float(pr.abs().max()))
+    worst = 0.0
+    for k, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        gref = P[k].grad
+        err = float((p.grad.cpu().double() - gref).norm() / (gref.norm() + 1e-12))
+        worst = max(worst, err)
+        assert err < 2e-4, (k, err)
+    print(f"config 4 at size: loss {float(loss):.6f} (fp64 {float(loss_ref):.6f}), worst head-gradient rel. error {worst:.2e}")
+
+    # (b) the step as the tool runs it (mlc_train.py:230-262)
+    m.extractor.eval(); m.projectors.train(); m.mlc_sa.train(); m.prototypes.train()
+    heads0 = {k: p.detach().clone() for k, p in m.named_parameters() if p.requires_grad}
+    opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=margs.base_lr, weight_decay=margs.wd)
+    _, preds = m(derm, clinic)
+    loss = sum(crit(p / margs.temperature, a) for p, a in zip(preds, assign)) / 8
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    opt.step()
+    torch.cuda.synchronize()
+    assert math.isfinite(float(loss)) and 0.0 < float(loss) < 20.0
+    assert all(not torch.equal(p.detach(), heads0[k]) for k, p in m.named_parameters() if p.requires_grad)
+    after = m.extractor.state_dict()
+    assert all(torch.equal(before[k], after[k]) for k in before), "the frozen extractor (parameters AND BatchNorm buffers) moved"
+
+
+def _rank_main(rank, world, port, q, log_path):
+    try:
+        os.environ["SM3_DIST_BACKEND"] = "gloo"   # two ranks on ONE GPU: RCCL refuses a device twice
+        os.environ["SM3_FORCE_DEVICE"] = "0"
+        for p in (ROOT, os.path.join(ROOT, "skin-sm3_amd"), os.path.join(ROOT, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        torch.set_num_threads(4)
+        mt = _tool()
+        args = mt.get_parser().parse_args(["--data-name", "synthetic", "--epochs", "1", "-b", "128", "--num-samples", "128",
+                                           "--img-sz", "224", "224", "--amp", "--log-path", log_path, "--save-freq", "1"]
+                                          + RUN_SH)
+        args.world_size, args.port, args.probe = world, port, {}
+        from src.models.simclr import SimCLRSkinV32
+        torch.manual_seed(args.seed)
+        fresh = SimCLRSkinV32(arch=args.arch, proj_dim=args.extractor_proj_dim)   # what main() builds first, same seed
+        ref_sd = {k: v.clone() for k, v in fresh.state_dict().items() if "projector" not in k and "cross_proj" not in k}
+        hist = mt.main(rank, args)
+        model = args.probe["model"]
+        ext = model.extractor.state_dict()
+        frozen_ok = all(torch.equal(ext[k].cpu(), v) for k, v in ref_sd.items() if k in ext)
+        heads = torch.cat([p.detach().float().reshape(-1).cpu() for k, p in model.named_parameters() if p.requires_grad])
+        q.put((rank, True, {"hist": hist, "assign": [a.tolist() for a in args.probe["assignments"]],
+                            "protos": [float(p.double().sum()) for p in args.probe["prototypes"]],
+                            "heads": [float(heads.double().sum()), float(heads.double().abs().sum())],
+                            "frozen_ok": frozen_ok, "n_ext": len(ref_sd)}))
+    except Exception:
+        q.put((rank, False, traceback.format_exc()))
+
+
+def test_config4_two_ranks_cluster_and_step_on_one_gpu(tmp_path):
+    """tools/mlc_train.py with world size 2 at 64 pairs of 224 x 224 per rank (bf16 encoders), both ranks on the test box's one
+    GPU over gloo, real kernels: each rank's memory bank is gathered on rank 0, clustered there (spherical k-means on
+    csrc/heads_train.hip) and broadcast -- both ranks must end with IDENTICAL pseudo-labels for all 128 samples and identical
+    prototypes; the DistributedDataParallel step then leaves identical heads on both ranks, a finite loss, and the frozen
+    extractor exactly as it was built."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, ok, payload = q.get(timeout=180)
+        assert ok, f"rank {r} failed:\n{payload}"
+        res[r] = payload
+    for p in procs:
+        p.join(timeout=60)
+    a, b = res[0], res[1]
+    assert a["assign"] == b["assign"], "pseudo-labels differ between the ranks"
+    for lab, n in zip(a["assign"], [5, 3, 2, 3, 3, 3, 3, 2]):
+        assert len(lab) == 128 and all(0 <= v < n for v in lab), "a sample was left without a pseudo-label (-100)"
+    assert a["protos"] == b["protos"]
+    assert a["heads"] == b["heads"], (a["heads"], b["heads"])     # replicas in sync after the averaged step
+    for r in (a, b):
+        assert len(r["hist"]) == 1 and math.isfinite(r["hist"][0]) and 0.0 < r["hist"][0] < 20.0, r["hist"]
+        assert r["frozen_ok"] and r["n_ext"] > 600
+    assert os.path.exists(os.path.join(str(tmp_path), "ckp_0.pth"))
+
+
+@pytest.mark.parametrize("dtname", ["bf16", "f16"])
+def test_linear_and_two_pass_batchnorm_forms_agree_at_b16(dtname):
+    """the BatchNorm-by-linearity forms (csrc/linbn.hip, the 16-bit default) against the two-pass form of the SAME
+    engine at B = 16 pairs of 224 x 224, where 4-image BatchNorms no longer dominate: loss, gradient norm and gradient
+    direction of a whole step, each form also measured against the exact-f32 mode -- the linear form must be no further
+    from f32 than the two-pass form is (+ margin), and the two forms must agree with each other at least as well as either
+    agrees with f32."""
+    from sm3hip.trainer import SM3Trainer
+    from test_config_gpu import _build, _latent_batch
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16}[dtname]
+    derm, clinic = _latent_batch(16, 224, 21)
+
+    def grad(dtype, linbn):
+        model = _build(21, dtype)
+        tr = SM3Trainer(model, lr=0.0, init_scale=1024.0)
+        eng = tr._engine()
+        if linbn is not None:
+            eng.linbn = linbn
+        loss = float(tr.step(derm, clinic))
+        torch.cuda.synchronize()
+        g = eng.store.flat_g.double().cpu()
+        if dtype == torch.float16:
+            assert tr.steps_taken() == 1
+            g = g / 1024.0
+        del tr, model, eng
+        torch.cuda.empty_cache()
+        return loss, g
+
+    cos = lambda a, b: float(torch.dot(a, b) / (a.norm() * b.norm()))
+    l32, g32 = grad(torch.float32, None)
+    lon, gon = grad(dt, True)
+    loff, goff = grad(dt, False)
+    c_on, c_off, c_between = cos(gon, g32), cos(goff, g32), cos(gon, goff)
+    n32, non, noff = float(g32.norm()), float(gon.norm()), float(goff.norm())
+    print(f"{dtname} B=16 224: loss f32 {l32:.4f} linear {lon:.4f} two-pass {loff:.4f}; cosine vs f32 linear {c_on:.3f} two-pass "
+          f"{c_off:.3f}, between the forms {c_between:.3f}; |g| f32 {n32:.4f} linear {non:.4f} two-pass {noff:.4f}")
+    assert abs(lon - loff) < (0.05 if dtname == "f16" else 0.25)
+    assert abs(non - noff) < 0.05 * noff and abs(non - n32) < 0.10 * n32
+    assert c_on > c_off - 0.05 and c_on >= 0.65
+    assert c_between >= min(c_on, c_off) - 0.1
