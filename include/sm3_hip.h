@@ -193,6 +193,16 @@ int sm3_bn_finalize(const double* sums, int groups /* sums is [views][groups][2C
                     float eps, float momentum, float* running_mean, float* running_var,
                     int64_t* num_batches_tracked /* += views */, float* scale, float* shift, float* save_mean,
                     float* save_invstd /* all four [views][C]; running statistics updated view by view */, void* stream);
+/* sm3_bn_stats_reduce (stage A) + sm3_bn_finalize in ONE launch, for a single rank (no exchange between the two): replaces
+ * the same nn.BatchNorm2d / BatchNorm1d train-mode statistics (src/models/resnet.py:145-149, src/models/simclr.py:20-26) with one
+ * dependent launch fewer per BatchNorm.  The block that draws the last arrival ticket of a 32-channel block finalizes it: same
+ * association, same bits as the two-launch form.  workspace: views * SM3_BN_REDUCE_GROUPS * 2C doubles; tickets: (C + 31) / 32
+ * uint32, ZERO before the first use and left zero by every launch; both private to the stream (launches on one stream reuse them
+ * in order). */
+int sm3_bn_stats_finalize(const float* partials, int rows, int C, int views, double* workspace, uint32_t* tickets, double count,
+                          const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                          float* running_var, int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean,
+                          float* save_invstd, void* stream);
 /* eval mode: scale/shift from the running statistics */
 int sm3_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean,
                             const float* running_var, float eps, int C, float* scale, float* shift,

@@ -106,19 +106,27 @@ __global__ void bn_stats_reduce_b(const double* __restrict__ ws, int G, int C, d
 // pure latency (a chain of dependent L2 loads per sum) and sits on the critical path of every BatchNorm.  views > 2
 // loop over pairs.  Running statistics are still updated view 0 first, then view 1, by one lane, as in the reference's
 // sequential encoder(x1); encoder(x2).
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, int groups, int views, double count, int C,
-                                   const float* gamma, const float* beta, float eps, float momentum,
-                                   float* running_mean, float* running_var, int64_t* nbt, float* scale, float* shift,
-                                   float* save_mean, float* save_invstd) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int q = t & 3, stat = (t >> 2) & 1, vl = (t >> 3) & 1, c = t >> 4;
-    if (t == 0 && nbt) nbt[0] += views;
+// One channel's finalize, run by a 16-lane group: lane = (view-of-pair vl, statistic, quad lane q).  ws: [views][groups][2C]
+// fp64 partial sums (groups == 1: the sums themselves).  Shared by bn_finalize_kernel and bn_stats_finalize_kernel: the two
+// produce the same bits.  `lane16` = lane index inside the group, c < C or the group idles (it still takes part in shuffles).
+struct BnFinalizeArgs {
+    double count;
+    int C;
+    const float *gamma, *beta;
+    float eps, momentum;
+    float *running_mean, *running_var;
+    float *scale, *shift, *save_mean, *save_invstd;
+};
+__device__ __forceinline__ void bn_finalize_channel(const double* __restrict__ sums, int groups, int views, int c, int lane16,
+                                                    const BnFinalizeArgs& a) {
+    const int C = a.C;
+    const int q = lane16 & 3, stat = (lane16 >> 2) & 1, vl = (lane16 >> 3) & 1;
     const int cc = c < C ? c : 0;
     float rm = 0.f, rv = 0.f;
-    const bool owner = (c < C) && ((t & 15) == 0);
+    const bool owner = (c < C) && (lane16 == 0);
     if (owner) {
-        rm = running_mean ? running_mean[c] : 0.f;
-        rv = running_var ? running_var[c] : 0.f;
+        rm = a.running_mean ? a.running_mean[c] : 0.f;
+        rv = a.running_var ? a.running_var[c] : 0.f;
     }
     for (int v0 = 0; v0 < views; v0 += 2) {
         const int v = v0 + vl;
@@ -134,24 +142,96 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int groups, 
         for (int k = 0; k < 2 && v0 + k < views; ++k) {
             const double s1 = k ? s1_v1 : mine, s2 = k ? s2_v1 : s2_same_view;
             const int vv = v0 + k;
-            const double mean = s1 / count;
-            double var = s2 / count - mean * mean;
+            const double mean = s1 / a.count;
+            double var = s2 / a.count - mean * mean;
             if (var < 0) var = 0;
-            const double invstd = 1.0 / sqrt(var + (double)eps);
-            const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-            scale[(long)vv * C + c] = (float)(g * invstd);
-            shift[(long)vv * C + c] = (float)((double)b - mean * (double)g * invstd);
-            if (save_mean) save_mean[(long)vv * C + c] = (float)mean;
-            if (save_invstd) save_invstd[(long)vv * C + c] = (float)invstd;
-            rm = (1.f - momentum) * rm + momentum * (float)mean;
-            const double unbiased = var * (count / fmax(count - 1.0, 1.0));
-            rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+            const double invstd = 1.0 / sqrt(var + (double)a.eps);
+            const float g = a.gamma ? a.gamma[c] : 1.f, b = a.beta ? a.beta[c] : 0.f;
+            a.scale[(long)vv * C + c] = (float)(g * invstd);
+            a.shift[(long)vv * C + c] = (float)((double)b - mean * (double)g * invstd);
+            if (a.save_mean) a.save_mean[(long)vv * C + c] = (float)mean;
+            if (a.save_invstd) a.save_invstd[(long)vv * C + c] = (float)invstd;
+            rm = (1.f - a.momentum) * rm + a.momentum * (float)mean;
+            const double unbiased = var * (a.count / fmax(a.count - 1.0, 1.0));
+            rv = (1.f - a.momentum) * rv + a.momentum * (float)unbiased;
         }
     }
     if (owner) {
-        if (running_mean) running_mean[c] = rm;
-        if (running_var) running_var[c] = rv;
+        if (a.running_mean) a.running_mean[c] = rm;
+        if (a.running_var) a.running_var[c] = rv;
     }
+}
+
+// 16 lanes per channel: lane = (view v in {0,1}) x (statistic in {sum, sum of squares}) x (quad lane q); the four
+// group sums of a channel (2 views x 2 statistics) run side by side instead of one after the other -- this kernel is
+// pure latency (a chain of dependent L2 loads per sum) and sits on the critical path of every BatchNorm.  views > 2
+// loop over pairs.  Running statistics are still updated view 0 first, then view 1, by one lane, as in the reference's
+// sequential encoder(x1); encoder(x2).
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int groups, int views, int64_t* nbt, BnFinalizeArgs a) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 && nbt) nbt[0] += views;
+    bn_finalize_channel(sums, groups, views, t >> 4, t & 15, a);
+}
+
+// Statistics reduction AND finalize of one BatchNorm in ONE launch (single rank; VERDICT r3 item 5: the two dependent
+// 8 us launches per BatchNorm were 2.7 ms of a step).  Grid (ceil(C / 32), G, views): a block owns 32 channels x both
+// statistics of G-th row group of one view -- stage A exactly as bn_stats_reduce_a (same row walk, same association), one
+// fp64 row of the [views][G][2C] workspace per block.  Then an arrival ticket per channel block: the block that draws the
+// last ticket finalizes those 32 channels for every view with bn_finalize_channel -- the same bits as the two-launch form.
+// Hand-off (MI355X_MICROARCH.md, Valid forms): plain stores -> the storing wave's s_waitcnt vmcnt(0) -> workgroup barrier ->
+// lane 0: agent-scope release fence, s_waitcnt vmcnt(0), relaxed agent-scope ticket add; last arriver: agent-scope acquire
+// fence, s_waitcnt vmcnt(0), workgroup barrier, plain loads.  The last arriver zeroes the ticket word for the next launch
+// (tickets live in a zero-initialised per-stream buffer).
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partials, int rows, int views,
+                                                                double* __restrict__ ws_all, unsigned* __restrict__ tickets,
+                                                                int64_t* nbt, BnFinalizeArgs a) {
+    __shared__ double red[4][64];
+    __shared__ int s_last;
+    const int C = a.C, G = gridDim.y, v = blockIdx.z;
+    const float* part = partials + (long)v * rows * 2 * C;
+    double* ws = ws_all + ((long)v * G + blockIdx.y) * 2 * C;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int ch = blockIdx.x * 32 + (tx & 31);
+    const int col = (tx >> 5) * C + ch;  // stat-major within a partial row
+    double acc = 0.0;
+    if (ch < C) {
+        double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        const int step = G * 4;
+        int r = blockIdx.y * 4 + ty;
+        for (; r + 3 * step < rows; r += 4 * step) {
+            acc += (double)part[(long)r * 2 * C + col];
+            a1 += (double)part[(long)(r + step) * 2 * C + col];
+            a2 += (double)part[(long)(r + 2 * step) * 2 * C + col];
+            a3 += (double)part[(long)(r + 3 * step) * 2 * C + col];
+        }
+        for (; r < rows; r += step) acc += (double)part[(long)r * 2 * C + col];
+        acc = (acc + a1) + (a2 + a3);
+    }
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && ch < C) ws[col] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the storing wave's stores are acknowledged ...
+    __syncthreads();                                   // ... before lane 0 publishes them
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned total = (unsigned)(G * views);
+        const unsigned t = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == total - 1);
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+            if (blockIdx.x == 0 && nbt) nbt[0] += views;
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // 32 channels x 16 lanes = 512 lane slots: two rounds of the 256 threads
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+        bn_finalize_channel(ws_all, G, views, blockIdx.x * 32 + half * 16 + (threadIdx.x >> 4), threadIdx.x & 15, a);
 }
 
 __global__ void bn_eval_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
@@ -664,9 +744,23 @@ extern "C" int sm3_bn_finalize(const double* sums, int groups, int views, double
                                int64_t* num_batches_tracked, float* scale, float* shift, float* save_mean,
                                float* save_invstd, void* stream) {
     if (!sums || !scale || !shift || C <= 0 || count <= 0 || groups < 1 || views < 1) return SM3_EINVAL;
+    const BnFinalizeArgs a{count, C, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd};
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((16 * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, groups, views,
-                       count, C, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift,
-                       save_mean, save_invstd);
+                       num_batches_tracked, a);
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_bn_stats_finalize(const float* partials, int rows, int C, int views, double* workspace, uint32_t* tickets,
+                                     double count, const float* gamma, const float* beta, float eps, float momentum,
+                                     float* running_mean, float* running_var, int64_t* num_batches_tracked, float* scale,
+                                     float* shift, float* save_mean, float* save_invstd, void* stream) {
+    if (!partials || !workspace || !tickets || !scale || !shift || rows <= 0 || C <= 0 || count <= 0 || views < 1)
+        return SM3_EINVAL;
+    const int G = sm3_bn_reduce_groups(rows);
+    const BnFinalizeArgs a{count, C, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd};
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 31) / 32, G, views), dim3(256), 0, (hipStream_t)stream, partials, rows,
+                       views, workspace, tickets, num_batches_tracked, a);
     SM3_CHECK_LAUNCH();
     return 0;
 }

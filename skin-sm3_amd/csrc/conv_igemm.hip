@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "conv_common.h"
 
@@ -71,8 +72,21 @@ struct StampRec {
 // tap bookkeeping and every LDS-DMA piece of the K loop and leave after it; the WM*WN CONSUMER waves (the only ones that
 // hold accumulators) issue nothing but ds_read_b128 + MFMA in the loop and run the epilogue alone.  Same stage ring,
 // same one barrier per K-step, same arithmetic in the same order: outputs are bit-identical to the unsplit kernel.
-template <typename T, int BM, int BN, int WM, int WN, int STAGES, int EPI, bool SEG = false, bool SPLIT = false>
-__global__ __launch_bounds__(WM* WN * 64 * (SPLIT ? 2 : 1), ((EPI == 3 || SPLIT) ? 4 : 2)) void conv_igemm_kernel(const ConvParams p) {  // EPI 3: 130 -> 128 registers, 4 workgroups per CU
+// VAR (bit mask of variants that change instructions, never results):
+//   kVarSplit  the loader / consumer split above;
+//   kVarPw     POINTWISE launches (one tap at (0, 0) -- or two K segments over the same pixels --, stride 1, dense output, no
+//              compact addend): a tile row IS pixel m0 + r, so the loader state and the epilogue's row addresses are one
+//              multiply-add per row instead of the general gather's divisions and bounds tests.  These launches are the
+//              HBM-bound half of the step and were VALU-issue-bound: ~1 170 vector instructions per thread and tile, 217 of
+//              them set-up and ~280 row addressing (profiles/r04a_smemtime_phases_1x1.txt);
+//   kVarNoX    EPI 3 without the producer's x (the linear BatchNorm forms: ReLU mask + sum(dz) only): no x operand stream,
+//              no sum(dz * xhat) arithmetic, and with the registers that frees ALL rows' operands are requested before the
+//              staging instead of half of them after it.
+constexpr int kVarSplit = 1, kVarPw = 2, kVarNoX = 4;
+template <typename T, int BM, int BN, int WM, int WN, int STAGES, int EPI, bool SEG = false, int VAR = 0>
+__global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((EPI >= 2 || (VAR & kVarSplit)) ? 4 : 2)) void conv_igemm_kernel(const ConvParams p) {  // EPI 3: 130 -> 128 registers, 4 workgroups per CU
+    constexpr bool SPLIT = (VAR & kVarSplit) != 0, PW = (VAR & kVarPw) != 0, NOX = (VAR & kVarNoX) != 0;
+    static_assert(!NOX || EPI == 3, "kVarNoX: the fused BN-backward epilogue");
 #ifdef SM3_STAMP
     StampRec stamp;
 #endif
@@ -133,6 +147,11 @@ __global__ __launch_bounds__(WM* WN * 64 * (SPLIT ? 2 : 1), ((EPI == 3 || SPLIT)
         const int r = (tid >> 3) + i * RPP;
         a_ch[i] = (uint32_t)((pos ^ (r >> 1)) & 7) * 16u;  // source chunk of this lane (swizzle on the source side)
         const int m = m0 + r;
+        if constexpr (PW) {  // the row is pixel m of the source
+            a_iy0[i] = a_ix0[i] = 0;
+            a_pix[i] = m < p.M ? m : -1;
+            continue;
+        }
         if (m < p.M) {
             const int n = fdiv(m, p.div_HoWo);
             const int rem = m - n * p.HoWo;
@@ -165,10 +184,15 @@ __global__ __launch_bounds__(WM* WN * 64 * (SPLIT ? 2 : 1), ((EPI == 3 || SPLIT)
     int cur_src = 0;  // segment of the tap being staged (wave-uniform)
 
     auto set_tap = [&](int t) {
-        const int ddy = p.dy[t], ddx = p.dx[t];
-        const int dpix = ddy * p.Wi + ddx;
         if constexpr (SEG) cur_src = __builtin_amdgcn_readfirstlane((int)p.tap_src[t]);
         const uint32_t rb = (SEG && cur_src) ? row_bytes1 : row_bytes;
+        if constexpr (PW) {
+#pragma unroll
+            for (int i = 0; i < AI; ++i) a_off[i] = a_pix[i] >= 0 ? (uint32_t)a_pix[i] * rb + a_ch[i] : kOOB;
+            return;
+        }
+        const int ddy = p.dy[t], ddx = p.dx[t];
+        const int dpix = ddy * p.Wi + ddx;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             const int iy = a_iy0[i] + ddy, ix = a_ix0[i] + ddx;
@@ -383,23 +407,38 @@ __global__ __launch_bounds__(WM* WN * 64 * (SPLIT ? 2 : 1), ((EPI == 3 || SPLIT)
         const int cc = tid % CPR, r0 = tid / CPR;
         const int ncol = n0 + cc * 8;
         const bool fz = EPI == 3 && p.fz_partials != nullptr;
-        const bool fzx = fz && p.fz_x != nullptr;
+        const bool fzx = !NOX && fz && p.fz_x != nullptr;
         // ---- EPI >= 2: what the read-back loop needs from global memory, requested NOW (all NPASS rows of this thread:
         // 16-32 KB per workgroup in flight while the accumulators are converted and staged)
         uint32_t eoff[EPI >= 2 ? NPASS : 1];           // byte offset of the thread's vector in row k of the output; ~0 = none
-        uint4 pre_add[EPI >= 2 ? NPASS : 1], pre_x[EPI == 3 ? NPASS : 1];
+        uint4 pre_add[EPI >= 2 ? NPASS : 1], pre_x[(EPI == 3 && !NOX) ? NPASS : 1];
         unsigned pre_mk[EPI == 3 ? NPASS : 1];
         // EPI 3 asks for the first half of its rows here and for the second half right after the barrier (while the first
         // half is being finished): two operand streams per row would otherwise hold 64 registers beside the accumulators
-        constexpr int NEARLY = EPI == 3 ? NPASS / 2 : NPASS;
-        const bool dense_out = (p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.HWout == p.HoWo);
+        constexpr int NEARLY = (EPI == 3 && !NOX) ? NPASS / 2 : NPASS;
+        const bool dense_out = PW || (p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.HWout == p.HoWo);
+        // pointwise: row k of this thread is output row m0 + r0 + k * RSTEP, RSTEP rows further down each time
+        const uint32_t pw_base = (uint32_t)(((long)(m0 + r0) * p.Co + ncol) * 2), pw_step = (uint32_t)RSTEP * (uint32_t)p.Co * 2u;
         auto request = [&](int k) {
             const int m = m0 + r0 + k * RSTEP;
             eoff[k] = ~0u;
             pre_add[k] = make_uint4(0, 0, 0, 0);
             if constexpr (EPI == 3) {
-                pre_x[k] = make_uint4(0, 0, 0, 0);
+                if constexpr (!NOX) pre_x[k] = make_uint4(0, 0, 0, 0);
                 pre_mk[k] = 0xffu;
+            }
+            if constexpr (PW) {
+                if (m < p.M && ncol < p.Co) {
+                    eoff[k] = pw_base + (uint32_t)k * pw_step;  // tensors stay below 3 GB (host check)
+                    if (p.addend) pre_add[k] = ldg16<true>(p.addend + eoff[k]);
+                    if constexpr (EPI == 3) {
+                        if constexpr (!NOX) {
+                            if (fzx) pre_x[k] = ldg16<true>(p.fz_x + eoff[k]);
+                        }
+                        if (fz && p.fz_mask) pre_mk[k] = p.fz_mask[eoff[k] >> 4];
+                    }
+                }
+                return;
             }
             if (m < p.M && ncol < p.Co) {
                 long opix = m;
@@ -421,7 +460,9 @@ __global__ __launch_bounds__(WM* WN * 64 * (SPLIT ? 2 : 1), ((EPI == 3 || SPLIT)
                     }
                 }
                 if constexpr (EPI == 3) {
-                    if (fzx) pre_x[k] = ldg16<true>(p.fz_x + eoff[k]);
+                    if constexpr (!NOX) {
+                        if (fzx) pre_x[k] = ldg16<true>(p.fz_x + eoff[k]);
+                    }
                     if (fz && p.fz_mask) pre_mk[k] = p.fz_mask[eoff[k] >> 4];
                 }
             }
@@ -431,54 +472,73 @@ __global__ __launch_bounds__(WM* WN * 64 * (SPLIT ? 2 : 1), ((EPI == 3 || SPLIT)
             for (int k = 0; k < NEARLY; ++k) request(k);
         }
         SM3_MARK(6);
+        // The staging loop in four compile-time flavours (statistics wanted or not, affine or not): the launch-level flags
+        // are tested once, not per accumulator pair -- EPI 2 / 3 launches almost never want the BatchNorm sums of their
+        // output and used to pay 2 v_dot2 per pair for them.
+        const bool epl = p.ep_scale != nullptr || p.ep_rv != nullptr;
+        const bool aff = epl || (SEG && p.col_bias);
+        const bool early_relu = epl && p.ep_relu && (EPI == 1 || !p.addend) && !p.ep_mask;
+        auto stage_tile = [&](auto stats_c, auto aff_c) {
+            constexpr bool STATS = decltype(stats_c)::value, AFF = decltype(aff_c)::value;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float s1 = 0.f, s2 = 0.f;
-            char* colp = sC + (wn * WTN + j * 32 + frow) * 2 + (wm * WTM + 4 * fh) * LEAN_PITCH;
-            // BatchNorm affine (+ReLU when nothing is added afterwards) of this lane's column, in the accumulator layout;
-            // per view in the train-mode fused form
-            const int gcol = n0 + wn * WTN + j * 32 + frow;
-            const bool epl = p.ep_scale != nullptr || p.ep_rv != nullptr;
-            float esc = 1.f, esh = 0.f;
-            if (epl && gcol < p.Co) {
-                if (p.ep_rv) {
-                    ep_affine(p, gcol, esc, esh);
-                } else {
-                    esc = p.ep_scale[tile_view * p.Co + gcol];
-                    esh = p.ep_shift[tile_view * p.Co + gcol];
-                }
-            }
-            if constexpr (SEG) {  // constant term of the linear BatchNorm backward (per output channel and view)
-                if (p.col_bias && gcol < p.Co) esh += p.col_bias[tile_view * p.Co + gcol];
-            }
-            const bool early_relu = epl && p.ep_relu && (EPI == 1 || !p.addend) && !p.ep_mask;
-            const float elo = early_relu ? 0.f : -INFINITY;
-            const bool aff = epl || (SEG && p.col_bias);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {  // registers 2q, 2q+1 = rows R, R+1 of this lane's column
-                    float v0 = acc[i][j][2 * q], v1 = acc[i][j][2 * q + 1];
-                    if (aff) {
-                        v0 = fmaxf(v0 * esc + esh, elo);
-                        v1 = fmaxf(v1 * esc + esh, elo);
+            for (int j = 0; j < TN; ++j) {
+                float s1 = 0.f, s2 = 0.f;
+                char* colp = sC + (wn * WTN + j * 32 + frow) * 2 + (wm * WTM + 4 * fh) * LEAN_PITCH;
+                // BatchNorm affine (+ReLU when nothing is added afterwards) of this lane's column, in the accumulator layout;
+                // per view in the train-mode fused form
+                float esc = 1.f, esh = 0.f, elo = -INFINITY;
+                if constexpr (AFF) {
+                    const int gcol = n0 + wn * WTN + j * 32 + frow;
+                    if (epl && gcol < p.Co) {
+                        if (p.ep_rv) {
+                            ep_affine(p, gcol, esc, esh);
+                        } else {
+                            esc = p.ep_scale[tile_view * p.Co + gcol];
+                            esh = p.ep_shift[tile_view * p.Co + gcol];
+                        }
                     }
-                    const uint32_t pk = pack2<T>(v0, v1);
-                    s1 = dot2acc<T>(pk, ones, s1);
-                    s2 = dot2acc<T>(pk, pk, s2);
-                    const int R = i * 32 + (q & 1) * 2 + 8 * (q >> 1);
-                    *reinterpret_cast<uint16_t*>(colp + R * LEAN_PITCH) = (uint16_t)pk;
-                    *reinterpret_cast<uint16_t*>(colp + (R + 1) * LEAN_PITCH) = (uint16_t)(pk >> 16);
+                    if constexpr (SEG) {  // constant term of the linear BatchNorm backward (per output channel and view)
+                        if (p.col_bias && gcol < p.Co) esh += p.col_bias[tile_view * p.Co + gcol];
+                    }
+                    elo = early_relu ? 0.f : -INFINITY;
                 }
-            if (p.partials) {
-                s1 += __shfl_xor(s1, 32, 64);
-                s2 += __shfl_xor(s2, 32, 64);
-                if (lane < 32) {
-                    const int col = wn * WTN + j * 32 + lane;
-                    sStat[(wm * BN + col) * 2 + 0] = s1;
-                    sStat[(wm * BN + col) * 2 + 1] = s2;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {  // registers 2q, 2q+1 = rows R, R+1 of this lane's column
+                        float v0 = acc[i][j][2 * q], v1 = acc[i][j][2 * q + 1];
+                        if constexpr (AFF) {
+                            v0 = fmaxf(v0 * esc + esh, elo);
+                            v1 = fmaxf(v1 * esc + esh, elo);
+                        }
+                        const uint32_t pk = pack2<T>(v0, v1);
+                        if constexpr (STATS) {
+                            s1 = dot2acc<T>(pk, ones, s1);
+                            s2 = dot2acc<T>(pk, pk, s2);
+                        }
+                        const int R = i * 32 + (q & 1) * 2 + 8 * (q >> 1);
+                        *reinterpret_cast<uint16_t*>(colp + R * LEAN_PITCH) = (uint16_t)pk;
+                        *reinterpret_cast<uint16_t*>(colp + (R + 1) * LEAN_PITCH) = (uint16_t)(pk >> 16);
+                    }
+                if constexpr (STATS) {
+                    s1 += __shfl_xor(s1, 32, 64);
+                    s2 += __shfl_xor(s2, 32, 64);
+                    if (lane < 32) {
+                        const int col = wn * WTN + j * 32 + lane;
+                        sStat[(wm * BN + col) * 2 + 0] = s1;
+                        sStat[(wm * BN + col) * 2 + 1] = s2;
+                    }
                 }
             }
+        };
+        using std::true_type;
+        using std::false_type;
+        if (p.partials) {
+            if (aff) stage_tile(true_type{}, true_type{});
+            else stage_tile(true_type{}, false_type{});
+        } else {
+            if (aff) stage_tile(false_type{}, true_type{});
+            else stage_tile(false_type{}, false_type{});
         }
         __syncthreads();
         SM3_MARK(3);
@@ -554,13 +614,19 @@ __global__ __launch_bounds__(WM* WN * 64 * (SPLIT ? 2 : 1), ((EPI == 3 || SPLIT)
                     packed = pack16<T>(v);
                     if constexpr (EPI == 3) {
                         if (fz) {  // sums of the STORED (rounded) dz, as the standalone kernel's
-                            float dzr[8], xv[8];
+                            float dzr[8];
                             unpack16<T>(packed, dzr);
-                            unpack16<T>(pre_x[k], xv);
+                            if constexpr (NOX) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                f_s1[e] += dzr[e];
-                                f_s2[e] += dzr[e] * (xv[e] - f_mu[e]) * f_is[e];  // f_mu = f_is = 0 without x: stays 0
+                                for (int e = 0; e < 8; ++e) f_s1[e] += dzr[e];
+                            } else {
+                                float xv[8];
+                                unpack16<T>(pre_x[k], xv);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) {
+                                    f_s1[e] += dzr[e];
+                                    f_s2[e] += dzr[e] * (xv[e] - f_mu[e]) * f_is[e];  // f_mu = f_is = 0 without x: stays 0
+                                }
                             }
                         }
                     }
@@ -804,8 +870,9 @@ __global__ __launch_bounds__(WM* WN * 64 * (SPLIT ? 2 : 1), ((EPI == 3 || SPLIT)
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int STAGES, int EPI, bool SEG = false, bool SPLIT = false>
+template <typename T, int BM, int BN, int WM, int WN, int STAGES, int EPI, bool SEG = false, int VAR = 0>
 int launch_conv_st(const ConvParams& p0, hipStream_t st) {
+    constexpr bool SPLIT = (VAR & kVarSplit) != 0;
     ConvParams p = p0;
     {
         const char* dv = getenv("SM3_CONV_DBG");
@@ -819,7 +886,7 @@ int launch_conv_st(const ConvParams& p0, hipStream_t st) {
     static_assert(MAIN >= 256 * 2 * 8 * 4, "reduction scratch of the fused BN-backward epilogue must fit");
     p.tilesM = (p.M + BM - 1) / BM;
     p.tilesN = (p.Co + BN - 1) / BN;
-    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, STAGES, EPI, SEG, SPLIT>;
+    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, STAGES, EPI, SEG, VAR>;
     // the dynamic-LDS limit is a per-device attribute of the function: set it once per (instantiation, device)
     static std::atomic<uint32_t> attr_set{0};  // bit d: done on device d
     int dev = 0;
@@ -840,7 +907,8 @@ int launch_conv_st(const ConvParams& p0, hipStream_t st) {
 // SM3_CONV_SPLIT (A/B switch, read at every launch): loader / consumer waves in the 2-stage K loop of
 //   bit 0: the plain forward launches (EPI 1) with >= 4 K-steps per tap on 128-column tiles -- where it measures faster
 //          (profiles/r04a_split_ab.txt: +3 ... +17 % at Ci >= 256, nothing at Ci = 128, -12 % on the 64-column tiles),
-//   bit 1 / 2 / 3: EPI 2 / EPI 3 / two-segment launches, bit 4: bit 0 without the shape rule.
+//   bit 4: bit 0 without the shape rule.  (EPI 2 / EPI 3 / two-segment launches measured 12 - 37 % SLOWER split -- their
+//   epilogues spill at the 128 registers of 16 waves per CU -- and are no longer built.)
 static int conv_split_mode() {
     const char* v = getenv("SM3_CONV_SPLIT");
     return v ? atoi(v) : 0;  // default off: inside a step it equals the 8-wave variant on the 3x3 forward launches (+-0.5 %)
@@ -848,18 +916,49 @@ static int conv_split_mode() {
 template <int EPI, int BN>
 static bool conv_split_wanted(const ConvParams& p) {
     const int m = conv_split_mode();
-    if (EPI == 1) return (m & 16) || ((m & 1) && BN == 128 && p.kchunks >= 4);
-    return EPI == 2 ? (m & 2) : EPI == 3 ? (m & 4) : false;
+    return EPI == 1 && ((m & 16) || ((m & 1) && BN == 128 && p.kchunks >= 4));
+}
+
+// SM3_CONV_PW (A/B switch, read at every launch; default 3): bit 0 = the pointwise variants (kVarPw) for the launches that
+// qualify, bit 1 = the no-x variant of the fused BN-backward epilogue (kVarNoX) where no x is given.
+static int conv_pw_mode() {
+    const char* v = getenv("SM3_CONV_PW");
+    return v ? atoi(v) : 3;
+}
+// a tile row is pixel m0 + r of the source AND of the output: one tap at (0, 0) (or two segments, which the host only builds
+// over the same pixels), stride 1, same geometry in and out, dense output, dense addend
+static bool conv_is_pointwise(const ConvParams& p) {
+    const bool dense = p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.HWout == p.HoWo;
+    const bool taps0 = (p.x1 != nullptr) || (p.ntaps == 1 && p.dy[0] == 0 && p.dx[0] == 0);
+    return dense && taps0 && p.sy == 1 && p.sx == 1 && p.Hi * p.Wi == p.HoWo && p.add_sp_h == 0;
+}
+
+// 16-bit lean epilogues on the 1- or 2-stage K loop
+template <typename T, int BM, int BN, int WM, int WN, int EPI, bool SEG>
+int launch_conv_lean(const ConvParams& p, hipStream_t st, bool single) {
+    const int mode = conv_pw_mode();
+    if ((mode & 1) && conv_is_pointwise(p)) {
+        if constexpr (EPI == 3 && !SEG) {
+            if ((mode & 2) && p.fz_partials && !p.fz_x)
+                return single ? launch_conv_st<T, BM, BN, WM, WN, 1, 3, false, kVarPw | kVarNoX>(p, st)
+                              : launch_conv_st<T, BM, BN, WM, WN, 2, 3, false, kVarPw | kVarNoX>(p, st);
+        }
+        return single ? launch_conv_st<T, BM, BN, WM, WN, 1, EPI, SEG, kVarPw>(p, st)
+                      : launch_conv_st<T, BM, BN, WM, WN, 2, EPI, SEG, kVarPw>(p, st);
+    }
+    return single ? launch_conv_st<T, BM, BN, WM, WN, 1, EPI, SEG>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, EPI, SEG>(p, st);
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int EPI>
 int launch_conv_epi(const ConvParams& p, hipStream_t st, bool single, bool deep) {
     if (deep) return launch_conv_st<T, BM, BN, WM, WN, 4, EPI>(p, st);
-    if (single) return launch_conv_st<T, BM, BN, WM, WN, 1, EPI>(p, st);
-    if constexpr (EPI >= 1) {
-        if (conv_split_wanted<EPI, BN>(p)) return launch_conv_st<T, BM, BN, WM, WN, 2, EPI, false, true>(p, st);
+    if constexpr (EPI >= 1 && sizeof(T) == 2) {
+        if constexpr (EPI == 1) {
+            if (!single && conv_split_wanted<EPI, BN>(p)) return launch_conv_st<T, BM, BN, WM, WN, 2, EPI, false, kVarSplit>(p, st);
+        }
+        return launch_conv_lean<T, BM, BN, WM, WN, EPI, false>(p, st, single);
     }
-    return launch_conv_st<T, BM, BN, WM, WN, 2, EPI>(p, st);
+    return single ? launch_conv_st<T, BM, BN, WM, WN, 1, EPI>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, EPI>(p, st);
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -871,15 +970,8 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
     if (p.x1) {  // two K segments (16-bit types only: the exact-f32 parity mode never takes the linear BatchNorm backward)
         if constexpr (sizeof(T) == 2) {
             const bool one = p.nsteps_seg <= single_max;
-            const bool split = !one && (conv_split_mode() & 8);
-            if (lean && p.fz_partials) {
-                if (split) return launch_conv_st<T, BM, BN, WM, WN, 2, 3, true, true>(p, st);
-                return one ? launch_conv_st<T, BM, BN, WM, WN, 1, 3, true>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, 3, true>(p, st);
-            }
-            if (lean) {
-                if (split) return launch_conv_st<T, BM, BN, WM, WN, 2, 2, true, true>(p, st);
-                return one ? launch_conv_st<T, BM, BN, WM, WN, 1, 2, true>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, 2, true>(p, st);
-            }
+            if (lean && p.fz_partials) return launch_conv_lean<T, BM, BN, WM, WN, 3, true>(p, st, one);
+            if (lean) return launch_conv_lean<T, BM, BN, WM, WN, 2, true>(p, st, one);
             return one ? launch_conv_st<T, BM, BN, WM, WN, 1, 0, true>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, 0, true>(p, st);
         } else {
             return SM3_EDTYPE;

@@ -89,6 +89,7 @@ SIGNATURES = {
     "sm3_bn_stats_reduce": [_P, _I, _I, _P, _P, _I, _P],
     "sm3_bn_reduce_groups": [_I],
     "sm3_bn_finalize": [_P, _I, _I, _D, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
+    "sm3_bn_stats_finalize": [_P, _I, _I, _I, _P, _P, _D, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
     "sm3_bn_eval_scale_shift": [_P, _P, _P, _P, _F, _I, _P, _P, _P],
     "sm3_bn_act": [_I, _P, _P, _P, _P, _I, _I, _P, _P, _L, _I, _I, _P],
     "sm3_bn_add_bn_act": [_I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P],

@@ -288,6 +288,10 @@ class SM3Engine:
         self.kind = kind
         self.store = None
         self.stat_sync = None
+        # one-launch BatchNorm statistics (single rank): bit-identical, 124 launches fewer per step -- and 0.8 % SLOWER in the
+        # two-lane step (62.3 vs 61.7 ms, gpurun_out r4e4): the agent-scope release fence of every block writes back an L2 that
+        # the other lane's convolution keeps dirty.  Opt-in.
+        self.fused_stats = _os.environ.get("SM3_BN_FUSED_STATS", "0") == "1"
         self.world_size = 1
         self.grad_ready = None  # callback(first_param_name, last_param_name) for gradient-bucket overlap
         self.fuse_bn_bwd = True  # BN-backward phase 1 inside the data-gradient epilogue (sm3_conv_dgrad_bnfuse)
@@ -581,7 +585,11 @@ class SM3Engine:
                     sums = self._work("sums", 2 * 2 * 2048, torch.float64)
                     ops.bn_stats_reduce(partials, prow // V, C, sums, views=V)
                     self.stat_sync(sums[:n])  # one all-reduce for both views
-            else:  # single rank: stage B of the reduction is folded into bn_finalize (one launch fewer per BN)
+            elif self.fused_stats:
+                # single rank: the whole statistics chain (row-group sums, their total, mean / var / scale / shift, running
+                # statistics) is ONE launch -- the last block to arrive finalizes (sm3_bn_stats_finalize)
+                sums, groups = None, 0
+            else:  # ... or two: stage B of the reduction folded into bn_finalize (SM3_BN_FUSED_STATS=0)
                 sums, groups = ops.bn_stats_reduce(partials, prow // V, C, None, views=V)
             ordered = self._ordered_bn and dev.type == "cuda"
 
@@ -590,10 +598,16 @@ class SM3Engine:
                     # running_mean/var/num_batches_tracked are updated view 0 first, then view 1, as in the reference's
                     # sequential encoder(x1); encoder(x2): the view-1 lane waits for view 0's update of THIS BatchNorm
                     torch.cuda.current_stream().wait_event(self._bn_ev[bu.name])
-                ops.bn_finalize(sums, count, C, gamma, beta, BN_EPS, BN_MOMENTUM, rm if track else None,
-                                rv if track else None,
-                                self.buffers[bu.name + ".num_batches_tracked"] if track else None,
-                                scale, shift, mean, invstd, groups=groups, views=V)
+                if sums is None:
+                    ops.bn_stats_finalize(partials, prow // V, count, C, gamma, beta, BN_EPS, BN_MOMENTUM,
+                                          rm if track else None, rv if track else None,
+                                          self.buffers[bu.name + ".num_batches_tracked"] if track else None,
+                                          scale, shift, mean, invstd, views=V)
+                else:
+                    ops.bn_finalize(sums, count, C, gamma, beta, BN_EPS, BN_MOMENTUM, rm if track else None,
+                                    rv if track else None,
+                                    self.buffers[bu.name + ".num_batches_tracked"] if track else None,
+                                    scale, shift, mean, invstd, groups=groups, views=V)
                 if ordered and self._view == 0:
                     ev = self._bn_ev.get(bu.name)
                     if ev is None:

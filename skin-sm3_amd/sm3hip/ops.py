@@ -722,6 +722,39 @@ def bn_finalize(sums, count, Cn, gamma, beta, eps, momentum, running_mean, runni
                                           _ptr(shift), _ptr(save_mean), _ptr(save_invstd), _stream()), "sm3_bn_finalize")
 
 
+_bn_tickets = {}
+
+
+def bn_stats_finalize(partials, rows, count, Cn, gamma, beta, eps, momentum, running_mean, running_var, nbt, scale, shift,
+                      save_mean, save_invstd, views=1):
+    """bn_stats_reduce (stage A) + bn_finalize as ONE launch (single rank): partials [views][rows][2][C] -> scale / shift /
+    save_mean / save_invstd [views][C], running statistics updated view by view.  Same bits as the two-launch form."""
+    _chk(partials, torch.float32, "partials")
+    for t, n in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
+        _chk(t, torch.float32, n)
+        if t is not None and t.numel() < Cn:
+            raise ValueError(f"{n} too small")
+    for t, n in ((scale, "scale"), (shift, "shift"), (save_mean, "save_mean"), (save_invstd, "save_invstd")):
+        _chk(t, torch.float32, n)
+        if t is not None and t.numel() < views * Cn:
+            raise ValueError(f"{n} too small")
+    _chk(nbt, torch.int64, "num_batches_tracked")
+    if partials.numel() < views * rows * 2 * Cn:
+        raise ValueError("bn_stats_finalize: partials too small")
+    ws = _bn_workspace(partials.device, Cn, views)
+    key = (partials.device, _stream_handle() if partials.device.type == "cuda" else 0)
+    tk = _bn_tickets.get(key)
+    if tk is None:  # zero once; every launch leaves them zero (stream-ordered reuse: one set per device AND stream)
+        tk = _bn_tickets[key] = torch.zeros(256, dtype=torch.int32, device=partials.device)
+    if (Cn + 31) // 32 > tk.numel():
+        raise ValueError("bn_stats_finalize: more than 8192 channels")
+    with _prof("bn_stats_finalize", 0.0, 4.0 * views * rows * 2 * Cn):
+        check(_lib.load().sm3_bn_stats_finalize(_ptr(partials), rows, Cn, views, _ptr(ws), _ptr(tk), float(count), _ptr(gamma),
+                                                _ptr(beta), eps, momentum, _ptr(running_mean), _ptr(running_var), _ptr(nbt),
+                                                _ptr(scale), _ptr(shift), _ptr(save_mean), _ptr(save_invstd), _stream()),
+              "sm3_bn_stats_finalize")
+
+
 def bn_eval_scale_shift(gamma, beta, running_mean, running_var, eps, Cn, scale, shift):
     for t in (gamma, beta, running_mean, running_var, scale, shift):
         _chk(t, torch.float32)

@@ -98,7 +98,12 @@ def test_engine_dry_run_sequences_and_bucket_schedule(model, linbn):
             del eng.backward  # the engine is cached on the (module-scoped) model
         calls = Counter(fake.calls)
     # 53 convs x 4 encoder passes + 3 linears x (2 in-modal + 4 cross) projector passes
-    assert calls["sm3_bn_finalize"] == 53 * 4 + 3 * 6 == 230  # 212 BN2d + 18 BN1d per step
+    # 212 BN2d + 18 BN1d per step.  Single rank: statistics reduction + finalize are ONE launch
+    # (sm3_bn_stats_finalize) wherever the statistics come from a convolution's partial rows; the units whose statistics come
+    # from the moments of their input (linbn_fwd_stats) keep the plain finalize
+    n_from_moments = (48 + 2 * 16) if linbn else 0
+    assert calls["sm3_bn_finalize"] + calls["sm3_bn_stats_finalize"] == 53 * 4 + 3 * 6 == 230
+    assert calls["sm3_bn_finalize"] == (n_from_moments if eng.fused_stats else 230)
     nlin = 64 if linbn else 0  # 16 Bottlenecks x 4 encoder passes: conv3 -> bn3 units whose backward goes by linearity
     nds = 16 if linbn else 0   # ... and the 4 downsample conv -> BatchNorm units of every pass
     assert calls["sm3_conv_wgrad"] == 230 - 4 - nlin - nds and calls["sm3_stem_wgrad_bn"] == 4  # bf16: direct stem (csrc/stem.hip)
