@@ -22,6 +22,10 @@
 
 using namespace sm3conv;
 
+#ifndef SM3_CONV_PF
+#define SM3_CONV_PF 0  // 1: fragment double-buffering inside a K-step for the 2- / 4-stage 16-bit kernels (build-time A/B)
+#endif
+
 namespace {
 
 // STAGES = 2: K-loop with the DMA of step s+1 in flight while step s is computed (LDS 64 KB + 2 KB, 2 workgroups
@@ -84,7 +88,9 @@ struct StampRec {
 //              staging instead of half of them after it.
 constexpr int kVarSplit = 1, kVarPw = 2, kVarNoX = 4;
 template <typename T, int BM, int BN, int WM, int WN, int STAGES, int EPI, bool SEG = false, int VAR = 0>
-__global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((EPI >= 2 || (VAR & kVarSplit)) ? 4 : 2)) void conv_igemm_kernel(const ConvParams p) {  // EPI 3: 130 -> 128 registers, 4 workgroups per CU
+// registers: the 1-stage kernels (34 KB of LDS) run 4 workgroups per CU = 4 waves per SIMD, so their epilogues must fit 128
+// registers; the 2- and 4-stage kernels are limited to 2 / 1 workgroups per CU by their LDS and may use 256
+__global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * WN == 8 && STAGES == 1) ? 8 : ((EPI >= 2 && STAGES == 1) || (VAR & kVarSplit)) ? 4 : 2)) void conv_igemm_kernel(const ConvParams p) {
     constexpr bool SPLIT = (VAR & kVarSplit) != 0, PW = (VAR & kVarPw) != 0, NOX = (VAR & kVarNoX) != 0;
     static_assert(!NOX || EPI == 3, "kVarNoX: the fused BN-backward epilogue");
 #ifdef SM3_STAMP
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((EPI >=
 
     auto compute = [&](int stage) {
         const char* sS = smem + stage * STAGE;
-        if constexpr (SPLIT) {
+        if constexpr (SPLIT || (SM3_CONV_PF && STAGES >= 2 && sizeof(T) == 2)) {
             // consumer waves: the fragments of K-quarter kk+1 are requested before the MFMAs of quarter kk are issued
             // (a second fragment register set: the loop has them to spare, the epilogue sets the kernel's maximum)
             uint4 fa[2][TM], fb[2][TN];
@@ -638,17 +644,26 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((EPI >=
                 if (fz) {
                     const int fz_prow = tile_view ? p.fz_row_off1 + bm - p.fz_view_tiles : p.fz_row_off + bm;
                     __syncthreads();  // everyone is done reading sC: reuse it for the cross-thread reduction
-                    float* sRed = reinterpret_cast<float*>(smem);  // [NT][16] floats = 16 KB
+                    // sRed[value e][thread], rows of NT + 8 floats: a wave writes 64 consecutive banks, and the 64 readers of
+                    // a wave (value col % 8 of thread rl * CPR + col / 8) hit bank 8 * (col % 8) + col / 8 + const -- all
+                    // different.  (The [thread][16] layout of round 3 was an 8-way conflict on every write: most of the
+                    // 28 % LDS bank-conflict cycles of this instantiation.)
+                    constexpr int RP = NT + 8;
+                    constexpr int NSTAT = NOX ? 1 : 2;  // without x the sum(dz * xhat) slot is written as 0
+                    float* sRed = reinterpret_cast<float*>(smem);  // [8 * NSTAT][RP] floats <= 16.5 KB
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        sRed[tid * 16 + e] = f_s1[e];
-                        sRed[tid * 16 + 8 + e] = f_s2[e];
+                        sRed[e * RP + tid] = f_s1[e];
+                        if constexpr (!NOX) sRed[(8 + e) * RP + tid] = f_s2[e];
                     }
                     __syncthreads();
                     for (int o = tid; o < 2 * BN; o += NT) {
                         const int stat = o / BN, col = o % BN;  // channel n0+col lives in threads with cc == col/8
                         float a = 0.f;
-                        for (int rl = 0; rl < NT / CPR; ++rl) a += sRed[(rl * CPR + col / 8) * 16 + stat * 8 + col % 8];
+                        if (stat < NSTAT) {
+                            const float* src = sRed + (stat * 8 + col % 8) * RP + col / 8;
+                            for (int rl = 0; rl < NT / CPR; ++rl) a += src[rl * CPR];
+                        }
                         if (n0 + col < p.Co) p.fz_partials[((long)fz_prow * 2 + stat) * p.Co + n0 + col] = a;
                     }
                     SM3_MARK(5);
@@ -963,8 +978,13 @@ int launch_conv_epi(const ConvParams& p, hipStream_t st, bool single, bool deep)
 
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_conv(const ConvParams& p, hipStream_t st) {
+    // K-steps up to which the ONE-stage loop runs (34 KB of LDS, 4 workgroups per CU overlapping each other) instead of the
+    // double-buffered one (66 KB, 2 per CU).  Rounds 1-3 drew the line at 8 K-steps; with the lean / pointwise epilogues the
+    // one-stage loop wins at EVERY length measured (profiles/r04a_stage_choice_*: 3x3 256->256, 36 K-steps, 847 -> 950
+    // TFLOP/s; two-segment 1x1 launches -11 ... -20 %; whole step 4 239 -> 4 354 pairs/s), so the default is "always"; the
+    // 4-stage loop of the small-grid launches (deep, below) is not affected.  SM3_CONV_SINGLE_STAGE_MAX=8 restores round 3.
     const char* v = getenv("SM3_CONV_SINGLE_STAGE_MAX");
-    const int single_max = v ? atoi(v) : 8;
+    const int single_max = v ? atoi(v) : (1 << 30);
     const char* lv = getenv("SM3_CONV_LEAN");
     const bool lean = !(lv && atoi(lv) == 0);  // SM3_CONV_LEAN=0: everything through the general epilogue (A/B, debugging)
     if (p.x1) {  // two K segments (16-bit types only: the exact-f32 parity mode never takes the linear BatchNorm backward)
@@ -993,8 +1013,10 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
                 // 3x3 forward launches: 8 waves on the same 128 x 128 tile (64 x 32 wave tiles) -- each wave issues 4 of the
                 // stage's LDS-DMA pieces instead of 8, which is as long as its MFMA phase (profiles/r03b_smemtime_kloop_timeline.txt):
                 // +2 ... +8 % on these layers; the short-K 1x1 layers lose (their epilogue on 512 threads) and keep 4 waves.
-                static const bool w8 = !(getenv("SM3_CONV_W8") && atoi(getenv("SM3_CONV_W8")) == 0);
-                if (w8 && p.ntaps >= 9 && !single && !deep && !conv_split_wanted<1, BN>(p)) return launch_conv_st<T, BM, BN, 2, 4, 2, 1>(p, st);
+                const char* w8v = getenv("SM3_CONV_W8");
+                const int w8 = w8v ? atoi(w8v) : 1;  // bit 0: the 2-stage 8-wave kernel; bit 1: 8 waves on the 1-stage loop too (A/B)
+                if ((w8 & 1) && p.ntaps >= 9 && !single && !deep && !conv_split_wanted<1, BN>(p)) return launch_conv_st<T, BM, BN, 2, 4, 2, 1>(p, st);
+                if ((w8 & 2) && p.ntaps >= 9 && single && !deep) return launch_conv_st<T, BM, BN, 2, 4, 1, 1>(p, st);
             }
             return launch_conv_epi<T, BM, BN, WM, WN, 1>(p, st, single, deep);  // train-mode forward, conv + evalBN (+ReLU)
         }
