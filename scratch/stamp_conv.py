@@ -73,6 +73,9 @@ def run(name, N, H, W, Ci, Co, k, stats=True):
 
 
 print(__doc__.split("Usage")[0])
+print("(SM3_CONV_SINGLE_STAGE_MAX = %s: the ONE-stage loop runs up to that many K-steps -- there 'issue' is the DMA issue of the next\n"
+      " stage AFTER the barrier that ends the reads of this one, 'drain' the full landing latency, 'barrier' both barriers of a K-step;\n"
+      " four workgroups per CU overlap each other instead of two stages inside one)" % os.environ.get("SM3_CONV_SINGLE_STAGE_MAX", "default (always)"))
 run("layer3 conv2, 3x3 256->256 (lean forward + BN sums)", 512, 14, 14, 256, 256, 3)
 run("layer2 conv2, 3x3 128->128", 512, 28, 28, 128, 128, 3)
 run("layer4 conv2, 3x3 512->512", 512, 7, 7, 512, 512, 3)

@@ -386,15 +386,39 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
         stamp.nsteps = nsteps;
 #endif
         for (int s = 0; s < nsteps; ++s) {
+#ifdef SM3_STAMP
+            const unsigned long long q0 = SM3_STAMP_NOW();
+#endif
             compute(0);
+#ifdef SM3_STAMP
+            const unsigned long long q1 = SM3_STAMP_NOW();
+#endif
             __syncthreads();  // everyone is done reading the stage
+#ifdef SM3_STAMP
+            const unsigned long long q2 = SM3_STAMP_NOW();
+            stamp.seg[1] += q1 - q0; stamp.seg[3] += q2 - q1;
+#endif
             if (s + 1 < nsteps) {
                 advance();
                 dma_stage(0, (uint32_t)kc * 128u, wtap_off + (uint32_t)kc * 128u);
+#ifdef SM3_STAMP
+                const unsigned long long q3 = SM3_STAMP_NOW();
+#endif
                 dma_drain();
+#ifdef SM3_STAMP
+                const unsigned long long q4 = SM3_STAMP_NOW();
+#endif
                 __syncthreads();
+#ifdef SM3_STAMP
+                const unsigned long long q5 = SM3_STAMP_NOW();
+                stamp.seg[0] += q3 - q2; stamp.seg[2] += q4 - q3; stamp.seg[3] += q5 - q4;
+#endif
             }
         }
+#ifdef SM3_STAMP
+        stamp.t_loop0 = stamp.mark[1];
+        stamp.t_loop1 = SM3_STAMP_NOW();
+#endif
     }
     }  // !SPLIT
     SM3_MARK(2);

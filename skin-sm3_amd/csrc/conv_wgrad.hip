@@ -432,8 +432,13 @@ int launch_wgrad(WgradParams p, hipStream_t st) {
     const bool dense = p.ntaps == 1 && p.sy == 1 && p.sx == 1 && p.dyt[0] == 0 && p.dxt[0] == 0 &&
                        p.HoWo == p.Hi * p.Wi;
     if (dense) {
-        static const bool kg2 = !(getenv("SM3_WGRAD_KG") && atoi(getenv("SM3_WGRAD_KG")) == 1);
+        // SM3_WGRAD_KG=1: one K-group (64 KB, two workgroups per CU); SM3_WGRAD_DENSE_NST=2 with it: 2 stages, 32 KB, four to
+        // five workgroups per CU (A/B switches, read at every launch)
+        const char* kgv = getenv("SM3_WGRAD_KG");
+        const bool kg2 = !(kgv && atoi(kgv) == 1);
         if (kg2) return launch_wgrad_kp<T, BMW, BNW, KP, true, 4, 2>(p, st);
+        const char* nv = getenv("SM3_WGRAD_DENSE_NST");
+        if (nv && atoi(nv) == 2) return launch_wgrad_kp<T, BMW, BNW, KP, true, 2>(p, st);
         return launch_wgrad_kp<T, BMW, BNW, KP, true, 4>(p, st);
     }
     return launch_wgrad_kp<T, BMW, BNW, KP, false, 2>(p, st);
