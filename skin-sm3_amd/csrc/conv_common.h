@@ -94,6 +94,20 @@ __device__ __forceinline__ void mma_frag<float>(const uint4& a, const uint4& b, 
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
 }
 
+// 16 x 16 x 32 form of the 16-bit MFMA (kVarM16 of conv_igemm.hip): A / B fragments of 8 consecutive k per lane
+template <typename T>
+__device__ __forceinline__ void mma_frag16(const uint4& a, const uint4& b, f32x4& c);
+template <>
+__device__ __forceinline__ void mma_frag16<bf16_t>(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_frag16<f16_t>(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_frag16<float>(const uint4&, const uint4&, f32x4&) {}  // (never instantiated for f32)
+
 // byte offset of 16-byte chunk `c` of row `r` inside a [rows][128 B] LDS tile.  Two rows share a
 // 256-byte bank row, so the swizzle key is the row pair: the 16 lanes of every ds_read_b128 group
 // then hit 16 distinct 16-byte slots.

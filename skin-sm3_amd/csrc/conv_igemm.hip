@@ -86,12 +86,17 @@ struct StampRec {
 //   kVarNoX    EPI 3 without the producer's x (the linear BatchNorm forms: ReLU mask + sum(dz) only): no x operand stream,
 //              no sum(dz * xhat) arithmetic, and with the registers that frees ALL rows' operands are requested before the
 //              staging instead of half of them after it.
-constexpr int kVarSplit = 1, kVarPw = 2, kVarNoX = 4;
+//   kVarM16    the 16-bit MFMAs as v_mfma_f32_16x16x32 instead of 32x32x16: same LDS fragment traffic, same accumulator
+//              registers, same cycles per FLOP -- but the chip holds a higher clock on this shape under load
+//              (MI355X_MICROARCH.md, DVFS give-back item 7); lean epilogues only (the accumulator layout differs).
+constexpr int kVarSplit = 1, kVarPw = 2, kVarNoX = 4, kVarM16 = 8;
 template <typename T, int BM, int BN, int WM, int WN, int STAGES, int EPI, bool SEG = false, int VAR = 0>
 // registers: the 1-stage kernels (34 KB of LDS) run 4 workgroups per CU = 4 waves per SIMD, so their epilogues must fit 128
 // registers; the 2- and 4-stage kernels are limited to 2 / 1 workgroups per CU by their LDS and may use 256
-__global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * WN == 8 && STAGES == 1) ? 8 : ((EPI >= 2 && STAGES == 1) || (VAR & kVarSplit)) ? 4 : 2)) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * WN == 8 && STAGES == 1) ? 8 : ((EPI >= 1 && STAGES == 1) || (VAR & kVarSplit)) ? 4 : 2)) void conv_igemm_kernel(const ConvParams p) {
     constexpr bool SPLIT = (VAR & kVarSplit) != 0, PW = (VAR & kVarPw) != 0, NOX = (VAR & kVarNoX) != 0;
+    constexpr bool M16 = (VAR & kVarM16) != 0;
+    static_assert(!M16 || (EPI >= 1 && sizeof(T) == 2 && !SPLIT), "kVarM16: 16-bit lean epilogues");
     static_assert(!NOX || EPI == 3, "kVarNoX: the fused BN-backward epilogue");
 #ifdef SM3_STAMP
     StampRec stamp;
@@ -223,13 +228,30 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
         for (int i = 0; i < BI; ++i) dma16(rw, sB + i * (RPP * 128), b_off[i], soff_b);
     };
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[M16 ? 1 : TM][M16 ? 1 : TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < (M16 ? 1 : TM); ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < (M16 ? 1 : TN); ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // kVarM16: 16 x 16 tiles, four accumulator registers each; lane = (column j = lane & 15, row group g = lane >> 4),
+    // register r = row 4 g + r of the tile
+    constexpr int TM4 = WTM / 16, TN4 = WTN / 16;
+    f32x4 acc4[M16 ? TM4 : 1][M16 ? TN4 : 1];
+#pragma unroll
+    for (int i = 0; i < (M16 ? TM4 : 1); ++i)
+#pragma unroll
+        for (int j = 0; j < (M16 ? TN4 : 1); ++j) acc4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fragment of a 16 x 16 x 32 MFMA: lane (row l & 15, K group l >> 4) holds 8 consecutive k = chunk 4 h + (l >> 4) of
+    // its row for K half h: base(l >> 4) ^ (h << 6), by the same XOR linearity as below
+    uint32_t fa4[M16 ? TM4 : 1], fb4[M16 ? TN4 : 1];
+    if constexpr (M16) {
+#pragma unroll
+        for (int i = 0; i < TM4; ++i) fa4[i] = lds_off(wm * WTM + i * 16 + (lane & 15), lane >> 4);
+#pragma unroll
+        for (int j = 0; j < TN4; ++j) fb4[j] = A_BYTES + lds_off(wn * WTN + j * 16 + (lane & 15), lane >> 4);
+    }
 
     // fragment read offsets: chunk (2*kk + fh) of row r sits at r*128 + (((2*kk+fh) ^ (r>>1)) & 7) * 16
     //   = base(r, fh) ^ (kk << 5)   (bits 5-6 of the offset carry kk; r*128 leaves them clear)
@@ -264,6 +286,21 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) mma_frag<T>(fa[kk & 1][i], fb[kk & 1][j], acc[i][j]);
+            }
+            return;
+        }
+        if constexpr (M16) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint4 fa[TM4], fb[TN4];
+#pragma unroll
+                for (int i = 0; i < TM4; ++i) fa[i] = *reinterpret_cast<const uint4*>(sS + (fa4[i] ^ (h << 6)));
+#pragma unroll
+                for (int j = 0; j < TN4; ++j) fb[j] = *reinterpret_cast<const uint4*>(sS + (fb4[j] ^ (h << 6)));
+#pragma unroll
+                for (int i = 0; i < TM4; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN4; ++j) mma_frag16<T>(fa[i], fb[j], acc4[i][j]);
             }
             return;
         }
@@ -497,6 +534,31 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
                 }
             }
         };
+        // per-column BatchNorm affine / constant term of this lane's TN columns (accumulator layout), requested BEFORE the
+        // row operands: their latency (two dependent L2 round trips per column block, 4 - 6 k cycles of the 7 k the staging
+        // phase of the fused-BatchNorm forward launches took) now hides behind the issue of the row requests
+        const bool epl = p.ep_scale != nullptr || p.ep_rv != nullptr;
+        const bool aff = epl || (SEG && p.col_bias);
+        constexpr int NCB = M16 ? TN4 : TN, CBW = M16 ? 16 : 32;  // column blocks of this lane, their width
+        const int lcol = M16 ? (lane & 15) : frow;
+        float esc_j[NCB], esh_j[NCB];
+#pragma unroll
+        for (int j = 0; j < NCB; ++j) {
+            esc_j[j] = 1.f;
+            esh_j[j] = 0.f;
+            const int gcol = n0 + wn * WTN + j * CBW + lcol;
+            if (epl && gcol < p.Co) {
+                if (p.ep_rv) {
+                    ep_affine(p, gcol, esc_j[j], esh_j[j]);
+                } else {
+                    esc_j[j] = p.ep_scale[tile_view * p.Co + gcol];
+                    esh_j[j] = p.ep_shift[tile_view * p.Co + gcol];
+                }
+            }
+            if constexpr (SEG) {  // constant term of the linear BatchNorm backward (per output channel and view)
+                if (p.col_bias && gcol < p.Co) esh_j[j] += p.col_bias[tile_view * p.Co + gcol];
+            }
+        }
         if constexpr (EPI >= 2) {
 #pragma unroll
             for (int k = 0; k < NEARLY; ++k) request(k);
@@ -505,33 +567,55 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
         // The staging loop in four compile-time flavours (statistics wanted or not, affine or not): the launch-level flags
         // are tested once, not per accumulator pair -- EPI 2 / 3 launches almost never want the BatchNorm sums of their
         // output and used to pay 2 v_dot2 per pair for them.
-        const bool epl = p.ep_scale != nullptr || p.ep_rv != nullptr;
-        const bool aff = epl || (SEG && p.col_bias);
         const bool early_relu = epl && p.ep_relu && (EPI == 1 || !p.addend) && !p.ep_mask;
         auto stage_tile = [&](auto stats_c, auto aff_c) {
             constexpr bool STATS = decltype(stats_c)::value, AFF = decltype(aff_c)::value;
+            if constexpr (M16) {
+                const int g4 = lane >> 4;
+#pragma unroll
+                for (int j = 0; j < TN4; ++j) {
+                    float s1 = 0.f, s2 = 0.f;
+                    char* colp = sC + (wn * WTN + j * 16 + lcol) * 2 + (wm * WTM + 4 * g4) * LEAN_PITCH;
+                    const float esc = esc_j[j], esh = esh_j[j], elo = (AFF && early_relu) ? 0.f : -INFINITY;
+#pragma unroll
+                    for (int i = 0; i < TM4; ++i)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {  // registers 2q, 2q+1 = rows 16 i + 4 g + 2q, +1 of this lane's column
+                            float v0 = acc4[i][j][2 * q], v1 = acc4[i][j][2 * q + 1];
+                            if constexpr (AFF) {
+                                v0 = fmaxf(v0 * esc + esh, elo);
+                                v1 = fmaxf(v1 * esc + esh, elo);
+                            }
+                            const uint32_t pk = pack2<T>(v0, v1);
+                            if constexpr (STATS) {
+                                s1 = dot2acc<T>(pk, ones, s1);
+                                s2 = dot2acc<T>(pk, pk, s2);
+                            }
+                            const int R = i * 16 + 2 * q;
+                            *reinterpret_cast<uint16_t*>(colp + R * LEAN_PITCH) = (uint16_t)pk;
+                            *reinterpret_cast<uint16_t*>(colp + (R + 1) * LEAN_PITCH) = (uint16_t)(pk >> 16);
+                        }
+                    if constexpr (STATS) {
+                        s1 += __shfl_xor(s1, 16, 64);
+                        s2 += __shfl_xor(s2, 16, 64);
+                        s1 += __shfl_xor(s1, 32, 64);
+                        s2 += __shfl_xor(s2, 32, 64);
+                        if (lane < 16) {
+                            const int col = wn * WTN + j * 16 + lane;
+                            sStat[(wm * BN + col) * 2 + 0] = s1;
+                            sStat[(wm * BN + col) * 2 + 1] = s2;
+                        }
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 float s1 = 0.f, s2 = 0.f;
                 char* colp = sC + (wn * WTN + j * 32 + frow) * 2 + (wm * WTM + 4 * fh) * LEAN_PITCH;
                 // BatchNorm affine (+ReLU when nothing is added afterwards) of this lane's column, in the accumulator layout;
                 // per view in the train-mode fused form
-                float esc = 1.f, esh = 0.f, elo = -INFINITY;
-                if constexpr (AFF) {
-                    const int gcol = n0 + wn * WTN + j * 32 + frow;
-                    if (epl && gcol < p.Co) {
-                        if (p.ep_rv) {
-                            ep_affine(p, gcol, esc, esh);
-                        } else {
-                            esc = p.ep_scale[tile_view * p.Co + gcol];
-                            esh = p.ep_shift[tile_view * p.Co + gcol];
-                        }
-                    }
-                    if constexpr (SEG) {  // constant term of the linear BatchNorm backward (per output channel and view)
-                        if (p.col_bias && gcol < p.Co) esh += p.col_bias[tile_view * p.Co + gcol];
-                    }
-                    elo = early_relu ? 0.f : -INFINITY;
-                }
+                const float esc = esc_j[j], esh = esh_j[j], elo = (AFF && early_relu) ? 0.f : -INFINITY;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -972,19 +1056,44 @@ static bool conv_is_pointwise(const ConvParams& p) {
     return dense && taps0 && p.sy == 1 && p.sx == 1 && p.Hi * p.Wi == p.HoWo && p.add_sp_h == 0;
 }
 
+// The 16 x 16 x 32 MFMA shape (kVarM16) in the one-stage lean launches: measured 4 % SLOWER over the convolution class
+// (3x3 forward 920 -> 870 TFLOP/s, step 4 346 -> 4 266 pairs/s, gpurun_out r4e15) -- twice the MFMA instructions per
+// K-step cost more issue slots than the shape's clock advantage returns in a loop that is not MFMA-dense -- and one
+// epilogue variant of it fails a kernel test.  Built only with -DSM3_CONV_M16_BUILD (then SM3_CONV_M16=1 selects it).
+static int conv_m16_mode() {
+#ifdef SM3_CONV_M16_BUILD
+    const char* v = getenv("SM3_CONV_M16");
+    return v ? atoi(v) : 0;
+#else
+    return 0;
+#endif
+}
+
 // 16-bit lean epilogues on the 1- or 2-stage K loop
 template <typename T, int BM, int BN, int WM, int WN, int EPI, bool SEG>
 int launch_conv_lean(const ConvParams& p, hipStream_t st, bool single) {
     const int mode = conv_pw_mode();
+    const bool m16 = single && (conv_m16_mode() & 1);
+    (void)m16;
     if ((mode & 1) && conv_is_pointwise(p)) {
         if constexpr (EPI == 3 && !SEG) {
-            if ((mode & 2) && p.fz_partials && !p.fz_x)
+            if ((mode & 2) && p.fz_partials && !p.fz_x) {
+#ifdef SM3_CONV_M16_BUILD
+                if (m16) return launch_conv_st<T, BM, BN, WM, WN, 1, 3, false, kVarPw | kVarNoX | kVarM16>(p, st);
+#endif
                 return single ? launch_conv_st<T, BM, BN, WM, WN, 1, 3, false, kVarPw | kVarNoX>(p, st)
                               : launch_conv_st<T, BM, BN, WM, WN, 2, 3, false, kVarPw | kVarNoX>(p, st);
+            }
         }
+#ifdef SM3_CONV_M16_BUILD
+        if (m16) return launch_conv_st<T, BM, BN, WM, WN, 1, EPI, SEG, kVarPw | kVarM16>(p, st);
+#endif
         return single ? launch_conv_st<T, BM, BN, WM, WN, 1, EPI, SEG, kVarPw>(p, st)
                       : launch_conv_st<T, BM, BN, WM, WN, 2, EPI, SEG, kVarPw>(p, st);
     }
+#ifdef SM3_CONV_M16_BUILD
+    if (m16) return launch_conv_st<T, BM, BN, WM, WN, 1, EPI, SEG, kVarM16>(p, st);
+#endif
     return single ? launch_conv_st<T, BM, BN, WM, WN, 1, EPI, SEG>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, EPI, SEG>(p, st);
 }
 
