@@ -29,12 +29,14 @@ static RowWalk make_walk(int64_t rows, int cvecs, int max_gy, int views = 1) {
     if (w.tby < 1) w.tby = 1;
     w.gx = (cvecs + w.tbx - 1) / w.tbx;
     int64_t gy = (rows + (int64_t)w.tby * 8 - 1) / ((int64_t)w.tby * 8);  // >= 8 rows per thread
-    // At most 512 blocks = 2 per CU (env SM3_BN_GRID_CAP).  With 4-8 rows in flight per thread that already
-    // saturates HBM (scratch/stream_bench.hip: 1024 >= 2048 blocks), and it leaves 24 of a CU's 32 wave slots to
-    // the other execution lane's convolution: 2048 -> 768 was worth 1.2 % of the two-lane step in round 1; with the
-    // one-stage convolutions of round 4 (4 workgroups per CU) the optimum moved down once more -- 2048 / 1024 / 768 /
-    // 512 / 384 / 256 blocks: 4 263 / 4 302 / 4 309 / 4 340 / 4 358* / 4 330* pairs/s (* another box: 768 = 4 370).
-    static const int grid_cap = getenv("SM3_BN_GRID_CAP") ? atoi(getenv("SM3_BN_GRID_CAP")) : 512;
+    // At most 768 blocks = 3 per CU (env SM3_BN_GRID_CAP).  With 4-8 rows in flight per thread that already
+    // saturates HBM (scratch/stream_bench.hip: 1024 >= 2048 blocks), and it leaves 20 of a CU's 32 wave slots to
+    // the other execution lane's convolution: 2048 -> 768 was worth 1.2 % of the two-lane step in round 1.  Round 4
+    // re-swept it against the one-stage convolutions -- 2048 / 1024 / 768 / 512 / 384 / 256 blocks: 4 263 / 4 302 /
+    // 4 309 / 4 340 / 4 358* / 4 330* pairs/s (* another box, where 768 gave 4 370 and 512 gave 4 380): 512 is +0.2 ...
+    // +0.7 % in the two-lane step but runs the pass itself 20 % slower when it has the chip alone (5.2 -> 4.2 TB/s, as
+    // under a SyncBN exchange), so 768 stays.
+    static const int grid_cap = getenv("SM3_BN_GRID_CAP") ? atoi(getenv("SM3_BN_GRID_CAP")) : 768;
     const int64_t cap = grid_cap / (w.gx * views) > 0 ? grid_cap / (w.gx * views) : 1;  // the cap is per launch, views included
     if (gy > cap) gy = cap;
     if (gy > max_gy) gy = max_gy;
