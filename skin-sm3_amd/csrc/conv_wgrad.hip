@@ -71,7 +71,10 @@ __device__ __forceinline__ uint32_t swz_bytes(int row) {
 // and accumulators; group 1 hands its tile to group 0 through LDS and ONE set of f32 atomics leaves the workgroup --
 // the same waves per CU as two 4-wave workgroups at half the atomic traffic (the 1x1 layers paid 20 % for atomics).
 template <typename T, int BMW, int BNW, int KP, bool DENSE, int NST, int KG = 1>  // KP = pixels per K-step, NST = LDS stages
-__global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(const WgradParams p) {
+#ifndef SM3_WGRAD_OCC
+#define SM3_WGRAD_OCC 0  // build-time A/B: 4 = cap the tap-shifted (3x3 / strided) kernel at 128 registers -> 4 workgroups per CU
+#endif
+__global__ __launch_bounds__(256 * KG, (SM3_WGRAD_OCC && !DENSE && KG == 1) ? SM3_WGRAD_OCC : 1) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int SZ = sizeof(T);
     constexpr bool kBf16 = (SZ == 2);
     constexpr int RA = BMW * SZ, RB = BNW * SZ;                 // bytes per tile row (one pixel)
