@@ -210,3 +210,27 @@ def test_linear_and_two_pass_batchnorm_forms_agree_at_b16(dtname):
     assert abs(non - noff) < (0.03 if dtname == "f16" else 0.08) * noff and abs(non - n32) < 0.10 * n32
     assert c_on > c_off - 0.05 and c_on >= (0.65 if dtname == "f16" else 0.15)
     assert c_between >= min(c_on, c_off) - 0.1
+
+
+def test_bench_p2p_ab_prints_a_second_record_with_its_witness():
+    """`SM3_BENCH_AB_P2P=1` repeats the timed loop with the peer-to-peer SyncBN exchange and prints a
+    second, line-compatible record after the contract's one.  Rehearsed on the one GPU with the data-parallel path forced
+    (`SM3_BENCH_FORCE_DP=1`: one rank over the real `nccl` backend): two JSON lines, the first with the RCCL witness (ranks
+    COUNTED by an all-reduce), the second with `syncbn_exchange == "p2p"` and the mailboxes' memory kind."""
+    import json
+    import subprocess
+    env = dict(os.environ, SM3_BENCH_FORCE_DP="1", SM3_BENCH_AB_P2P="1", MASTER_PORT="29577")
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "32",
+                         "--img", "64", "--no-cpu-baseline", "--no-other-dtypes"], env=env, capture_output=True, text=True,
+                        timeout=300)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    lines = [json.loads(l) for l in pr.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 2, pr.stdout
+    first, second = lines
+    w1, w2 = first["config"]["witness"], second["config"]["witness"]
+    assert w1["backend"] == "nccl" and w1["rccl_ranks"] == 1 and w1["syncbn_exchange"] == "rccl" and w1["nccl_version"]
+    assert w2["syncbn_exchange"] == "p2p" and w2["p2p_mailbox_memory"] in ("finegrained", "coarse") and w2["rccl_ranks"] == 1
+    for rec in lines:
+        assert rec["unit"] == "pairs/s" and rec["value"] > 0 and rec["n_gpus"] == 1 and rec["steps"] == 2
+        assert math.isfinite(rec["config"]["loss"])
+    assert abs(first["config"]["loss"] - second["config"]["loss"]) < 0.5   # same model, two more steps at lr 1e-6
