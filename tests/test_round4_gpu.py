@@ -233,4 +233,6 @@ def test_bench_p2p_ab_prints_a_second_record_with_its_witness():
     for rec in lines:
         assert rec["unit"] == "pairs/s" and rec["value"] > 0 and rec["n_gpus"] == 1 and rec["steps"] == 2
         assert math.isfinite(rec["config"]["loss"])
-    assert abs(first["config"]["loss"] - second["config"]["loss"]) < 0.5   # same model, two more steps at lr 1e-6
+    # the same trainer keeps training on the same batch through both loops (13.4 -> 12.2 after three steps, 10.6 after six,
+    # whichever exchange carries the statistics: scratch/dbg_p2p_switch.py): the second record continues the first
+    assert second["config"]["loss"] < first["config"]["loss"] + 0.5
