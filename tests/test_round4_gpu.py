@@ -236,3 +236,95 @@ def test_bench_p2p_ab_prints_a_second_record_with_its_witness():
     # the same trainer keeps training on the same batch through both loops (13.4 -> 12.2 after three steps, 10.6 after six,
     # whichever exchange carries the statistics: scratch/dbg_p2p_switch.py): the second record continues the first
     assert second["config"]["loss"] < first["config"]["loss"] + 0.5
+
+
+_VARIANT_ENVS = [
+    ("default", {}),
+    ("round3_stage_rule", {"SM3_CONV_SINGLE_STAGE_MAX": "8"}),
+    ("two_stage_split", {"SM3_CONV_SINGLE_STAGE_MAX": "8", "SM3_CONV_SPLIT": "17", "SM3_CONV_W8": "0"}),
+    ("two_stage_4waves", {"SM3_CONV_SINGLE_STAGE_MAX": "8", "SM3_CONV_W8": "0"}),
+    ("no_pointwise", {"SM3_CONV_PW": "0"}),
+    ("pointwise_with_x_path", {"SM3_CONV_PW": "1"}),
+    ("one_stage_8waves", {"SM3_CONV_W8": "3"}),
+    ("general_epilogue", {"SM3_CONV_LEAN": "0"}),
+]
+
+
+@pytest.mark.parametrize("dtname", ["bf16", "f16"])
+def test_gather_gemm_variants_are_bit_identical(dtname, monkeypatch):
+    """Every instruction-level variant of the gather-GEMM that round 4 added or re-ranked (one-stage vs double-buffered K
+    loop, loader / consumer waves, 8-wave tiles, pointwise and no-x epilogues) computes the same sums in the same order: on a
+    3x3 and two 1x1 shapes, forward (+ BatchNorm partial sums), fused BatchNorm + identity + ReLU forward and the data
+    gradient with fused BN-backward phase 1 (with and without x) give the SAME BITS under every switch -- so an A/B of two
+    variants compares speed and nothing else.  (The general f32-staging epilogue, SM3_CONV_LEAN=0, rounds once instead of
+    twice where an affine or an addend follows: it is compared on the plain forward only.)"""
+    from sm3hip import ops
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16}[dtname]
+    code = ops.dtype_code(dt)
+    D = torch.device(DEV)
+    g = torch.Generator().manual_seed(77)
+    cases = [(4, 256, 256, 14, 3), (2, 1024, 256, 14, 1), (3, 128, 512, 28, 1)]   # N, Ci, Co, H, k
+    results = {}
+    for vname, env in _VARIANT_ENVS:
+        for k_ in ("SM3_CONV_SINGLE_STAGE_MAX", "SM3_CONV_SPLIT", "SM3_CONV_W8", "SM3_CONV_PW", "SM3_CONV_LEAN"):
+            monkeypatch.delenv(k_, raising=False)
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        outs = []
+        for ci_, (N, Ci, Co, H, k) in enumerate(cases):
+            gg = torch.Generator().manual_seed(77 + ci_)  # a case's inputs do not depend on what ran before it
+            pad = k // 2
+            d = ops.fwd_desc(code, N, H, H, Ci, Co, k, 1, pad)
+            M = N * H * H
+            x = torch.randn(M, Ci, generator=gg).to(dt).to(D)
+            w = (torch.randn(Co, k * k * Ci, generator=gg) / math.sqrt(k * k * Ci)).to(dt).to(D)
+            y = torch.empty(M, Co, dtype=dt, device=D)
+            part = torch.zeros(ops.conv_partial_rows(d) * 2 * Co, device=D)
+            ops.conv_gemm(d, x, w, y, None, part)
+            outs += [y, part]
+            if vname == "general_epilogue":
+                continue
+            if k == 1:  # fused BatchNorm affine + identity + ReLU + ReLU bits (EPI 2)
+                res = torch.randn(M, Co, generator=gg).to(dt).to(D)
+                sc, sh = (torch.rand(Co, generator=gg) + 0.5).to(D), torch.randn(Co, generator=gg).to(D)
+                y2 = torch.empty(M, Co, dtype=dt, device=D)
+                mk = torch.zeros(M * Co // 8, dtype=torch.uint8, device=D)
+                ops.conv_bn_act_fused(d, x, w, sc, sh, res, True, y2, mk, views=1)
+                outs += [y2, mk]
+            # data gradient with the fused phase 1: dy [M, Co] -> dz [M, Ci]
+            descs, full = ops.dgrad_descs(code, N, H, H, Ci, Co, k, 1, pad)
+            dy = torch.randn(M, Co, generator=gg).to(dt).to(D)
+            wdg = (torch.randn(Ci, k * k * Co, generator=gg) / math.sqrt(k * k * Co)).to(dt).to(D)
+            add = torch.randn(M, Ci, generator=gg).to(dt).to(D)
+            bnx = torch.randn(M, Ci, generator=gg).to(dt).to(D)
+            msk = torch.randint(0, 256, (M * Ci // 8,), generator=gg, dtype=torch.uint8).to(D)
+            mean, istd = torch.randn(Ci, generator=gg).to(D), (torch.rand(Ci, generator=gg) + 0.5).to(D)
+            for with_x in (True, False):
+                dz = torch.empty(M, Ci, dtype=dt, device=D)
+                total = sum(ops.conv_partial_rows(dd) for dd in descs)
+                fp = torch.zeros(total * 2 * Ci, device=D)
+                off = 0
+                for dd in descs:
+                    off += ops.conv_dgrad_bnfuse(dd, dy, wdg, dz, add, msk, bnx if with_x else None, mean, istd, fp, off)
+                outs += [dz, fp]
+        torch.cuda.synchronize()
+        results[vname] = outs
+    ref = results["default"]
+    for vname, outs in results.items():
+        if vname == "general_epilogue":
+            for i in range(len(cases)):
+                assert torch.equal(outs[2 * i], ref[_fwd_index(i, cases)]), (vname, i)
+            continue
+        assert len(outs) == len(ref)
+        for i, (a, b) in enumerate(zip(outs, ref)):
+            assert torch.equal(a, b), (vname, i, float((a.double() - b.double()).abs().max()))
+
+
+def _fwd_index(i, cases):
+    """Position of case i's plain forward output in the flat result list of the full variants."""
+    pos = 0
+    for j, (N, Ci, Co, H, k) in enumerate(cases):
+        if j == i:
+            return pos
+        pos += 2 + (2 if k == 1 else 0) + 4
+    raise IndexError(i)
