@@ -91,6 +91,7 @@ class SM3Trainer:
         st = eng.store
         a, b = self._bucket_range(eng, first, last)
         self._handles.append(dist.all_reduce(st.flat_g[a:b], async_op=True, group=self._groups["grads"]))
+        self._handle_ranges.append((a, b))
 
     def _bucket_range(self, eng, first, last):
         st = eng.store
@@ -282,7 +283,7 @@ class SM3Trainer:
                 dz["cross0"][half * Bm:(half + 1) * Bm] += dd[:Bm]
                 dmeta += dd[Bm:]
             dz["meta"] = dmeta
-        self._handles = []
+        self._handles, self._handle_ranges = [], []
         # Single rank, no loss scaling: AdamW runs bucket by bucket as the gradients become final, on the lane that finished
         # them -- the other lane's backward hides it (one launch over all 81.65 M parameters at the end of the step is 0.45 ms
         # during which nothing else runs).  Data parallel: the buckets are all-reduced instead and AdamW follows the last
@@ -305,8 +306,28 @@ class SM3Trainer:
             eng.grad_ready = (lambda f, l: self._bucket_ready(eng, f, l)) if self.dp else None
         eng.backward(saved, dz)
         eng.grad_ready = None
-        for h in self._handles:
-            h.wait()
+        # Data parallel without loss scaling: AdamW follows every bucket's all-reduce on its own (the stream waits for
+        # collective k, updates bucket k, while collectives k+1 ... are still on the wire) instead of one launch over all
+        # 81.65 M parameters behind the LAST collective -- provided the notified ranges tile the buffer exactly
+        # (they are the schedule the single-rank path verifies; anything else falls back to the single launch).
+        dp_buckets = False
+        if self.dp and sc is None and self._handles and len(self._handles) == len(self._handle_ranges) \
+                and os.environ.get("SM3_ADAMW_BUCKETS", "1") != "0":
+            pos = 0
+            for a, b in sorted(self._handle_ranges):
+                if a != pos or b <= a:
+                    break
+                pos = b
+            dp_buckets = pos == st.total
+        if dp_buckets:
+            self.step_count += 1
+            for h, (a, b) in zip(self._handles, self._handle_ranges):
+                h.wait()
+                ops.adamw(st.flat_p[a:b], st.flat_g[a:b], self.m[a:b], self.v[a:b], self.lr, self.betas[0], self.betas[1],
+                          self.eps, self.wd, self.step_count, 1.0 / self.world)
+        else:
+            for h in self._handles:
+                h.wait()
         if verify:
             pos = 0
             for a, b in sorted(ranges):
@@ -317,8 +338,8 @@ class SM3Trainer:
                 raise RuntimeError(f"gradient-ready notifications do not tile the {st.total} parameters exactly once "
                                    f"(contiguous cover ends at {pos}, {len(ranges)} notifications)")
             self._sched_ok = sched_key
-        if early:
-            pass  # every bucket has had its AdamW launch on the lane that finished it
+        if early or dp_buckets:
+            pass  # every bucket has had its AdamW launch (on the lane that finished it / behind its all-reduce)
         elif sc is None:
             self.step_count += 1
             ops.adamw(st.flat_p, st.flat_g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
