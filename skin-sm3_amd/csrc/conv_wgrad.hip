@@ -74,7 +74,7 @@ template <typename T, int BMW, int BNW, int KP, bool DENSE, int NST, int KG = 1>
 #ifndef SM3_WGRAD_OCC
 #define SM3_WGRAD_OCC 0  // build-time A/B: 4 = cap the tap-shifted (3x3 / strided) kernel at 128 registers -> 4 workgroups per CU
 #endif
-__global__ __launch_bounds__(256 * KG, (SM3_WGRAD_OCC && !DENSE && KG == 1) ? SM3_WGRAD_OCC : 1) void conv_wgrad_kernel(const WgradParams p) {
+__global__ __launch_bounds__(256 * KG, (NST == 1 || (SM3_WGRAD_OCC && !DENSE && KG == 1)) ? 4 : 1) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int SZ = sizeof(T);
     constexpr bool kBf16 = (SZ == 2);
     constexpr int RA = BMW * SZ, RB = BNW * SZ;                 // bytes per tile row (one pixel)
@@ -238,16 +238,25 @@ __global__ __launch_bounds__(256 * KG, (SM3_WGRAD_OCC && !DENSE && KG == 1) ? SM
     // trip of its DMA, so with one stage in flight (NST = 2) the loop runs at the DMA latency; each step waits (counted
     // vmcnt) only for its own stage and passes one barrier.
     constexpr int PER = AI + BI;  // DMA instructions per stage per wave
-    static_assert(NST >= 2 && NST <= 4 && 2 * PER <= 63, "vmcnt immediates below cover NST <= 4");
+    static_assert(NST >= 1 && NST <= 4 && 2 * PER <= 63, "vmcnt immediates below cover NST <= 4");
+    // NST = 1 (round 4, the lesson of the forward kernel): ONE stage of KP pixels, nothing in flight while it is computed --
+    // the workgroups of a CU (four at 32 KB and 128 registers) overlap each other instead of a ring overlapping itself
     for (int s = 0; s < NST - 1 && s < nsteps; ++s) dma_stage(s, s);
 
     for (int s = 0; s < nsteps; ++s) {
-        const int younger = min(NST - 2, nsteps - 1 - s);  // stages issued after stage s
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
-        else dma_drain();
-        __syncthreads();  // stage s has landed for everyone; everyone is done computing stage s - 1
-        if (s + NST - 1 < nsteps) dma_stage((s + NST - 1) % NST, s + NST - 1);
+        if constexpr (NST == 1) {
+            if (s > 0) __syncthreads();  // everyone is done computing stage s - 1
+            dma_stage(0, s);
+            dma_drain();
+            __syncthreads();  // stage s has landed for everyone
+        } else {
+            const int younger = min(NST - 2, nsteps - 1 - s);  // stages issued after stage s
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+            else dma_drain();
+            __syncthreads();  // stage s has landed for everyone; everyone is done computing stage s - 1
+            if (s + NST - 1 < nsteps) dma_stage((s + NST - 1) % NST, s + NST - 1);
+        }
         const char* sS = smem + (grp * NST + s % NST) * STAGE;
         if constexpr (kBf16) {
 #pragma unroll
@@ -442,7 +451,21 @@ int launch_wgrad(WgradParams p, hipStream_t st) {
         if (kg2) return launch_wgrad_kp<T, BMW, BNW, KP, true, 4, 2>(p, st);
         const char* nv = getenv("SM3_WGRAD_DENSE_NST");
         if (nv && atoi(nv) == 2) return launch_wgrad_kp<T, BMW, BNW, KP, true, 2>(p, st);
+        if constexpr (sizeof(T) == 2) {
+            if (nv && atoi(nv) == 1) return launch_wgrad_kp<T, BMW, BNW, 64, true, 1>(p, st);
+        }
         return launch_wgrad_kp<T, BMW, BNW, KP, true, 4>(p, st);
+    }
+    // Tap-shifted layers (3x3, strided), 16-bit, Ci >= 128: ONE stage of 64 pixels (32 KB, 124 registers: four workgroups
+    // per CU overlap each other) instead of the 2-stage ring of 32 -- the forward kernel's lesson of round 4, worth 1.5 - 3.5 %
+    // here (2.000 / 1.333 / 0.940 -> 1.971 / 1.290 / 0.912 ms per step on the 256 / 128 / 512-channel layers; the 64-channel
+    // layer loses 1.5 % and keeps the ring).  SM3_WGRAD_TAP1=0 restores the ring everywhere; =2: two K-groups on a 4-stage
+    // ring (half the atomics; 4 - 67 % slower).  The dense layers keep their 4-stage two-group ring (one stage: +3 ... +40 %).
+    if constexpr (sizeof(T) == 2) {
+        const char* tv = getenv("SM3_WGRAD_TAP1");
+        const int mode = tv ? atoi(tv) : 1;
+        if (mode == 1 && p.Ci >= 128) return launch_wgrad_kp<T, BMW, BNW, 64, false, 1>(p, st);
+        if (mode == 2) return launch_wgrad_kp<T, BMW, BNW, KP, false, 4, 2>(p, st);
     }
     return launch_wgrad_kp<T, BMW, BNW, KP, false, 2>(p, st);
 }
