@@ -57,6 +57,7 @@ struct ConvParams {
     uint8_t tap_src[SM3_MAX_TAPS];
     uint32_t w_view_bytes, w1_view_bytes;
     const float* col_bias;  // [views][Co] f32 added to the accumulators (before the addend), or null
+    int halo_rows, halo_a_bytes, halo_stat_off;  // kVarHalo (conv_igemm.hip): rows of the A image, its bytes, statistics scratch
     int dbg;  // SM3_CONV_DBG: experiment switches of the split K loop (bit 0: consumer waves at s_setprio 1)
 };
 

@@ -89,13 +89,21 @@ struct StampRec {
 //   kVarM16    the 16-bit MFMAs as v_mfma_f32_16x16x32 instead of 32x32x16: same LDS fragment traffic, same accumulator
 //              registers, same cycles per FLOP -- but the chip holds a higher clock on this shape under load
 //              (MI355X_MICROARCH.md, DVFS give-back item 7); lean epilogues only (the accumulator layout differs).
-constexpr int kVarSplit = 1, kVarPw = 2, kVarNoX = 4, kVarM16 = 8;
+//   kVarHalo   stride-1 3 x 3 launches (forward and data gradient): a tile's rows are 128 CONSECUTIVE pixels, so the nine taps
+//              of a channel chunk read the same W + 1 pixels either side of them.  The A image of a chunk (tile rows + that
+//              halo + one zero row) is staged ONCE and the nine K-steps of the chunk read it at a per-tap row shift (rows whose
+//              tap falls outside the image read the zero row); only the B tile is staged per K-step.  18 - 22 KB of A per
+//              nine K-steps instead of 144: these launches drew ~15 TB/s through L2 -> LDS, 85 % of what LDS-DMA delivers
+//              from L2 (MI355X_MICROARCH.md, "Indexed rows: gather into LDS").  K order: chunk outer, tap inner.
+constexpr int kVarSplit = 1, kVarPw = 2, kVarNoX = 4, kVarM16 = 8, kVarHalo = 16;
 template <typename T, int BM, int BN, int WM, int WN, int STAGES, int EPI, bool SEG = false, int VAR = 0>
 // registers: the 1-stage kernels (34 KB of LDS) run 4 workgroups per CU = 4 waves per SIMD, so their epilogues must fit 128
 // registers; the 2- and 4-stage kernels are limited to 2 / 1 workgroups per CU by their LDS and may use 256
 __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * WN == 8 && STAGES == 1) ? 8 : ((EPI >= 1 && STAGES == 1) || (VAR & kVarSplit)) ? 4 : 2)) void conv_igemm_kernel(const ConvParams p) {
     constexpr bool SPLIT = (VAR & kVarSplit) != 0, PW = (VAR & kVarPw) != 0, NOX = (VAR & kVarNoX) != 0;
-    constexpr bool M16 = (VAR & kVarM16) != 0;
+    constexpr bool M16 = (VAR & kVarM16) != 0, HALO = (VAR & kVarHalo) != 0;
+    static_assert(!HALO || (EPI >= 1 && STAGES == 1 && !SEG && !(VAR & (kVarSplit | kVarPw | kVarM16)) && sizeof(T) == 2 && WM * WN == 4),
+                  "kVarHalo: 16-bit lean one-stage kernels, 4 waves");
     static_assert(!M16 || (EPI >= 1 && sizeof(T) == 2 && !SPLIT), "kVarM16: 16-bit lean epilogues");
     static_assert(!NOX || EPI == 3, "kVarNoX: the fused BN-backward epilogue");
 #ifdef SM3_STAMP
@@ -158,6 +166,10 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
         const int r = (tid >> 3) + i * RPP;
         a_ch[i] = (uint32_t)((pos ^ (r >> 1)) & 7) * 16u;  // source chunk of this lane (swizzle on the source side)
         const int m = m0 + r;
+        if constexpr (HALO) {  // (own loader state below)
+            a_iy0[i] = a_ix0[i] = a_pix[i] = 0;
+            continue;
+        }
         if constexpr (PW) {  // the row is pixel m of the source
             a_iy0[i] = a_ix0[i] = 0;
             a_pix[i] = m < p.M ? m : -1;
@@ -321,7 +333,7 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
     const int nsteps = SEG ? p.nsteps_seg : p.ntaps * p.kchunks;
     int t = 0, kc = 0;
     SM3_MARK(0);
-    set_tap(0);
+    if constexpr (!HALO) set_tap(0);
     int kch = (SEG && cur_src) ? p.kchunks1 : p.kchunks;  // K-steps of the current tap
     uint32_t wtap_off = (uint32_t)p.wtap[0] * ((SEG && cur_src) ? row_bytes1 : row_bytes);
     auto advance = [&]() {
@@ -333,7 +345,81 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
             wtap_off = (uint32_t)p.wtap[t] * ((SEG && cur_src) ? row_bytes1 : row_bytes);
         }
     };
-    if constexpr (SPLIT) {
+    if constexpr (HALO) {
+        // A image: halo rows j = 0 .. HR-1 hold pixels m0 - (W+1) + j (zeros where that is no pixel of the tensor), row HR
+        // (and the rest of the last 32-row pass) zeros; B tile behind it.  Both swizzled like the general stage.
+        const int HR = p.halo_rows, hoff = p.Wi + 1, q0 = m0 - hoff;
+        const uint32_t a_chunk = (uint32_t)((pos ^ (tid >> 4)) & 7) * 16u;  // (j >> 1) & 7 of row j = (tid >> 3) + 32 i: the same for every i
+        const uint32_t sAw = smem_lds + (uint32_t)(wave * (8 * 128));
+        const uint32_t sBw = sAw + (uint32_t)p.halo_a_bytes;
+        const int npass = p.halo_a_bytes >> 12;  // 32 rows x 128 B per pass
+        // (the chunk's byte offset rides in the per-lane offset, not the scalar one: the eight offsets are then no loop
+        // invariants the compiler would keep in registers across the K loop)
+        auto halo_issue = [&](uint32_t chunk_off) {
+            const uint32_t base = (uint32_t)(q0 + (tid >> 3)) * row_bytes + a_chunk + chunk_off;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i < npass) {
+                    const int j = (tid >> 3) + i * 32, q = q0 + j;
+                    const bool ok = j < HR && (unsigned)q < (unsigned)p.M;
+                    dma16(rx, sAw + i * 4096, ok ? base + (uint32_t)(i * 32) * row_bytes : kOOB, 0);
+                }
+            }
+        };
+        // which of the nine taps exist for this lane's fragment rows: bit (dy + 1) * 3 + (dx + 1)
+        int frag_row[TM];
+        unsigned tap_ok[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            frag_row[i] = wm * WTM + i * 32 + frow;
+            const int m = m0 + frag_row[i];
+            tap_ok[i] = 0;
+            if (m < p.M) {
+                const int n = fdiv(m, p.div_HoWo);
+                const int rem = m - n * p.HoWo;
+                const int oy = fdiv(rem, p.div_Wo);
+                const int ox = rem - oy * p.Wo;
+                const unsigned ym = (oy > 0 ? 1u : 0u) | 2u | (oy + 1 < p.Hi ? 4u : 0u);
+                const unsigned xm = (ox > 0 ? 1u : 0u) | 2u | (ox + 1 < p.Wi ? 4u : 0u);
+                tap_ok[i] = ((ym & 1u) ? xm : 0u) | ((ym & 2u) ? xm << 3 : 0u) | ((ym & 4u) ? xm << 6 : 0u);
+            }
+        }
+        uint32_t fbh[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fbh[j] = (uint32_t)p.halo_a_bytes + lds_off(wn * WTN + j * 32 + frow, fh);
+        const int kchunks = p.kchunks;
+#pragma unroll 1
+        for (int c = 0; c < kchunks; ++c) {
+#pragma unroll 1
+            for (int tt = 0; tt < 9; ++tt) {
+                if ((c | tt) != 0) __syncthreads();  // everyone is done reading what this step overwrites
+                if (tt == 0) halo_issue((uint32_t)c * 128u);
+                const uint32_t soff_b = (uint32_t)p.wtap[tt] * row_bytes + (uint32_t)c * 128u;
+#pragma unroll
+                for (int i = 0; i < BI; ++i) dma16(rw, sBw + i * (RPP * 128), b_off[i], soff_b);
+                const int ddy = p.dy[tt], ddx = p.dx[tt];
+                const int bit = (ddy + 1) * 3 + ddx + 1, shift = hoff + ddy * p.Wi + ddx;
+                uint32_t fah[TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fah[i] = lds_off(((tap_ok[i] >> bit) & 1u) ? frag_row[i] + shift : HR, fh);
+                dma_drain();
+                __syncthreads();
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    uint4 fa[TM], fb[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(smem + (fah[i] ^ (kk << 5)));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const uint4*>(smem + (fbh[j] ^ (kk << 5)));
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) mma_frag<T>(fa[i], fb[j], acc[i][j]);
+                }
+            }
+        }
+        __syncthreads();  // the epilogue re-uses the image
+    } else if constexpr (SPLIT) {
         if (is_loader) {
             dma_stage(0, 0, wtap_off);
             dma_drain();
@@ -469,7 +555,7 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
         static_assert(sizeof(T) == 2, "lean epilogue is for the 16-bit types");
         constexpr int CPR = BN / 8, RSTEP = NT / CPR, NPASS = BM / RSTEP;
         char* sC = smem;
-        float* sStat = reinterpret_cast<float*>(smem + MAIN_BYTES);  // [WM][BN][2]
+        float* sStat = reinterpret_cast<float*>(smem + (HALO ? p.halo_stat_off : MAIN_BYTES));  // [WM][BN][2]
         const uint32_t ones = ones2<T>();
         const int cc = tid % CPR, r0 = tid / CPR;
         const int ncol = n0 + cc * 8;
@@ -993,6 +1079,32 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
     }
 }
 
+constexpr int kHaloLdsMax = 40960;  // a quarter of a CU's LDS: the halo kernels keep 4 workgroups per CU
+
+// SM3_CONV_HALO (A/B switch, read at every launch): the halo-resident A image (kVarHalo) for the launches it fits:
+// nine taps at (-1..1, -1..1) over one tensor, stride 1, same geometry in and out, dense output and addend.
+// Default on: 3x3 forward 887 -> 967 (256 ch), 906 -> 1 004 (128 ch), 718 -> 802 (64 ch) TFLOP/s, data gradient + fused
+// BN-backward phase 1 +7 ... +14 %, whole step 4 321 -> 4 432 pairs/s (profiles/r04c_halo_ab.txt).  The sums are the same,
+// their order is not (chunk outer, tap inner): results agree with the general gather to one rounding of the 16-bit output.
+static int conv_halo_mode() {
+    const char* v = getenv("SM3_CONV_HALO");
+    return v ? atoi(v) : 1;
+}
+template <int BM, int BN>
+static bool conv_halo_ok(const ConvParams& p) {
+    if (!conv_halo_mode() || p.ntaps != 9 || p.x1 || p.sy != 1 || p.sx != 1 || p.add_sp_h) return false;
+    const bool dense = p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.HWout == p.HoWo;
+    if (!dense || p.Hi * p.Wi != p.HoWo || p.Wi != p.Wo) return false;
+    unsigned seen = 0;
+    for (int t = 0; t < 9; ++t) {
+        if (p.dy[t] < -1 || p.dy[t] > 1 || p.dx[t] < -1 || p.dx[t] > 1) return false;
+        seen |= 1u << ((p.dy[t] + 1) * 3 + p.dx[t] + 1);
+    }
+    if (seen != 0x1ffu) return false;
+    const int rows = BM + 2 * (p.Wi + 1) + 1;
+    return ((rows + 31) / 32) * 4096 + BN * 128 <= kHaloLdsMax;
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int STAGES, int EPI, bool SEG = false, int VAR = 0>
 int launch_conv_st(const ConvParams& p0, hipStream_t st) {
     constexpr bool SPLIT = (VAR & kVarSplit) != 0;
@@ -1005,8 +1117,20 @@ int launch_conv_st(const ConvParams& p0, hipStream_t st) {
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int C_BYTES = LEAN ? BM * (BN * 2 + 16) : (BM / WM) * (BN + 4) * 4;
     constexpr int MAIN = (STAGES * STAGE > C_BYTES) ? STAGES * STAGE : C_BYTES;
-    constexpr int LDS = MAIN + WM * BN * 2 * 4;
+    constexpr int STAT = WM * BN * 2 * 4;
+    constexpr int LDS_STATIC = MAIN + STAT;
     static_assert(MAIN >= 256 * 2 * 8 * 4, "reduction scratch of the fused BN-backward epilogue must fit");
+    int LDS = LDS_STATIC;
+    if constexpr ((VAR & kVarHalo) != 0) {
+        // halo image: 128 tile rows + (W + 1) either side + a zero row, in whole 32-row passes; the B tile behind it; the
+        // statistics scratch of the epilogue sits at the end (inside the by then dead image when that is the larger)
+        p.halo_rows = BM + 2 * (p.Wi + 1);
+        p.halo_a_bytes = ((p.halo_rows + 1 + 31) / 32) * 4096;
+        const int image = p.halo_a_bytes + BN * 128;
+        LDS = image > C_BYTES + STAT ? image : C_BYTES + STAT;
+        if (LDS > kHaloLdsMax) return SM3_EINVAL;  // (conv_halo_ok() is asked first)
+        p.halo_stat_off = LDS - STAT;
+    }
     p.tilesM = (p.M + BM - 1) / BM;
     p.tilesN = (p.Co + BN - 1) / BN;
     auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, STAGES, EPI, SEG, VAR>;
@@ -1015,8 +1139,8 @@ int launch_conv_st(const ConvParams& p0, hipStream_t st) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 31) dev = 0;
     if (!(attr_set.load(std::memory_order_acquire) & (1u << dev))) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (VAR & kVarHalo) ? kHaloLdsMax : LDS_STATIC);
         if (e != hipSuccess) return (int)e;
         attr_set.fetch_or(1u << dev, std::memory_order_release);
     }
@@ -1072,6 +1196,9 @@ static int conv_m16_mode() {
 // 16-bit lean epilogues on the 1- or 2-stage K loop
 template <typename T, int BM, int BN, int WM, int WN, int EPI, bool SEG>
 int launch_conv_lean(const ConvParams& p, hipStream_t st, bool single) {
+    if constexpr (!SEG && (EPI == 1 || EPI == 3) && WM * WN == 4) {
+        if (single && conv_halo_ok<BM, BN>(p)) return launch_conv_st<T, BM, BN, WM, WN, 1, EPI, false, kVarHalo>(p, st);
+    }
     const int mode = conv_pw_mode();
     const bool m16 = single && (conv_m16_mode() & 1);
     (void)m16;

@@ -268,6 +268,7 @@ def test_gather_gemm_variants_are_bit_identical(dtname, monkeypatch):
     for vname, env in _VARIANT_ENVS:
         for k_ in ("SM3_CONV_SINGLE_STAGE_MAX", "SM3_CONV_SPLIT", "SM3_CONV_W8", "SM3_CONV_PW", "SM3_CONV_LEAN"):
             monkeypatch.delenv(k_, raising=False)
+        monkeypatch.setenv("SM3_CONV_HALO", "0")  # same sums in ANOTHER order: test_halo_resident_3x3_... below
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
         outs = []
@@ -318,6 +319,82 @@ def test_gather_gemm_variants_are_bit_identical(dtname, monkeypatch):
         assert len(outs) == len(ref)
         for i, (a, b) in enumerate(zip(outs, ref)):
             assert torch.equal(a, b), (vname, i, float((a.double() - b.double()).abs().max()))
+
+
+@pytest.mark.parametrize("dtname", ["bf16", "f16"])
+def test_halo_resident_3x3_matches_the_general_gather(dtname, monkeypatch):
+    """The halo-resident A image of the stride-1 3x3 launches (kVarHalo: tile rows + W + 1 pixels either side staged once per
+    channel chunk, nine taps read it at a row shift, out-of-image taps read a zero row) against the general gather on the
+    same inputs: forward + BatchNorm partial sums, data gradient + fused BN-backward phase 1 with and without x.  Same
+    products, K-steps summed chunk-outer instead of tap-outer: one chunk (Ci = 64) must give the SAME BITS, more chunks at
+    most one rounding step of the stored 16-bit value on a handful of elements.  Geometries: every layer width of the
+    network, images that end inside a tile, M not a multiple of 128, H != W, an image smaller than the halo; the small-grid
+    4-stage kernel is switched off so that the variant under test is the one that runs."""
+    from sm3hip import ops
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16}[dtname]
+    code = ops.dtype_code(dt)
+    D = torch.device(DEV)
+    ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    monkeypatch.setenv("SM3_CONV_DEEP", "0")
+
+    def run(N, H, W, Ci, Co, seed):
+        gg = torch.Generator().manual_seed(seed)
+        d = ops.fwd_desc(code, N, H, W, Ci, Co, 3, 1, 1)
+        M = N * H * W
+        x = torch.randn(M, Ci, generator=gg).to(dt).to(D)
+        w = (torch.randn(Co, 9 * Ci, generator=gg) / math.sqrt(9 * Ci)).to(dt).to(D)
+        y = torch.empty(M, Co, dtype=dt, device=D)
+        part = torch.zeros(ops.conv_partial_rows(d) * 2 * Co, device=D)
+        ops.conv_gemm(d, x, w, y, None, part)
+        outs = [y, part]
+        descs, _ = ops.dgrad_descs(code, N, H, W, Ci, Co, 3, 1, 1)
+        dy = torch.randn(M, Co, generator=gg).to(dt).to(D)
+        wdg = (torch.randn(Ci, 9 * Co, generator=gg) / math.sqrt(9 * Co)).to(dt).to(D)
+        add = torch.randn(M, Ci, generator=gg).to(dt).to(D)
+        bnx = torch.randn(M, Ci, generator=gg).to(dt).to(D)
+        msk = torch.randint(0, 256, (M * Ci // 8,), generator=gg, dtype=torch.uint8).to(D)
+        mean, istd = torch.randn(Ci, generator=gg).to(D), (torch.rand(Ci, generator=gg) + 0.5).to(D)
+        for with_x in (True, False):
+            dz = torch.empty(M, Ci, dtype=dt, device=D)
+            fp = torch.zeros(sum(ops.conv_partial_rows(dd) for dd in descs) * 2 * Ci, device=D)
+            off = 0
+            for dd in descs:
+                off += ops.conv_dgrad_bnfuse(dd, dy, wdg, dz, add, msk, bnx if with_x else None, mean, istd, fp, off)
+            outs += [dz, fp]
+        torch.cuda.synchronize()
+        return outs
+
+    cases = [(3, 14, 14, 256, 256), (2, 28, 28, 128, 128), (2, 56, 56, 64, 64), (5, 7, 7, 512, 512), (3, 10, 14, 128, 256),
+             (1, 3, 5, 64, 64), (40, 14, 14, 256, 256)]
+    for ci_, c in enumerate(cases):
+        monkeypatch.setenv("SM3_CONV_HALO", "0")
+        a = run(*c, seed=5 + ci_)
+        monkeypatch.setenv("SM3_CONV_HALO", "1")
+        b = run(*c, seed=5 + ci_)
+        for i, (u, v) in enumerate(zip(a, b)):
+            what = (c, ["y", "partials", "dz(x)", "fz partials(x)", "dz", "fz partials"][i])
+            if c[3] == 64:
+                assert torch.equal(u, v), what
+                continue
+            u, v = u.double(), v.double()
+            if i % 2 == 0:  # stored 16-bit tensors: one rounding step of the larger magnitude, on few elements
+                assert bool(((u - v).abs() <= 2 * ulp * torch.maximum(u.abs(), v.abs()) + 1e-30).all()), what
+                assert float((u != v).double().mean()) < 2e-3, what
+            else:           # f32 sums of those tensors over 128 rows
+                assert float((u - v).abs().max()) <= 2e-3 * (float(u.abs().max()) + 1e-6), what
+    # the variant must be the one the step uses: a forward 3x3 of the network at size, both forms against fp64
+    N, H, Ci = 8, 14, 256
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, Ci, H, H, generator=g).to(dt)
+    w = (torch.randn(Ci, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci)).to(dt)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, Ci)
+    d = ops.fwd_desc(code, N, H, H, Ci, Ci, 3, 1, 1)
+    xd = x.permute(0, 2, 3, 1).contiguous().reshape(-1, Ci).to(D)
+    wd = w.permute(0, 2, 3, 1).contiguous().reshape(Ci, -1).to(D)
+    y = torch.empty(N * H * H, Ci, dtype=dt, device=D)
+    ops.conv_gemm(d, xd, wd, y, None, None)
+    torch.cuda.synchronize()
+    assert float((y.cpu().double() - ref).abs().max()) < 4 * ulp * float(ref.abs().max())
 
 
 def _fwd_index(i, cases):
