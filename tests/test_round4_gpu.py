@@ -327,7 +327,7 @@ def test_halo_resident_3x3_matches_the_general_gather(dtname, monkeypatch):
     channel chunk, nine taps read it at a row shift, out-of-image taps read a zero row) against the general gather on the
     same inputs: forward + BatchNorm partial sums, data gradient + fused BN-backward phase 1 with and without x.  Same
     products, K-steps summed chunk-outer instead of tap-outer: one chunk (Ci = 64) must give the SAME BITS, more chunks at
-    most one rounding step of the stored 16-bit value on a handful of elements.  Geometries: every layer width of the
+    most one rounding step of the 16-bit GEMM result on a handful of elements.  Geometries: every layer width of the
     network, images that end inside a tile, M not a multiple of 128, H != W, an image smaller than the halo; the small-grid
     4-stage kernel is switched off so that the variant under test is the one that runs."""
     from sm3hip import ops
@@ -378,8 +378,11 @@ def test_halo_resident_3x3_matches_the_general_gather(dtname, monkeypatch):
                 continue
             u, v = u.double(), v.double()
             if i % 2 == 0:  # stored 16-bit tensors: one rounding step of the larger magnitude, on few elements
-                assert bool(((u - v).abs() <= 2 * ulp * torch.maximum(u.abs(), v.abs()) + 1e-30).all()), what
-                assert float((u != v).double().mean()) < 2e-3, what
+                # (of the GEMM result, that is: the data gradient adds its addend AFTER that rounding, so the step is measured
+                # on the tensor's scale, not on the element's own)
+                assert float((u - v).abs().max()) <= 2 * ulp * float(u.abs().max()), (what, float((u - v).abs().max()))
+                # (f16 rounds 8x finer than bf16, so the same f32 ordering noise crosses a rounding boundary 8x as often)
+                assert float((u != v).double().mean()) < (2e-3 if dt == torch.bfloat16 else 2e-2), (what, float((u != v).double().mean()))
             else:           # f32 sums of those tensors over 128 rows
                 assert float((u - v).abs().max()) <= 2e-3 * (float(u.abs().max()) + 1e-6), what
     # the variant must be the one the step uses: a forward 3x3 of the network at size, both forms against fp64
