@@ -455,14 +455,57 @@ __global__ __launch_bounds__(256) void weight_prep_batch_kernel(const sm3_wprep_
     T* __restrict__ wf = reinterpret_cast<T*>(it.w_fwd);
     T* __restrict__ wd = reinterpret_cast<T*>(it.w_dgrad);
     const int Co = it.Co, taps = it.taps, Ci = it.Ci, ld = it.ld_fwd, K = taps * Ci;
-    if (wf) {
+    // 16-bit banks of the usual shapes (no row padding, K a multiple of 4, Co even): 16-byte reads / 8-byte writes for the
+    // forward copy, and the transpose through 64 x 32 tiles whose writes are PAIRS of output channels (128 B per half-wave
+    // instead of 64) -- the element-wise forms ran at 0.85 TB/s, 0.66 ms per step for the model's 47 M weights
+    const bool vec = sizeof(T) == 2 && ld == K && (K & 3) == 0 && (Co & 1) == 0 && ((uintptr_t)w & 15) == 0 &&
+                     ((uintptr_t)wf & 7) == 0 && ((uintptr_t)wd & 3) == 0;
+    if (wf && vec) {
+        const int64_t nq = (int64_t)Co * K / 4;
+        const float4* __restrict__ w4 = reinterpret_cast<const float4*>(w);
+        uint2* __restrict__ o2 = reinterpret_cast<uint2*>(wf);
+        for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+            const float4 v = w4[q];
+            uint2 o;
+            if constexpr (sizeof(T) == 2) {
+                o.x = pack2<T>(v.x, v.y);
+                o.y = pack2<T>(v.z, v.w);
+            }
+            o2[q] = o;
+        }
+    } else if (wf) {
         const int64_t nf = (int64_t)Co * ld;
         for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nf; idx += (int64_t)gridDim.x * blockDim.x) {
             const int co = (int)(idx / ld), k = (int)(idx % ld);
             store_elem<T>(wf + idx, k < K ? w[(int64_t)co * K + k] : 0.f);
         }
     }
-    if (wd) {
+    if (wd && vec) {
+        __shared__ float tile2[64][33];
+        const int tco = (Co + 63) / 64, tci = (Ci + 31) / 32;
+        const int ntiles = taps * tco * tci;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+        for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+            const int t = tl / (tco * tci), r = tl - t * tco * tci;
+            const int co0 = (r / tci) * 64, ci0 = (r % tci) * 32;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {  // rows co0 + ty + 8j, columns ci0 + tx (128 B along ci per half-wave)
+                const int co = co0 + ty + 8 * j, ci = ci0 + tx;
+                tile2[ty + 8 * j][tx] = (co < Co && ci < Ci) ? w[((int64_t)co * taps + t) * Ci + ci] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // rows ci0 + ty + 8j, channel pair co0 + 2 tx, + 1 (128 B along co per half-wave)
+                const int ci = ci0 + ty + 8 * j, co = co0 + 2 * tx;
+                if constexpr (sizeof(T) == 2) {
+                    if (ci < Ci && co < Co)
+                        *reinterpret_cast<uint32_t*>(wd + ((int64_t)ci * taps + t) * Co + co) =
+                            pack2<T>(tile2[2 * tx][ty + 8 * j], tile2[2 * tx + 1][ty + 8 * j]);
+                }
+            }
+            __syncthreads();
+        }
+    } else if (wd) {
         const int tco = (Co + 31) / 32, tci = (Ci + 31) / 32;
         const int ntiles = taps * tco * tci;
         const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8

@@ -400,6 +400,40 @@ def test_halo_resident_3x3_matches_the_general_gather(dtname, monkeypatch):
     assert float((y.cpu().double() - ref).abs().max()) < 4 * ulp * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("dtname", ["bf16", "f16", "f32"])
+def test_batched_weight_prep_equals_the_single_bank_kernel(dtname):
+    """sm3_weight_prep_batch (all filter banks of a lane in one launch; 16-byte reads / packed writes and a 64 x 32 paired
+    transpose for the 16-bit banks) against sm3_weight_prep bank by bank: same bits in the forward copy and in the transposed
+    data-gradient bank, on every bank family of the model plus shapes the vector path must refuse (row padding, odd Co, a
+    master that is not 16-byte aligned, Ci not a multiple of 32)."""
+    from sm3hip import ops
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[dtname]
+    code = ops.dtype_code(dt)
+    D = torch.device(DEV)
+    g = torch.Generator().manual_seed(9)
+    # Co, taps, Ci, ld - K, element offset of the master inside its buffer
+    shapes = [(64, 9, 64, 0, 0), (256, 1, 64, 0, 0), (512, 9, 512, 0, 0), (2048, 1, 512, 0, 0), (2048, 1, 2048, 0, 0),
+              (128, 1, 2048, 0, 0), (64, 1, 147, 13, 0), (66, 9, 64, 0, 0), (33, 1, 64, 0, 0), (64, 1, 48, 0, 0), (128, 9, 128, 0, 3)]
+    items, singles = [], []
+    for Co, taps, Ci, pad, off in shapes:
+        K = taps * Ci
+        buf = torch.randn(Co * K + off, generator=g).to(D)
+        w = buf[off:].view(Co, K)
+        wf, wd = torch.zeros(Co, K + pad, dtype=dt, device=D), torch.zeros(Ci * taps * Co, dtype=dt, device=D)
+        wf1, wd1 = torch.full_like(wf, 7.0), torch.full_like(wd, 7.0)
+        items.append((w, wf, wd, Co, taps, Ci, K + pad))
+        ops.weight_prep(code, w, Co, taps, Ci, wf1, K + pad, wd1)
+        singles.append((wf1, wd1, w))
+    table = ops.weight_prep_table(items, D)
+    ops.weight_prep_batch(code, table)
+    torch.cuda.synchronize()
+    for (w, wf, wd, Co, taps, Ci, ld), (wf1, wd1, _) in zip(items, singles):
+        assert torch.equal(wf, wf1), ("forward bank", Co, taps, Ci, ld)
+        assert torch.equal(wd, wd1), ("data-gradient bank", Co, taps, Ci, ld)
+        ref = w.view(Co, taps, Ci).permute(2, 1, 0).contiguous().to(dt).reshape(-1)   # wd[ci][t][co] = w[co][t][ci]
+        assert torch.equal(wd, ref), ("transpose", Co, taps, Ci)
+
+
 def _fwd_index(i, cases):
     """Position of case i's plain forward output in the flat result list of the full variants."""
     pos = 0
