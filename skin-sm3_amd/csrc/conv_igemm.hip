@@ -346,8 +346,8 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
         }
     };
     if constexpr (HALO) {
-        // A image: halo rows j = 0 .. HR-1 hold pixels m0 - (W+1) + j (zeros where that is no pixel of the tensor), row HR
-        // (and the rest of the last 32-row pass) zeros; B tile behind it.  Both swizzled like the general stage.
+        // A image: halo rows j = 0 .. HR-1 hold pixels m0 - (W+1) + j (zeros where that is no pixel of the tensor), rows HR,
+        // HR + 1 (and the rest of the last 32-row pass) zeros; B tile behind it.  Both swizzled like the general stage.
         const int HR = p.halo_rows, hoff = p.Wi + 1, q0 = m0 - hoff;
         const uint32_t a_chunk = (uint32_t)((pos ^ (tid >> 4)) & 7) * 16u;  // (j >> 1) & 7 of row j = (tid >> 3) + 32 i: the same for every i
         const uint32_t sAw = smem_lds + (uint32_t)(wave * (8 * 128));
@@ -401,7 +401,13 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
                 const int bit = (ddy + 1) * 3 + ddx + 1, shift = hoff + ddy * p.Wi + ddx;
                 uint32_t fah[TM];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fah[i] = lds_off(((tap_ok[i] >> bit) & 1u) ? frag_row[i] + shift : HR, fh);
+                for (int i = 0; i < TM; ++i) {
+                    // a tap outside the image reads zeros AT THE BANKS its own row would have used (rows HR, HR + 1 are one
+                    // 256-byte bank row of zeros): the 16 lanes of a read group stay on 16 distinct slots (all redirected
+                    // lanes on ONE slot of row HR cost a 2-way conflict per group: 20 % LDS conflict cycles measured)
+                    const uint32_t own = lds_off(frag_row[i] + shift, fh);
+                    fah[i] = ((tap_ok[i] >> bit) & 1u) ? own : (uint32_t)HR * 128u + (own & 255u);
+                }
                 dma_drain();
                 __syncthreads();
 #pragma unroll
@@ -1101,7 +1107,7 @@ static bool conv_halo_ok(const ConvParams& p) {
         seen |= 1u << ((p.dy[t] + 1) * 3 + p.dx[t] + 1);
     }
     if (seen != 0x1ffu) return false;
-    const int rows = BM + 2 * (p.Wi + 1) + 1;
+    const int rows = BM + 2 * (p.Wi + 1) + 2;
     return ((rows + 31) / 32) * 4096 + BN * 128 <= kHaloLdsMax;
 }
 
@@ -1125,7 +1131,7 @@ int launch_conv_st(const ConvParams& p0, hipStream_t st) {
         // halo image: 128 tile rows + (W + 1) either side + a zero row, in whole 32-row passes; the B tile behind it; the
         // statistics scratch of the epilogue sits at the end (inside the by then dead image when that is the larger)
         p.halo_rows = BM + 2 * (p.Wi + 1);
-        p.halo_a_bytes = ((p.halo_rows + 1 + 31) / 32) * 4096;
+        p.halo_a_bytes = ((p.halo_rows + 2 + 31) / 32) * 4096;  // + two zero rows (one 256-byte bank row)
         const int image = p.halo_a_bytes + BN * 128;
         LDS = image > C_BYTES + STAT ? image : C_BYTES + STAT;
         if (LDS > kHaloLdsMax) return SM3_EINVAL;  // (conv_halo_ok() is asked first)
