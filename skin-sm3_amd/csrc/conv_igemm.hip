@@ -388,11 +388,21 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
 #pragma unroll
         for (int j = 0; j < TN; ++j) fbh[j] = (uint32_t)p.halo_a_bytes + lds_off(wn * WTN + j * 32 + frow, fh);
         const int kchunks = p.kchunks;
+#ifdef SM3_STAMP
+        stamp.mark[1] = stamp.t_loop0 = SM3_STAMP_NOW();
+        stamp.nsteps = 9 * kchunks;
+#endif
 #pragma unroll 1
         for (int c = 0; c < kchunks; ++c) {
 #pragma unroll 1
             for (int tt = 0; tt < 9; ++tt) {
+#ifdef SM3_STAMP
+                const unsigned long long q0 = SM3_STAMP_NOW();
+#endif
                 if ((c | tt) != 0) __syncthreads();  // everyone is done reading what this step overwrites
+#ifdef SM3_STAMP
+                const unsigned long long q1 = SM3_STAMP_NOW();
+#endif
                 if (tt == 0) halo_issue((uint32_t)c * 128u);
                 const uint32_t soff_b = (uint32_t)p.wtap[tt] * row_bytes + (uint32_t)c * 128u;
 #pragma unroll
@@ -408,8 +418,17 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
                     const uint32_t own = lds_off(frag_row[i] + shift, fh);
                     fah[i] = ((tap_ok[i] >> bit) & 1u) ? own : (uint32_t)HR * 128u + (own & 255u);
                 }
+#ifdef SM3_STAMP
+                const unsigned long long q2 = SM3_STAMP_NOW();
+#endif
                 dma_drain();
+#ifdef SM3_STAMP
+                const unsigned long long q3 = SM3_STAMP_NOW();
+#endif
                 __syncthreads();
+#ifdef SM3_STAMP
+                const unsigned long long q4 = SM3_STAMP_NOW();
+#endif
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     uint4 fa[TM], fb[TN];
@@ -422,8 +441,15 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
 #pragma unroll
                         for (int j = 0; j < TN; ++j) mma_frag<T>(fa[i], fb[j], acc[i][j]);
                 }
+#ifdef SM3_STAMP
+                const unsigned long long q5 = SM3_STAMP_NOW();
+                stamp.seg[0] += q2 - q1; stamp.seg[1] += q5 - q4; stamp.seg[2] += q3 - q2; stamp.seg[3] += (q1 - q0) + (q4 - q3);
+#endif
             }
         }
+#ifdef SM3_STAMP
+        stamp.t_loop1 = SM3_STAMP_NOW();
+#endif
         __syncthreads();  // the epilogue re-uses the image
     } else if constexpr (SPLIT) {
         if (is_loader) {
