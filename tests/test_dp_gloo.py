@@ -188,6 +188,24 @@ def _kmeans_cpu(emb, K, iters=10, generator=None):
     return c.float(), a
 
 
+def test_kmeans_restatement_reproduces_the_reference_function(golden_dir):
+    """The CPU restatement above against the REFERENCE'S OWN `cluster_memory` (tools/mlc_train.py:116-189, run on CPU by
+    oracle/gen_kmeans_golden.py, tests/golden/mlc_kmeans_ref.npz): same initial centroids from the same seed, same assignment
+    of every memory index, same centroids -- so the restatement the gloo and GPU tests lean on is pinned, not asserted."""
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, "mlc_kmeans_ref.npz"))
+    ncases = len([k for k in g.files if k.endswith("_meta")])
+    assert ncases == 4
+    for ci in range(ncases):
+        N, D, K, kseed = [int(v) for v in g[f"c{ci}_meta"]]
+        emb, index = torch.from_numpy(g[f"c{ci}_emb"]), torch.from_numpy(g[f"c{ci}_index"])
+        cent, a = _kmeans_cpu(emb, K, generator=torch.Generator().manual_seed(kseed))
+        assign = torch.full((N,), -100, dtype=torch.long)
+        assign[index] = a                                   # mlc_train.py:181: logged by memory index
+        assert torch.equal(assign, torch.from_numpy(g[f"c{ci}_assign"])), ci
+        assert float((cent - torch.from_numpy(g[f"c{ci}_centroids"])).abs().max()) < 2e-6, ci
+
+
 def _cluster_rank(rank, world):
     """tools/mlc_train.py:136-143,185-186 under data parallelism: every rank holds a shard of the memory bank; rank 0
     gathers it, clusters, and broadcasts centroids + assignments."""

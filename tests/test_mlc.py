@@ -131,6 +131,34 @@ def test_spherical_kmeans_matches_the_reference_algorithm():
     assert len(set(assign.cpu().tolist())) == K
 
 
+def test_cluster_memory_reproduces_the_reference_function(golden_dir):
+    """The tool's `cluster_memory` (HIP k-means kernels, prototype update) against the REFERENCE'S OWN function run on CPU
+    (tools/mlc_train.py:116-189 -> oracle/gen_kmeans_golden.py -> tests/golden/mlc_kmeans_ref.npz): four memory banks (413
+    cases x 512 / 256 / 128 dimensions, 96 x 128; 5 / 3 / 2 / 3 clusters, one with heavily overlapping clusters), the k-means
+    seed the reference drew its initial centroids with.  Every memory index gets the reference's assignment; the centroids
+    copied into the prototype layer agree to fp32 rounding."""
+    import importlib.util
+    import os
+    import types
+    import numpy as np
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "skin-sm3_amd", "tools")
+    spec = importlib.util.spec_from_file_location("sm3_mlc_train", os.path.join(tools, "mlc_train.py"))
+    mt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mt)
+    g = np.load(os.path.join(golden_dir, "mlc_kmeans_ref.npz"))
+    for ci in range(4):
+        N, D, K, kseed = [int(v) for v in g[f"c{ci}_meta"]]
+        emb = torch.from_numpy(g[f"c{ci}_emb"]).to(DEV)
+        index = torch.from_numpy(g[f"c{ci}_index"]).to(DEV)
+        proto = nn.Linear(D, K, bias=False).to(DEV)
+        args = types.SimpleNamespace(world_size=1, rank=0)
+        with torch.no_grad():
+            assign = mt.cluster_memory(args, proto, K, index, emb, generator=torch.Generator().manual_seed(kseed))
+        torch.cuda.synchronize()
+        assert torch.equal(assign.cpu(), torch.from_numpy(g[f"c{ci}_assign"])), ci
+        assert float((proto.weight.detach().cpu() - torch.from_numpy(g[f"c{ci}_centroids"])).abs().max()) < 5e-6, ci
+
+
 def test_mlc_train_tool_runs_and_learns(tmp_path):
     """tools/mlc_train.py end to end on synthetic data: frozen HIP extractor (eval mode), memory bank, per-epoch spherical
     k-means, pseudo-label training of the heads.  Every epoch's loss is finite, the heads move between the first and the last
