@@ -400,10 +400,16 @@ int sm3_ntxent_logits(const float* z, int R, int D, float temperature, float* zn
 /* d(loss)/dz from d(loss)/dlogits (reference layout), written as dtype */
 int sm3_ntxent_logits_bwd(int dtype, const float* dlogits, const float* zn, const float* inv_norm, int R,
                           int D, float temperature, void* dz, void* stream);
-/* mean cross-entropy against label 0 of logits [R][Cc]; loss[0] += weight*CE; dlogits = weight*grad */
-int sm3_ce_label0(const float* logits, int R, int Cc, float weight, float* loss, float* dlogits, void* stream);
+/* Every loss entry point below adds ONE value per call to loss[0]: the per-row terms are written to a buffer and summed
+ * in a fixed order (fp64, one workgroup) -- like the reference's single CrossEntropyLoss reduction over a materialised
+ * logits tensor (tools/backbone_train.py:531), the loss is a function of its inputs bit for bit (no float atomics).
+ * The calls that accumulate into the same loss[0] must be enqueued on one stream. */
+/* mean cross-entropy against label 0 of logits [R][Cc]; loss[0] += weight*CE; dlogits = weight*grad.
+ * row_terms: R floats of scratch (required when loss is given). */
+int sm3_ce_label0(const float* logits, int R, int Cc, float weight, float* row_terms, float* loss, float* dlogits,
+                  void* stream);
 /* fused: loss[0] += weight * NTXent(z); dz = weight * dNTXent/dz (dtype); never materialises logits.
- * workspace: R*D + 2*R floats (normalised rows, inverse norms, per-row logsumexp). */
+ * workspace: R*D + 3*R floats (normalised rows, inverse norms, per-row logsumexp, per-row loss terms). */
 int sm3_ntxent_fused(int dtype, const float* z, int R, int D, float temperature, float weight,
                      float* workspace, float* loss, void* dz, void* stream);
 
@@ -422,7 +428,7 @@ int sm3_ntxent_fused_scaled(int dtype, const float* z, int R, int D, float tempe
  *   v = dzn_a + dzn_b (dzn_b nullable). */
 int sm3_normalize_rows(const float* z, int R, int D, float* zn, float* inv_norm, void* stream);
 int sm3_ntxent_rect(float* S, int Rl, int Rg, int self_offset, float temperature, float weight, const float* dz_scale,
-                    float* loss, void* stream);
+                    float* row_terms /* Rl floats of scratch */, float* loss, void* stream);
 int sm3_normalize_rows_bwd(int dtype, const float* dzn_a, const float* dzn_b, const float* zn, const float* inv_norm,
                            int R, int D, void* dz, void* stream);
 
@@ -540,6 +546,13 @@ int sm3_mlc_kmeans_update(float* centroids, const float* sums, const int* counts
  * (also forced by SM3_P2P_FINEGRAINED=0, for an A/B of the two). */
 int sm3_p2p_mailbox_bytes(void);
 int sm3_p2p_max_elems(void);
+/* largest world size a mailbox has room for (8: one node), and the byte layout of a mailbox -- the data area
+ * [data_first, data_first + data_bytes) source rank `src` writes for exchange slot `slot` (0 / 1) and the 8-byte arrival
+ * flag of its block `block` (elems_per_block doubles each) -- so that a host-side check can prove, without a GPU, that the
+ * areas of max_world ranks x 2 slots x every block are disjoint and inside sm3_p2p_mailbox_bytes(). */
+int sm3_p2p_max_world(void);
+int sm3_p2p_layout(int slot, int src, int block, int64_t* data_first, int64_t* data_bytes, int64_t* flag_off,
+                   int* elems_per_block);
 int sm3_p2p_alloc(void** ptr, void* ipc_handle_64, int* kind_out);
 int sm3_p2p_open(const void* ipc_handle_64, void** ptr);
 int sm3_p2p_close(void* ptr);

@@ -193,6 +193,22 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Fixed-order sum of n fp32 terms by ONE 256-thread workgroup (every thread must call it): thread t adds terms t, t + 256, ...
+// in fp64, the 64 lanes of a wave fold by the xor butterfly, the four wave sums are added in wave order.  The result is a
+// function of the terms alone -- no atomics, no arrival order.  `sh4` = 4 doubles of LDS.  (The reference's loss is one
+// fixed-order reduction as well: nn.CrossEntropyLoss over a materialised logits tensor, tools/backbone_train.py:531.)
+__device__ __forceinline__ double block256_ordered_sum(const float* __restrict__ terms, int n, double* sh4) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) a += (double)terms[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = a;
+    __syncthreads();
+    const double s = ((sh4[0] + sh4[1]) + sh4[2]) + sh4[3];
+    __syncthreads();
+    return s;
+}
+
 // expands CALL(T) for the element type of `dtype`; returns SM3_EDTYPE for anything else
 #define SM3_DISPATCH_DTYPE(dtype, CALL)          \
     do {                                         \

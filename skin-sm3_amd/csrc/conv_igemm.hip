@@ -337,6 +337,17 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
     int kch = (SEG && cur_src) ? p.kchunks1 : p.kchunks;  // K-steps of the current tap
     uint32_t wtap_off = (uint32_t)p.wtap[0] * ((SEG && cur_src) ? row_bytes1 : row_bytes);
     auto advance = [&]() {
+        if constexpr (!SEG && !PW && !HALO && sizeof(T) == 2 && EPI >= 1) {
+            if (p.kord) {  // chunk outer, tap inner: the summation order of kVarHalo (ConvParams::kord)
+                if (++t == p.ntaps) {
+                    t = 0;
+                    ++kc;
+                }
+                set_tap(t);
+                wtap_off = (uint32_t)p.wtap[t] * row_bytes;
+                return;
+            }
+        }
         if (++kc == kch) {
             kc = 0;
             ++t;
@@ -1122,8 +1133,8 @@ static int conv_halo_mode() {
     const char* v = getenv("SM3_CONV_HALO");
     return v ? atoi(v) : 1;
 }
-template <int BM, int BN>
-static bool conv_halo_ok(const ConvParams& p) {
+// the launches whose K order is "chunk outer, tap inner" (ConvParams::kord): a property of the LAYER, never of the grid
+static bool conv_halo_geometry(const ConvParams& p) {
     if (!conv_halo_mode() || p.ntaps != 9 || p.x1 || p.sy != 1 || p.sx != 1 || p.add_sp_h) return false;
     const bool dense = p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.HWout == p.HoWo;
     if (!dense || p.Hi * p.Wi != p.HoWo || p.Wi != p.Wo) return false;
@@ -1132,7 +1143,12 @@ static bool conv_halo_ok(const ConvParams& p) {
         if (p.dy[t] < -1 || p.dy[t] > 1 || p.dx[t] < -1 || p.dx[t] > 1) return false;
         seen |= 1u << ((p.dy[t] + 1) * 3 + p.dx[t] + 1);
     }
-    if (seen != 0x1ffu) return false;
+    return seen == 0x1ffu;
+}
+// ... and of those the ones whose A image fits a quarter of a CU's LDS run on the halo kernel itself
+template <int BM, int BN>
+static bool conv_halo_ok(const ConvParams& p) {
+    if (!p.kord) return false;
     const int rows = BM + 2 * (p.Wi + 1) + 2;
     return ((rows + 31) / 32) * 4096 + BN * 128 <= kHaloLdsMax;
 }
@@ -1269,7 +1285,9 @@ int launch_conv_epi(const ConvParams& p, hipStream_t st, bool single, bool deep)
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
-int launch_conv(const ConvParams& p, hipStream_t st) {
+int launch_conv(const ConvParams& p_in, hipStream_t st) {
+    ConvParams p = p_in;
+    p.kord = 0;
     // K-steps up to which the ONE-stage loop runs (34 KB of LDS, 4 workgroups per CU overlapping each other) instead of the
     // double-buffered one (66 KB, 2 per CU).  Rounds 1-3 drew the line at 8 K-steps; with the lean / pointwise epilogues the
     // one-stage loop wins at EVERY length measured (profiles/r04a_stage_choice_*: 3x3 256->256, 36 K-steps, 847 -> 950
@@ -1297,6 +1315,9 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         if (lean) {
             const bool dense = p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.HWout == p.HoWo;
+            // 16-bit stride-1 3 x 3 launches sum chunk outer, tap inner in whichever kernel and with whichever epilogue the
+            // tests below pick (the K order is a property of the layer, not of the grid)
+            p.kord = conv_halo_geometry(p) ? 1 : 0;
             if (p.fz_partials) return launch_conv_epi<T, BM, BN, WM, WN, 3>(p, st, single, deep);  // data gradient + BN-backward phase 1
             // per-row work on the read-back: an addend, ReLU bits, per-view affine, a strided output
             if (p.addend || p.ep_mask || !dense || (p.ep_scale && p.fz_view_tiles))

@@ -241,25 +241,35 @@ __global__ __launch_bounds__(256) void mlc_colsum_kernel(const float* __restrict
 }
 
 // ---- pseudo-label cross-entropy over the heads (mlc_train.py:252-261): loss = mean_h mean_b CE(logits_h / T, target_h) ----
-// logits [B][Tn] (head h owns columns off[h] .. off[h+1]); targets [H][B] int64; one thread per (b, h)
+// logits [B][Tn] (head h owns columns off[h] .. off[h+1]); targets [H][B] int64.  ONE workgroup: thread t owns the
+// (b, h) pairs t, t + 256, ... (B * H is a few thousand five-class rows), adds their terms in fp64 in that order, and the
+// workgroup folds the 256 partial sums in a fixed order -- the loss is a function of the logits bit for bit, as the
+// reference's mean over per-head CrossEntropyLoss values is (no float atomics).
 __global__ __launch_bounds__(256) void mlc_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets,
                                                      const int* __restrict__ off, int H, int B, int Tn, float inv_t,
                                                      float* __restrict__ loss, float* __restrict__ dlogits) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * H) return;
-    const int b = i / H, h = i - b * H;
-    const int c0 = off[h], c1 = off[h + 1];
-    const float* row = logits + (int64_t)b * Tn;
-    float m = -INFINITY;
-    for (int c = c0; c < c1; ++c) m = fmaxf(m, row[c] * inv_t);
-    float se = 0.f;
-    for (int c = c0; c < c1; ++c) se += __expf(row[c] * inv_t - m);
-    const float lse = m + __logf(se);
-    const int t = (int)targets[(int64_t)h * B + b];
+    __shared__ double sh4[4];
     const float k = 1.f / ((float)B * (float)H);
-    atomicAdd(loss, k * (lse - row[c0 + t] * inv_t));
-    for (int c = c0; c < c1; ++c)
-        dlogits[(int64_t)b * Tn + c] = k * inv_t * (__expf(row[c] * inv_t - lse) - (c == c0 + t ? 1.f : 0.f));
+    double a = 0.0;
+    for (int i = threadIdx.x; i < B * H; i += 256) {
+        const int b = i / H, h = i - b * H;
+        const int c0 = off[h], c1 = off[h + 1];
+        const float* row = logits + (int64_t)b * Tn;
+        float m = -INFINITY;
+        for (int c = c0; c < c1; ++c) m = fmaxf(m, row[c] * inv_t);
+        float se = 0.f;
+        for (int c = c0; c < c1; ++c) se += __expf(row[c] * inv_t - m);
+        const float lse = m + __logf(se);
+        const int t = (int)targets[(int64_t)h * B + b];
+        a += (double)(k * (lse - row[c0 + t] * inv_t));
+        for (int c = c0; c < c1; ++c)
+            dlogits[(int64_t)b * Tn + c] = k * inv_t * (__expf(row[c] * inv_t - lse) - (c == c0 + t ? 1.f : 0.f));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) *loss += (float)(((sh4[0] + sh4[1]) + sh4[2]) + sh4[3]);
 }
 
 // ---- prototype heads backward: out[b][t] = <xn[b][tok(t)], W[t]> (+bias), xn = x or x/|x| ------------------------------
@@ -474,7 +484,7 @@ extern "C" int sm3_mlc_colsum(const float* dy, float* db, int64_t rows, int N, v
 extern "C" int sm3_mlc_ce(const float* logits, const int64_t* targets, const int* head_offsets, int H, int B, int Tn,
                           float temperature, float* loss, float* dlogits, void* stream) {
     if (!logits || !targets || !head_offsets || !loss || !dlogits || H <= 0 || B <= 0 || Tn <= 0 || temperature <= 0) return SM3_EINVAL;
-    hipLaunchKernelGGL(mlc_ce_kernel, dim3((B * H + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, targets, head_offsets,
+    hipLaunchKernelGGL(mlc_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, targets, head_offsets,
                        H, B, Tn, 1.f / temperature, loss, dlogits);
     SM3_CHECK_LAUNCH();
     return 0;

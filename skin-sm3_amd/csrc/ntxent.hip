@@ -19,6 +19,16 @@ __device__ __forceinline__ void store_out<bf16_t>(bf16_t* p, float v) { p->v = f
 template <>
 __device__ __forceinline__ void store_out<f16_t>(f16_t* p, float v) { p->v = f32_to_f16(v); }
 
+// *loss += the fixed-order sum of the per-row loss terms of one NT-Xent / cross-entropy call (one workgroup): the loss of a
+// step is then a function of the parameters bit for bit, like the reference's single CrossEntropyLoss reduction
+// (tools/backbone_train.py:101-102,119-121,531).  The calls of a step are enqueued on ONE stream, so the plain
+// read-modify-write of *loss happens in program order.
+__global__ __launch_bounds__(256) void ordered_loss_add_kernel(const float* __restrict__ terms, int n, float* __restrict__ loss) {
+    __shared__ double sh4[4];
+    const double s = block256_ordered_sum(terms, n, sh4);
+    if (threadIdx.x == 0) *loss += (float)s;
+}
+
 // one wave per row: zn = z / max(||z||, 1e-12)
 __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ z, int R, int D,
                                                              float* __restrict__ zn, float* __restrict__ inv_norm) {
@@ -117,7 +127,7 @@ __global__ __launch_bounds__(256) void logits_bwd_kernel(const float* __restrict
 
 // cross entropy against label 0, one workgroup per row
 __global__ __launch_bounds__(256) void ce_label0_kernel(const float* __restrict__ logits, int R, int Cc, float weight,
-                                                        float* __restrict__ loss, float* __restrict__ dlogits) {
+                                                        float* __restrict__ row_terms, float* __restrict__ dlogits) {
     __shared__ float red[8];
     const float* row = logits + (int64_t)blockIdx.x * Cc;
     float mx = -INFINITY;
@@ -133,7 +143,7 @@ __global__ __launch_bounds__(256) void ce_label0_kernel(const float* __restrict_
     __syncthreads();
     s = red[4] + red[5] + red[6] + red[7];
     const float lse = mx + __logf(s);
-    if (threadIdx.x == 0 && loss) atomicAdd(loss, weight * (lse - row[0]) / (float)R);
+    if (threadIdx.x == 0 && row_terms) row_terms[blockIdx.x] = weight * (lse - row[0]) / (float)R;
     if (dlogits) {
         const float k = weight / (float)R;
         float* drow = dlogits + (int64_t)blockIdx.x * Cc;
@@ -141,10 +151,10 @@ __global__ __launch_bounds__(256) void ce_label0_kernel(const float* __restrict_
     }
 }
 
-// fused path, phase A: per row i, lse_i = log sum_{j != i} exp(s_ij), loss += w/R * (lse_i - s_ip)
+// fused path, phase A: per row i, lse_i = log sum_{j != i} exp(s_ij), row_terms[i] = w/R * (lse_i - s_ip)
 __global__ __launch_bounds__(256) void fused_lse_kernel(const float* __restrict__ zn, int R, int D, float inv_t,
                                                         float weight, float* __restrict__ lse_out,
-                                                        float* __restrict__ loss) {
+                                                        float* __restrict__ row_terms) {
     extern __shared__ float sm[];  // zi[D] + s[R] + red[8]
     float* zi = sm;
     float* srow = sm + D;
@@ -176,7 +186,7 @@ __global__ __launch_bounds__(256) void fused_lse_kernel(const float* __restrict_
     if (threadIdx.x == 0) {
         const float lse = mx + __logf(red[4] + red[5] + red[6] + red[7]);
         lse_out[i] = lse;
-        if (loss) atomicAdd(loss, weight * (lse - srow[p]) / (float)R);
+        row_terms[i] = weight * (lse - srow[p]) / (float)R;
     }
 }
 
@@ -185,7 +195,13 @@ template <typename T>
 __global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict__ zn, const float* __restrict__ inv_norm,
                                                         const float* __restrict__ lse, int R, int D, float inv_t,
                                                         float weight, const float* __restrict__ dz_scale,
+                                                        const float* __restrict__ row_terms, float* __restrict__ loss,
                                                         T* __restrict__ dz) {
+    __shared__ double sh4[4];
+    if (loss && blockIdx.x == 0) {  // phase A has finished (stream order): its row terms, summed in a fixed order
+        const double s = block256_ordered_sum(row_terms, R, sh4);
+        if (threadIdx.x == 0) *loss += (float)s;
+    }
     extern __shared__ float sm[];  // zi[D] + coef[R] + red[4]
     float* zi = sm;
     float* coef = sm + D;
@@ -233,10 +249,10 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict_
 // S [Rl][Rg]: cosines of this rank's Rl = 2B normalised projections (rows) against the Rg = world * Rl gathered ones
 // (columns; rank r's block is columns r*Rl .., its own rows sit at columns off + i).  Row i's positive is the other view
 // of the same pair, column off + (i + B) % Rl; its own column is excluded.  One workgroup per row:
-//   loss += weight/Rl * (-S_ip/T + log sum_{j != self} exp(S_ij/T));   S_ij <- dloss/dS_ij (in place; 0 at self)
+//   row_terms[i] = weight/Rl * (-S_ip/T + log sum_{j != self} exp(S_ij/T));   S_ij <- dloss/dS_ij (in place; 0 at self)
 __global__ __launch_bounds__(256) void ntxent_rect_kernel(float* __restrict__ S, int Rl, int Rg, int off, float inv_t,
                                                           float weight, const float* __restrict__ dz_scale,
-                                                          float* __restrict__ loss) {
+                                                          float* __restrict__ row_terms) {
     __shared__ float red[8];
     const int i = blockIdx.x, self = off + i, pos = off + (i + (Rl >> 1)) % Rl;
     float* row = S + (int64_t)i * Rg;
@@ -256,7 +272,8 @@ __global__ __launch_bounds__(256) void ntxent_rect_kernel(float* __restrict__ S,
     se = (red[4] + red[5]) + (red[6] + red[7]);
     const float lse = mx + __logf(se);
     const float k = weight / (float)Rl;
-    if (threadIdx.x == 0) atomicAdd(loss, k * (lse - row[pos] * inv_t));
+    if (threadIdx.x == 0) row_terms[i] = k * (lse - row[pos] * inv_t);
+    __syncthreads();  // (row[pos] is read above, rewritten below)
     const float g = k * inv_t * (dz_scale ? dz_scale[0] : 1.f);
     for (int j = threadIdx.x; j < Rg; j += 256) {
         float d = 0.f;
@@ -316,12 +333,16 @@ extern "C" int sm3_ntxent_logits_bwd(int dtype, const float* dlogits, const floa
     return 0;
 }
 
-extern "C" int sm3_ce_label0(const float* logits, int R, int Cc, float weight, float* loss, float* dlogits,
-                             void* stream) {
-    if (!logits || R <= 0 || Cc <= 0) return SM3_EINVAL;
-    hipLaunchKernelGGL(ce_label0_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, logits, R, Cc, weight, loss,
-                       dlogits);
+extern "C" int sm3_ce_label0(const float* logits, int R, int Cc, float weight, float* row_terms, float* loss,
+                             float* dlogits, void* stream) {
+    if (!logits || R <= 0 || Cc <= 0 || (loss && !row_terms)) return SM3_EINVAL;
+    hipLaunchKernelGGL(ce_label0_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, logits, R, Cc, weight,
+                       loss ? row_terms : nullptr, dlogits);
     SM3_CHECK_LAUNCH();
+    if (loss) {
+        hipLaunchKernelGGL(ordered_loss_add_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, row_terms, R, loss);
+        SM3_CHECK_LAUNCH();
+    }
     return 0;
 }
 
@@ -340,15 +361,21 @@ constexpr int NTX_TI = 8, NTX_TJ = 64, NTX_CP = NTX_TJ + 4;
 template <bool BWD, typename T, int NV>
 __global__ __launch_bounds__(256) void ntxent_tile_kernel(const float* __restrict__ zn, const float* __restrict__ inv_norm,
                                                           float* __restrict__ lse, int R, int D, float inv_t, float weight,
-                                                          const float* __restrict__ dz_scale, float* __restrict__ loss,
-                                                          T* __restrict__ dz) {
+                                                          const float* __restrict__ dz_scale, float* __restrict__ row_terms,
+                                                          float* __restrict__ loss, T* __restrict__ dz) {
+    if constexpr (BWD) {
+        __shared__ double sh4[4];
+        if (loss && blockIdx.x == 0) {  // the LSE launch has finished (stream order): its row terms, summed in a fixed order
+            const double s = block256_ordered_sum(row_terms, R, sh4);
+            if (threadIdx.x == 0) *loss += (float)s;
+        }
+    }
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D4 = D >> 2, DP = D + 4;
     float* zi = sm;                      // [TI][DP]
     float* zj = zi + NTX_TI * DP;        // [TJ][DP]
     float* coef = zj + NTX_TJ * DP;      // [TI][CP]   (BWD)
     float* lse_t = coef + NTX_TI * NTX_CP;  // [TJ]    (BWD)
-    float* red = lse_t + NTX_TJ;         // [TI]
     const int t = threadIdx.x, il = t >> 5, jj = t & 31;
     const int i0 = blockIdx.x * NTX_TI, i = i0 + il, half = R >> 1;
     const bool row_ok = i < R;
@@ -494,34 +521,23 @@ __global__ __launch_bounds__(256) void ntxent_tile_kernel(const float* __restric
             s += __shfl_xor(s, o, 64);
             s_pos += __shfl_xor(s_pos, o, 64);
         }
-        if (jj == 0) {
-            float term = 0.f;
-            if (row_ok) {
-                const float l = mx + __logf(s);
-                lse[i] = l;
-                term = weight * (l - s_pos) / (float)R;
-            }
-            red[il] = term;
-        }
-        __syncthreads();
-        if (t == 0 && loss) {
-            float a = 0.f;
-#pragma unroll
-            for (int r = 0; r < NTX_TI; ++r) a += red[r];
-            atomicAdd(loss, a);
+        if (jj == 0 && row_ok) {
+            const float l = mx + __logf(s);
+            lse[i] = l;
+            row_terms[i] = weight * (l - s_pos) / (float)R;
         }
     }
 }
 
 template <typename T, int NV>
-static void launch_ntxent_tiles(const float* zn, const float* inv_norm, float* lse, int R, int D, float inv_t, float weight,
-                                const float* dz_scale, float* loss, T* dz, hipStream_t st) {
-    const size_t lds = (size_t)((NTX_TI + NTX_TJ) * (D + 4) + NTX_TI * NTX_CP + NTX_TJ + NTX_TI) * 4;
+static void launch_ntxent_tiles(const float* zn, const float* inv_norm, float* lse, float* row_terms, int R, int D, float inv_t,
+                                float weight, const float* dz_scale, float* loss, T* dz, hipStream_t st) {
+    const size_t lds = (size_t)((NTX_TI + NTX_TJ) * (D + 4) + NTX_TI * NTX_CP + NTX_TJ) * 4;
     const dim3 grid((R + NTX_TI - 1) / NTX_TI);
     hipLaunchKernelGGL((ntxent_tile_kernel<false, T, NV>), grid, dim3(256), lds, st, zn, inv_norm, lse, R, D, inv_t, weight,
-                       nullptr, loss, (T*)nullptr);
+                       nullptr, row_terms, (float*)nullptr, (T*)nullptr);
     hipLaunchKernelGGL((ntxent_tile_kernel<true, T, NV>), grid, dim3(256), lds, st, zn, inv_norm, lse, R, D, inv_t, weight,
-                       dz_scale, (float*)nullptr, dz);
+                       dz_scale, row_terms, loss, dz);
 }
 
 }  // namespace
@@ -535,22 +551,23 @@ static int ntxent_fused_impl(int dtype, const float* z, int R, int D, float temp
     float* zn = workspace;                    // [R][D]
     float* inv_norm = workspace + (size_t)R * D;  // [R]
     float* lse = inv_norm + R;                // [R]
+    float* row_terms = lse + R;               // [R]  per-row loss terms, summed in a fixed order by the backward launch
     hipStream_t st = (hipStream_t)stream;
     const float inv_t = 1.f / temperature;
     hipLaunchKernelGGL(normalize_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, st, z, R, D, zn, inv_norm);
     SM3_CHECK_LAUNCH();
     if (D % 4 == 0 && D <= 128 && ((uintptr_t)workspace & 15) == 0) {  // tiled kernels (8 anchors x 64-candidate tiles, 40 KB of LDS)
-#define SM3_NTX_TILE(T) launch_ntxent_tiles<T, 8>(zn, inv_norm, lse, R, D, inv_t, weight, dz_scale, loss, (T*)dz, st)
+#define SM3_NTX_TILE(T) launch_ntxent_tiles<T, 8>(zn, inv_norm, lse, row_terms, R, D, inv_t, weight, dz_scale, loss, (T*)dz, st)
         SM3_DISPATCH_DTYPE(dtype, SM3_NTX_TILE);
 #undef SM3_NTX_TILE
         SM3_CHECK_LAUNCH();
         return 0;
     }
-    hipLaunchKernelGGL(fused_lse_kernel, dim3(R), dim3(256), lds, st, zn, R, D, inv_t, weight, lse, loss);
+    hipLaunchKernelGGL(fused_lse_kernel, dim3(R), dim3(256), lds, st, zn, R, D, inv_t, weight, lse, row_terms);
     SM3_CHECK_LAUNCH();
 #define SM3_NTX(T)                                                                                                       \
     hipLaunchKernelGGL(fused_bwd_kernel<T>, dim3(R), dim3(256), lds, st, zn, inv_norm, lse, R, D, inv_t, weight, dz_scale, \
-                       (T*)dz)
+                       row_terms, loss, (T*)dz)
     SM3_DISPATCH_DTYPE(dtype, SM3_NTX);
 #undef SM3_NTX
     SM3_CHECK_LAUNCH();
@@ -576,11 +593,14 @@ extern "C" int sm3_normalize_rows(const float* z, int R, int D, float* zn, float
 }
 
 extern "C" int sm3_ntxent_rect(float* S, int Rl, int Rg, int self_offset, float temperature, float weight,
-                               const float* dz_scale, float* loss, void* stream) {
-    if (!S || !loss || Rl < 2 || (Rl & 1) || Rg < Rl || self_offset < 0 || self_offset + Rl > Rg || temperature <= 0)
+                               const float* dz_scale, float* row_terms, float* loss, void* stream) {
+    if (!S || !loss || !row_terms || Rl < 2 || (Rl & 1) || Rg < Rl || self_offset < 0 || self_offset + Rl > Rg ||
+        temperature <= 0)
         return SM3_EINVAL;
     hipLaunchKernelGGL(ntxent_rect_kernel, dim3(Rl), dim3(256), 0, (hipStream_t)stream, S, Rl, Rg, self_offset,
-                       1.f / temperature, weight, dz_scale, loss);
+                       1.f / temperature, weight, dz_scale, row_terms);
+    SM3_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ordered_loss_add_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, row_terms, Rl, loss);
     SM3_CHECK_LAUNCH();
     return 0;
 }

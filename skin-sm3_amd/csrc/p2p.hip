@@ -51,7 +51,13 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(double* __restrict__
     // An exchange that has already failed on this rank stays failed: no further waiting (a dead peer would cost its full
     // timeout 220 times per step), and the caller's sums are replaced by NaN so that whatever is computed from them -- the
     // BatchNorm statistics, the loss the trainer returns -- shows it, with or without a host read of *err.
-    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+    // ONE thread reads the flag and the block branches on the shared copy: the other lane's exchange kernel shares the word
+    // and may set it while this block's waves are starting -- per-thread reads could send some waves home and others into
+    // the barriers below.
+    __shared__ int s_bad;
+    if (threadIdx.x == 0) s_bad = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_bad != 0) {
         for (int i = i0 + threadIdx.x; i < i1; i += 256) buf[i] = __longlong_as_double(0x7ff8000000000000LL);
         return;
     }
@@ -71,10 +77,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(double* __restrict__
     // (2) raise my flag everywhere
     if ((int)threadIdx.x < world)
         __hip_atomic_store(&peers.box[threadIdx.x]->flag[slot][rank][b], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    // (3) wait for everybody's flag in MY mailbox
-    __shared__ int s_bad;
-    if (threadIdx.x == 0) s_bad = 0;
-    __syncthreads();
+    // (3) wait for everybody's flag in MY mailbox  (s_bad is 0 here, and every wave has read it: the barrier above)
     if ((int)threadIdx.x < world) {
         const unsigned long long* f = &peers.box[rank]->flag[slot][threadIdx.x][b];
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz wall clock
@@ -107,6 +110,23 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(double* __restrict__
 
 extern "C" int sm3_p2p_mailbox_bytes(void) { return (int)sizeof(Mailbox); }
 extern "C" int sm3_p2p_max_elems(void) { return kMaxN; }
+extern "C" int sm3_p2p_max_world(void) { return kMaxWorld; }
+// Byte offsets inside a mailbox of the data area [first, first + bytes) that source rank `src` writes for exchange slot
+// `slot`, and of the 8-byte arrival flag of its block `block` -- computed from the SAME struct the kernel addresses, so that a
+// host test can check without a GPU that the areas of 8 ranks x 2 slots x every block are disjoint and inside the allocation.
+extern "C" int sm3_p2p_layout(int slot, int src, int block, int64_t* data_first, int64_t* data_bytes, int64_t* flag_off,
+                              int* elems_per_block) {
+    if (slot < 0 || slot > 1 || src < 0 || src >= kMaxWorld || block < 0 || block >= kMaxBlocks || !data_first || !data_bytes ||
+        !flag_off)
+        return SM3_EINVAL;
+    const uintptr_t base = (uintptr_t)1 << 40;  // any address: only differences are taken
+    const Mailbox* m = reinterpret_cast<const Mailbox*>(base);
+    *data_first = (int64_t)((uintptr_t)&m->data[slot][src][0] - base);
+    *data_bytes = (int64_t)sizeof(m->data[slot][src]);
+    *flag_off = (int64_t)((uintptr_t)&m->flag[slot][src][block] - base);
+    if (elems_per_block) *elems_per_block = kChunk;
+    return 0;
+}
 
 // Mailboxes are FINE-GRAINED device memory (hipExtMallocWithFlags(hipDeviceMallocFinegrained), what RCCL uses for its own
 // IPC flag / data buffers): stores of another agent become visible to a kernel that is already running and polling, which

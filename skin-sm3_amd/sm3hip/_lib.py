@@ -64,6 +64,8 @@ SIGNATURES = {
     "sm3_linbn_fold": [_P, _I, _I, _I, _P, _P],
     "sm3_p2p_mailbox_bytes": [],
     "sm3_p2p_max_elems": [],
+    "sm3_p2p_max_world": [],
+    "sm3_p2p_layout": [_I, _I, _I, _P, _P, _P, _P],
     "sm3_p2p_alloc": [_P, _P, _P],
     "sm3_p2p_open": [_P, _P],
     "sm3_p2p_close": [_P],
@@ -118,10 +120,10 @@ SIGNATURES = {
     "sm3_cast_to_f32": [_I, _P, _P, _L, _P],
     "sm3_ntxent_logits": [_P, _I, _I, _F, _P, _P, _P, _P],
     "sm3_ntxent_logits_bwd": [_I, _P, _P, _P, _I, _I, _F, _P, _P],
-    "sm3_ce_label0": [_P, _I, _I, _F, _P, _P, _P],
+    "sm3_ce_label0": [_P, _I, _I, _F, _P, _P, _P, _P],
     "sm3_ntxent_fused": [_I, _P, _I, _I, _F, _F, _P, _P, _P, _P],
     "sm3_normalize_rows": [_P, _I, _I, _P, _P, _P],
-    "sm3_ntxent_rect": [_P, _I, _I, _I, _F, _F, _P, _P, _P],
+    "sm3_ntxent_rect": [_P, _I, _I, _I, _F, _F, _P, _P, _P, _P],
     "sm3_normalize_rows_bwd": [_I, _P, _P, _P, _P, _I, _I, _P, _P],
     "sm3_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P, _P],
     "sm3_adamw_dynamic": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P],

@@ -1163,7 +1163,15 @@ def ce_label0(logits, weight, loss, dlogits):
     R, Cc = logits.shape
     if dlogits is not None and dlogits.numel() != logits.numel():
         raise ValueError("ce_label0: size mismatch")
-    check(_lib.load().sm3_ce_label0(_ptr(logits), R, Cc, weight, _ptr(loss), _ptr(dlogits), _stream()), "sm3_ce_label0")
+    # per-row terms, summed in a fixed order by the library (the loss is a function of the logits bit for bit)
+    terms = torch.empty(R, dtype=torch.float32, device=logits.device) if loss is not None else None
+    check(_lib.load().sm3_ce_label0(_ptr(logits), R, Cc, weight, _ptr(terms), _ptr(loss), _ptr(dlogits), _stream()),
+          "sm3_ce_label0")
+
+
+def ntxent_workspace_floats(R, D):
+    """sm3_ntxent_fused's workspace: normalised rows, inverse norms, per-row logsumexp, per-row loss terms."""
+    return R * D + 3 * R
 
 
 def ntxent_fused(dtype, z, temperature, weight, workspace, loss, dz, dz_scale=None):
@@ -1171,7 +1179,7 @@ def ntxent_fused(dtype, z, temperature, weight, workspace, loss, dz, dz_scale=No
     _chk(z, torch.float32); _chk(workspace, torch.float32); _chk(loss, torch.float32); _chk(dz, TORCH_DTYPE[dtype])
     _chk(dz_scale, torch.float32, "dz_scale")
     R, D = z.shape
-    if workspace.numel() < R * D + 2 * R or dz.numel() != R * D:
+    if workspace.numel() < ntxent_workspace_floats(R, D) or dz.numel() != R * D:
         raise ValueError("ntxent_fused: size mismatch")
     with _prof("ntxent_fused", 6.0 * R * R * D, 4.0 * R * D * 3):
         if dz_scale is None:
@@ -1198,9 +1206,10 @@ def ntxent_rect(S, self_offset, temperature, weight, loss, dz_scale=None):
     Rl, Rg = S.shape
     if Rl % 2 or self_offset < 0 or self_offset + Rl > Rg:
         raise ValueError("ntxent_rect: bad geometry")
+    terms = torch.empty(Rl, dtype=torch.float32, device=S.device)  # per-row terms, summed in a fixed order by the library
     with _prof("ntxent_rect", 0.0, 8.0 * Rl * Rg):
-        check(_lib.load().sm3_ntxent_rect(_ptr(S), Rl, Rg, self_offset, temperature, weight, _ptr(dz_scale), _ptr(loss),
-                                          _stream()), "sm3_ntxent_rect")
+        check(_lib.load().sm3_ntxent_rect(_ptr(S), Rl, Rg, self_offset, temperature, weight, _ptr(dz_scale), _ptr(terms),
+                                          _ptr(loss), _stream()), "sm3_ntxent_rect")
 
 
 def normalize_rows_bwd(dtype, dzn_a, dzn_b, zn, inv_norm, dz):

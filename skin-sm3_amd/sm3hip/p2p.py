@@ -70,7 +70,8 @@ class P2PStatSync:
               "sm3_p2p_allreduce_f64")
 
     _MSG = ("P2PStatSync: a peer's statistics did not arrive in time (rank died or ranks out of step); every exchange "
-            "since then returned NaN")
+            "since then returned NaN.  SM3Trainer skipped the optimizer update of every step whose gradients were poisoned "
+            "(parameters and AdamW moments are those of the last good step; BatchNorm running statistics are not)")
 
     def check(self):
         """Raise if any exchange so far timed out (synchronises)."""

@@ -245,7 +245,7 @@ class SM3Trainer:
         sc = self._scaler_state(dev, eng.tdt)
         for name, z in zs.items():
             R, D = z.shape
-            ws = eng._work("ntxent_ws", R * D + 2 * R)
+            ws = eng._work("ntxent_ws", ops.ntxent_workspace_floats(R, D))
             dz[name] = torch.empty(R, D, dtype=eng.tdt, device=dev)
             scale = sc["scale"] if sc is not None else None
             if zt is not None:
@@ -275,7 +275,7 @@ class SM3Trainer:
             for half in (0, 1):
                 zz = torch.cat([zc[half * Bm:(half + 1) * Bm], z_meta], 0)
                 dd = torch.empty(2 * Bm, zz.shape[1], dtype=eng.tdt, device=dev)
-                ws = eng._work("ntxent_ws", zz.numel() + 4 * Bm)
+                ws = eng._work("ntxent_ws", ops.ntxent_workspace_floats(2 * Bm, zz.shape[1]))
                 if self.global_negatives:
                     self._ntxent_global(eng, "meta", zz, T, 0.5, loss, dd, sc["scale"] if sc is not None else None)
                 else:
@@ -311,7 +311,12 @@ class SM3Trainer:
         # 81.65 M parameters behind the LAST collective -- provided the notified ranges tile the buffer exactly
         # (they are the schedule the single-rank path verifies; anything else falls back to the single launch).
         dp_buckets = False
-        if self.dp and sc is None and self._handles and len(self._handles) == len(self._handle_ranges) \
+        # Peer-to-peer statistics exchange (opt-in): a timed-out exchange poisons its sums with NaN, which reach this rank's
+        # gradients directly and every other rank's through the gradient all-reduce.  The update must not be applied then
+        # (a caller that catches the error, or checkpoints on it, would hold a destroyed model): AdamW runs once,
+        # behind the last collective, gated on "this rank's exchange failed OR any gradient is non-finite".
+        p2p = self.__dict__.get("_p2p")
+        if self.dp and sc is None and p2p is None and self._handles and len(self._handles) == len(self._handle_ranges) \
                 and os.environ.get("SM3_ADAMW_BUCKETS", "1") != "0":
             pos = 0
             for a, b in sorted(self._handle_ranges):
@@ -342,8 +347,12 @@ class SM3Trainer:
             pass  # every bucket has had its AdamW launch (on the lane that finished it / behind its all-reduce)
         elif sc is None:
             self.step_count += 1
+            skip = None
+            if p2p is not None:
+                skip = p2p.err.clone()
+                ops.check_finite(st.flat_g, skip)
             ops.adamw(st.flat_p, st.flat_g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
-                      self.step_count, 1.0 / self.world)
+                      self.step_count, 1.0 / self.world, skip)
         else:
             # GradScaler.step() + update() (backbone_train.py:126-127) without a host synchronisation: inf / nan check
             # of the (all-reduced, still scaled) gradients, unscale + AdamW skipped on overflow, scale update

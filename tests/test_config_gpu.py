@@ -87,12 +87,12 @@ def test_config2_b256_224_bf16():
         runs[key] = (loss, float(gflat.double().norm()), stats)
         del tr, eng, model, gflat
         torch.cuda.empty_cache()
-    # both views as ONE batch of 512 images == two passes of
-    # 256: forward arithmetic is tile for tile the same -> running statistics bit-identical, loss equal up to the
-    # order of the four float-atomic loss terms; weight gradients differ by the summation order of the pixel axis
-    assert abs(runs["bf16_pair"][0] - runs["bf16_views"][0]) < 1e-5, (runs["bf16_pair"][0], runs["bf16_views"][0])
+    # both views as ONE batch of 512 images == two passes of 256: forward arithmetic is tile for tile the same -> running
+    # statistics bit-identical (asserted first: they pin the forward); the loss is a fixed-order fp64 sum of per-row terms
+    # (round 5: no float atomics), so it is EQUAL too; weight gradients differ by the summation order of the pixel axis
     for k, v in runs["bf16_pair"][2].items():
         assert torch.equal(v, runs["bf16_views"][2][k]), k
+    assert runs["bf16_pair"][0] == runs["bf16_views"][0], (runs["bf16_pair"][0], runs["bf16_views"][0])
     assert abs(runs["bf16_pair"][1] - runs["bf16_views"][1]) < 2e-3 * runs["bf16_views"][1]
     assert int(runs["bf16_pair"][2]["derm_backbone.encoder.bn1.num_batches_tracked"]) == 2
     # against the exact-f32 MFMA mode on the same inputs and weights.  Random init + N(0,1) noise images is the
@@ -111,7 +111,7 @@ def test_config2_b256_224_bf16():
 def test_b512_both_views_one_batch(dt):
     """B = 512 pairs per GPU: 1 024 images per launch, activation tensors up to 1.6 GB.  Possible in the one-batch mode only
     since the stem reads the images directly (the 2B-image im2col matrix would pass the 3 GB buffer-offset limit); equal
-    to the per-view passes (running statistics bit for bit, loss to the order of the float-atomic loss terms)."""
+    to the per-view passes (running statistics and the loss bit for bit)."""
     from sm3hip.trainer import SM3Trainer
     B, S = 512, 224
     g = torch.Generator(device=DEV).manual_seed(11)
@@ -134,11 +134,11 @@ def test_b512_both_views_one_batch(dt):
                       {k: v.clone() for k, v in model.state_dict().items() if "running" in k})
         del tr, eng, model
         torch.cuda.empty_cache()
-    # the loss is four NT-Xent terms whose row sums are added with float atomics: equal up to that order (a few ulp of 22);
-    # the forward itself is pinned bit for bit by the running statistics below
-    assert abs(runs[True][0] - runs[False][0]) < 5e-5, (runs[True][0], runs[False][0])
+    # the forward is pinned bit for bit by the running statistics; the loss (four NT-Xent terms, each a fixed-order sum of
+    # its per-row terms) is then equal as well
     for k, v in runs[True][2].items():
         assert torch.equal(v, runs[False][2][k]), k
+    assert runs[True][0] == runs[False][0], (runs[True][0], runs[False][0])
     assert abs(runs[True][1] - runs[False][1]) < 2e-3 * runs[False][1]
 
 

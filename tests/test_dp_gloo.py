@@ -52,7 +52,7 @@ def _entry(fn, rank, world, port, q):
         for p in (ROOT, os.path.join(ROOT, "skin-sm3_amd"), os.path.join(ROOT, "tests")):
             if p not in sys.path:
                 sys.path.insert(0, p)
-        torch.set_num_threads(4)
+        torch.set_num_threads(4 if world <= 2 else 1)
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
         out = fn(rank, world)
         dist.barrier()
@@ -78,7 +78,7 @@ class _AllReduceSum(torch.autograd.Function):
 
 def _oracle_rank(rank, world):
     from oracle import procedural, sm3_oracle as O
-    Bl, size, seed, T = 3, 32, 5, 0.1
+    Bl, size, seed, T = (3 if world <= 2 else 2), 32, 5, 0.1
     Bg = Bl * world
     state = procedural.make_state_dict(seed=seed)
     derm_np, clinic_np = procedural.make_pair_batch(Bg, size, seed)
@@ -96,6 +96,7 @@ def _oracle_rank(rank, world):
     result = None
     if rank == 0:
         # single-process reference: full-batch BN statistics, per-shard local-negative losses, averaged
+        torch.set_num_threads(8)  # (the other ranks wait in the all-gather below)
         P2, B2 = O.split_state(state, dt)
         dfull = [torch.from_numpy(a).to(dt) for a in derm_np]
         cfull = [torch.from_numpy(a).to(dt) for a in clinic_np]
@@ -121,6 +122,16 @@ def _oracle_rank(rank, world):
 
 def test_syncbn_and_grad_averaging_semantics_gloo():
     out = _spawn(_oracle_rank)[0]
+    assert out["grad_rel"] < 1e-9, out
+    assert out["buf_err"] < 1e-10, out
+    assert abs(out["loss_mean"] - out["loss_ref"]) < 1e-10, out
+    assert out["nbt"] == 2
+
+
+def test_syncbn_and_grad_averaging_semantics_gloo_world8():
+    """The same at BASELINE config 3's rank count: 8 ranks x 2 pairs (a rank's NT-Xent rows see their positive
+    and the two rows of the other local pair), statistics and gradients summed over 8."""
+    out = _spawn(_oracle_rank, world=8)[0]
     assert out["grad_rel"] < 1e-9, out
     assert out["buf_err"] < 1e-10, out
     assert abs(out["loss_mean"] - out["loss_ref"]) < 1e-10, out
@@ -168,6 +179,21 @@ def test_trainer_collective_pattern_gloo():
     # (engine.conv_bn `pending`, engine.bn_backward_join), 4 blocks x 4 encoder passes fewer than one per BatchNorm
     assert a["n_stats"] == 428
     assert a["bucket_elems"] == a["total"]            # gradient buckets tile the flat buffer exactly once
+    assert 4 <= a["n_buckets"] <= 16 and a["async"]
+
+
+def test_trainer_collective_pattern_gloo_world8():
+    """BASELINE config 3's rank count (8 x MI355X) on the CPU: the product trainer's collective sequence -- per-lane
+    SyncBatchNorm statistic all-reduces, gradient buckets as they become final, AdamW with grad_scale = 1/8 -- is the same
+    list on all eight ranks (no deadlock by construction), its counts do not depend on the world size, and the buckets tile
+    the flat gradient buffer exactly once.  No hardware with 8 GPUs was available to any round: config 3 stays unmeasured."""
+    res = _spawn(_trainer_rank, world=8)
+    assert len(res) == 8
+    for r in range(1, 8):
+        assert res[r]["seq"] == res[0]["seq"], r
+    a = res[0]
+    assert a["n_stats"] == 428
+    assert a["bucket_elems"] == a["total"]
     assert 4 <= a["n_buckets"] <= 16 and a["async"]
 
 
@@ -245,3 +271,49 @@ def test_mlc_cluster_memory_gather_kmeans_broadcast_gloo():
     assert a["assign"] == a["want"]                          # every sample's cluster, addressed by its dataset index
     assert min(a["assign"]) >= 0                             # no -100 left: the shards cover the bank
     assert a["weight"] == a["c_ref"]                         # the centroids became the prototype weights
+
+
+def test_mlc_cluster_memory_gather_kmeans_broadcast_gloo_world8():
+    """BASELINE config 4 is an 8-GPU configuration: eight shards of the memory bank -> rank 0 -> k-means -> broadcast."""
+    res = _spawn(_cluster_rank, world=8)
+    a = res[0]
+    for r in range(1, 8):
+        assert res[r]["assign"] == a["assign"] and res[r]["weight"] == a["weight"], r
+    assert a["assign"] == a["want"] and min(a["assign"]) >= 0 and len(a["assign"]) == 8 * 37
+    assert a["weight"] == a["c_ref"]
+
+
+def test_p2p_mailbox_layout_has_room_for_eight_ranks():
+    """csrc/p2p.hip addresses a mailbox as data[slot][source rank][element] + flag[slot][source rank][block].  Checked on
+    the host, from the library's own struct (sm3_p2p_layout): with 8 source ranks x 2 slots every data area and every flag
+    is inside sm3_p2p_mailbox_bytes(), no two overlap, the blocks of the largest exchange have a flag each, and the largest
+    message the engine exchanges -- bn3 and the downsample BatchNorm of layer 4 in one collective, two views, sum and sum of
+    squares of 2 048 channels each: 2 x 2 x 2 x 2 048 doubles -- fits sm3_p2p_max_elems()."""
+    import ctypes as C
+    from sm3hip import _lib
+    lib = _lib.load()
+    W = lib.sm3_p2p_max_world()
+    assert W == 8
+    total, nmax = lib.sm3_p2p_mailbox_bytes(), lib.sm3_p2p_max_elems()
+    assert nmax >= 2 * 2 * 2 * 2048
+    spans = []
+    per_block = None
+    d0, db, fo, epb = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()
+    for slot in (0, 1):
+        for src in range(W):
+            block = 0
+            while lib.sm3_p2p_layout(slot, src, block, C.byref(d0), C.byref(db), C.byref(fo), C.byref(epb)) == 0:
+                per_block = epb.value
+                if block == 0:
+                    assert db.value >= nmax * 8
+                    spans.append((d0.value, d0.value + db.value, ("data", slot, src)))
+                spans.append((fo.value, fo.value + 8, ("flag", slot, src, block)))
+                block += 1
+            assert block * per_block >= nmax, (block, per_block)       # every element of the largest message has a block
+    assert lib.sm3_p2p_layout(0, W, 0, C.byref(d0), C.byref(db), C.byref(fo), None) == -1   # a ninth rank is refused
+    assert lib.sm3_p2p_layout(2, 0, 0, C.byref(d0), C.byref(db), C.byref(fo), None) == -1   # ... and a third slot
+    spans.sort()
+    assert spans[0][0] >= 0 and spans[-1][1] <= total
+    for (a0, a1, wa), (b0, b1, wb) in zip(spans, spans[1:]):
+        assert a1 <= b0, (wa, wb)
+    assert all(s[0] % 8 == 0 for s in spans)                           # 64-bit atomics need 8-byte alignment

@@ -434,7 +434,7 @@ def test_ntxent_logits_and_backward(R):
     assert (dz.cpu().double() - z64.grad).abs().max().item() < 1e-4 * sc + 1e-7
 
     # fused path: same loss and gradient without the logits tensor
-    ws = torch.empty(R * 128 + 2 * R, device=D)
+    ws = torch.empty(ops.ntxent_workspace_floats(R, 128), device=D)
     loss2 = torch.zeros(1, device=D)
     dz2 = torch.empty(R, 128, device=D)
     ops.ntxent_fused(0, z.to(D), 0.1, 0.5, ws, loss2, dz2)
@@ -458,7 +458,7 @@ def test_ntxent_fused_tiled_and_row_kernels(R, Dm):
     ref_loss = 0.5 * O.cross_entropy_zero_label(ref_logits)
     ref_loss.backward()
     sc = z64.grad.abs().max().item()
-    ws = torch.empty(R * Dm + 2 * R, device=D)
+    ws = torch.empty(ops.ntxent_workspace_floats(R, Dm), device=D)
     for scale in (None, 1024.0):
         loss = torch.zeros(1, device=D)
         dz = torch.full((R, Dm), float("nan"), device=D)
@@ -468,6 +468,25 @@ def test_ntxent_fused_tiled_and_row_kernels(R, Dm):
         assert abs(float(loss) - float(ref_loss)) < 2e-5 * max(1.0, abs(float(ref_loss)))
         k = scale or 1.0
         assert (dz.cpu().double() / k - z64.grad).abs().max().item() < 1e-4 * sc + 1e-7
+    # The loss is a fixed-order sum of per-row terms (no float atomics): repeated calls -- alone, and beside a second stream
+    # that keeps the chip busy so that workgroups arrive in another order -- give the same bits, and four calls into one
+    # accumulator (the four terms of a step, tools/backbone_train.py:101-102,119-121) do too.
+    zd = z.to(D)
+    seen = set()
+    side = torch.cuda.Stream()
+    big = torch.randn(4096, 4096, device=D)
+    for rep in range(12):
+        loss = torch.zeros(1, device=D)
+        dz = torch.empty(R, Dm, device=D)
+        if rep % 2:
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    big = big * 1.0001
+        for w in (1.0, 1.0, 0.5, 0.5):
+            ops.ntxent_fused(0, zd, 0.1, w, ws, loss, dz)
+        torch.cuda.synchronize()
+        seen.add(loss.cpu().numpy().tobytes())
+    assert len(seen) == 1
 
 
 def test_adamw_matches_torch():

@@ -139,14 +139,19 @@ def _missing_peer_main(rank, world, port, q):
         tr = SM3Trainer(model, lr=1e-3)
         tr._engine()  # both ranks map each other's mailboxes ...
         tr._bucket_ready = lambda *a: None  # (no gradient all-reduce: this is about the statistics exchange, and rank 1 is absent)
-        out = {"nan": True, "check": True, "step": True, "s": 0.0}
+        out = {"nan": True, "check": True, "step": True, "s": 0.0, "params_kept": True}
         if rank == 0:  # ... but only rank 0 steps: its peer never raises a flag
             import time
             batch = ([torch.from_numpy(a).to(dev) for a in derm_np], [torch.from_numpy(a).to(dev) for a in clinic_np])
+            before = tr._engine().store.flat_p.clone()
             t0 = time.perf_counter()
             loss = float(tr.step(*batch))
             out["s"] = time.perf_counter() - t0
             out["nan"] = loss != loss
+            # the poisoned gradients were NOT applied: parameters bit-identical, AdamW moments still zero
+            st = tr._engine().store
+            out["params_kept"] = bool(torch.equal(st.flat_p, before)) and float(tr.m.abs().max()) == 0.0 \
+                and float(tr.v.abs().max()) == 0.0 and not bool(torch.isfinite(st.flat_g).all())
             try:
                 tr.check()
                 out["check"] = False
@@ -168,9 +173,11 @@ def _missing_peer_main(rank, world, port, q):
 def test_trainer_step_with_a_missing_peer_fails_loudly():
     """SM3_SYNCBN_P2P=1, rank 1 never steps: rank 0's first exchange runs into its timeout ONCE (0.5 s here), every later one
     returns at once, the step's loss is NaN, SM3Trainer.check() raises and so does the next step() -- training cannot carry
-    on with un-reduced statistics."""
+    on with un-reduced statistics -- and the optimizer update of the poisoned step is skipped on the device, so
+    a caller that catches the error still holds the model of the last good step."""
     res = _spawn(_missing_peer_main)
     assert res[0]["nan"] and res[0]["check"] and res[0]["step"], res[0]
+    assert res[0]["params_kept"], res[0]
     assert res[0]["s"] < 15.0, res[0]  # 220 exchanges x 0.5 s would be 110 s
 
 
