@@ -316,6 +316,12 @@ int sm3_linbn_scale_banks(int dtype, const void* w3, int K3, const float* scale3
  * Tm NULL, recomputed from G.  C % 128 == 0, p % 32 == 0. */
 int sm3_linbn_post(int dtype, const void* wbn, const void* w_dgrad, void* hn, const float* P, const float* G,
                    const float* Tm, const double* s, const float* coef, float* dw, int C, int p, int views, void* stream);
+/* sm3_linbn_banks + sm3_linbn_post as ONE launch (the links of the chain between a unit's backward GEMMs are launch
+ * latency): wa, col_const, hn and dw as those two produce them, bit for bit; the -diag(b) W bank is formed in registers
+ * (same product, same rounding) and never stored. */
+int sm3_linbn_banks_post(int dtype, const void* w_dgrad, const float* coef, void* wa, float* col_const, void* hn,
+                         const float* P, const float* G, const float* Tm, const double* s, float* dw, int C, int p, int views,
+                         void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Stem, pooling.  replaces resnet.py:208-213,224,294-305.

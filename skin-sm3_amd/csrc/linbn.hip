@@ -229,15 +229,13 @@ __global__ void linbn_coef_kernel(const double* __restrict__ gsums, double inv_c
 //   wa[v][ci][co] = T(a wd),  wbn[v][ci][co] = T(-b wd),  col_const[v][ci] = sum_co -(mu f(wbn) + m1 f(wa))
 // (the constant uses the ROUNDED products, so that what the GEMM adds up is centred exactly).
 template <typename T>
-__global__ __launch_bounds__(256) void linbn_banks_kernel(const T* __restrict__ wd, const float4* __restrict__ coef,
-                                                          T* __restrict__ wa, T* __restrict__ wbn,
-                                                          float* __restrict__ col_const, int C, int p) {
+__device__ __forceinline__ void banks_row(const T* __restrict__ wd, const float4* __restrict__ coef, T* __restrict__ wa,
+                                          T* __restrict__ wbn, float* __restrict__ col_const, int C, int p, int ci, int v,
+                                          float* red) {
     constexpr int E = 8;
-    __shared__ float red[4];
-    const int ci = blockIdx.x, v = blockIdx.y;
     const T* src = wd + (long)ci * C;
     T* oa = wa + ((long)v * p + ci) * C;
-    T* ob = wbn + ((long)v * p + ci) * C;
+    T* ob = wbn ? wbn + ((long)v * p + ci) * C : nullptr;  // (sm3_linbn_banks_post keeps -b wd in registers only)
     const float4* cf = coef + (long)v * C;
     float part = 0.f;
     for (int c0 = threadIdx.x * E; c0 < C; c0 += 256 * E) {
@@ -253,7 +251,7 @@ __global__ __launch_bounds__(256) void linbn_banks_kernel(const T* __restrict__ 
         }
         const uint4 pa = pack16<T>(fa), pb = pack16<T>(fb);
         *reinterpret_cast<uint4*>(oa + c0) = pa;
-        *reinterpret_cast<uint4*>(ob + c0) = pb;
+        if (ob) *reinterpret_cast<uint4*>(ob + c0) = pb;
         unpack16<T>(pa, fa);
         unpack16<T>(pb, fb);
 #pragma unroll
@@ -263,6 +261,14 @@ __global__ __launch_bounds__(256) void linbn_banks_kernel(const T* __restrict__ 
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
     __syncthreads();
     if (threadIdx.x == 0) col_const[(long)v * p + ci] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void linbn_banks_kernel(const T* __restrict__ wd, const float4* __restrict__ coef,
+                                                          T* __restrict__ wa, T* __restrict__ wbn,
+                                                          float* __restrict__ col_const, int C, int p) {
+    __shared__ float red[4];
+    banks_row<T>(wd, coef, wa, wbn, col_const, C, p, blockIdx.x, blockIdx.y, red);
 }
 
 // ---- sm3_linbn_scale_banks ------------------------------------------------------------------------------------------
@@ -297,21 +303,22 @@ __global__ __launch_bounds__(256) void linbn_scale_banks_kernel(const T* __restr
 //   tiles [0, views (p/32)^2):  hn[v][k][ci] = sum_co wbn_v[k][co] wd[ci][co] = -H_v          (16-bit MFMA, K = C)
 //   tiles beyond:  dw[co][ci] += sum_v a (P_v - m1 s_v^T) - b (W G_v - mu s_v^T),  W G_v read from Tm (saved by
 //                  sm3_linbn_fwd_stats) or, Tm == nullptr, recomputed here on the exact-f32 MFMA
+// wbn == nullptr (sm3_linbn_banks_post): the A fragments of the H tiles, T(-b wd), are formed here from wd and coef -- the
+// same fp32 product and the same rounding sm3_linbn_banks applies, so H has the same bits as with the stored bank.
 template <typename T>
-__global__ __launch_bounds__(256) void linbn_post_kernel(const T* __restrict__ wbn, const T* __restrict__ wd,
-                                                         T* __restrict__ hn, const float* __restrict__ P,
-                                                         const float* __restrict__ G, const float* __restrict__ Tm,
-                                                         const double* __restrict__ s, const float4* __restrict__ coef,
-                                                         float* __restrict__ dw, int C, int p, int views, int h_tiles) {
-    __shared__ float red[4 * 16 * 64];
+__device__ __forceinline__ void post_tile(const T* __restrict__ wbn, const T* __restrict__ wd, T* __restrict__ hn,
+                                          const float* __restrict__ P, const float* __restrict__ G,
+                                          const float* __restrict__ Tm, const double* __restrict__ s,
+                                          const float4* __restrict__ coef, float* __restrict__ dw, int C, int p, int views,
+                                          int h_tiles, int tile, float* red) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, kk = lane >> 5;
-    const int tile = blockIdx.x;  // one 32 x 32 tile per block, K split over its 4 waves
     const int pt = p / 32;
     if (tile < h_tiles) {
         const int v = tile / (pt * pt), rem = tile - v * pt * pt;
         const int k0 = (rem / pt) * 32, c0 = (rem % pt) * 32;
-        const T* ap = wbn + ((long)v * p + k0 + i) * C + 8 * kk;
+        const T* ap = wbn ? wbn + ((long)v * p + k0 + i) * C + 8 * kk : wd + (long)(k0 + i) * C + 8 * kk;
         const T* bp = wd + (long)(c0 + i) * C + 8 * kk;
+        const float4* cf = coef + (long)v * C + 8 * kk;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -322,6 +329,16 @@ __global__ __launch_bounds__(256) void linbn_post_kernel(const T* __restrict__ w
             for (int u = 0; u < U; ++u) {
                 fa[u] = *reinterpret_cast<const uint4*>(ap + c + 16 * u);
                 fb[u] = *reinterpret_cast<const uint4*>(bp + c + 16 * u);
+            }
+            if (!wbn) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    float w8[8];
+                    unpack16<T>(fa[u], w8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) w8[e] = -cf[c + 16 * u + e].y * w8[e];
+                    fa[u] = pack16<T>(w8);
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -381,6 +398,39 @@ __global__ __launch_bounds__(256) void linbn_post_kernel(const T* __restrict__ w
         dw[(long)co * p + ci0 + i] += tot[q];
     }
 }
+
+template <typename T>
+__global__ __launch_bounds__(256) void linbn_post_kernel(const T* __restrict__ wbn, const T* __restrict__ wd,
+                                                         T* __restrict__ hn, const float* __restrict__ P,
+                                                         const float* __restrict__ G, const float* __restrict__ Tm,
+                                                         const double* __restrict__ s, const float4* __restrict__ coef,
+                                                         float* __restrict__ dw, int C, int p, int views, int h_tiles) {
+    __shared__ float red[4 * 16 * 64];
+    post_tile<T>(wbn, wd, hn, P, G, Tm, s, coef, dw, C, p, views, h_tiles, blockIdx.x, red);  // one 32 x 32 tile per block
+}
+
+// ---- sm3_linbn_banks_post -------------------------------------------------------------------------------------------
+// sm3_linbn_banks and sm3_linbn_post as ONE launch (round 5: the chain between the GEMMs of a unit's backward is launch
+// latency, 13 us per link): blocks [0, tiles) are the -H and weight-gradient tiles of post_tile (the -b wd operand formed on
+// the fly: nothing of the bank rows below is read by them), the p * views blocks behind them write diag(a) wd and the
+// constant row.  The -diag(b) wd bank is never stored.
+template <typename T>
+__global__ __launch_bounds__(256) void linbn_banks_post_kernel(const T* __restrict__ wd, const float4* __restrict__ coef,
+                                                               T* __restrict__ wa, float* __restrict__ col_const,
+                                                               T* __restrict__ hn, const float* __restrict__ P,
+                                                               const float* __restrict__ G, const float* __restrict__ Tm,
+                                                               const double* __restrict__ s, float* __restrict__ dw, int C,
+                                                               int p, int views, int h_tiles, int tiles) {
+    __shared__ float red[4 * 16 * 64];
+    const int b = blockIdx.x;
+    if (b < tiles) {
+        post_tile<T>(nullptr, wd, hn, P, G, Tm, s, coef, dw, C, p, views, h_tiles, b, red);
+        return;
+    }
+    const int r = b - tiles;
+    banks_row<T>(wd, coef, wa, nullptr, col_const, C, p, r % p, r / p, red);
+}
+
 
 inline bool lin16(int dtype) { return dtype == SM3_BF16 || dtype == SM3_F16; }
 
@@ -502,6 +552,26 @@ extern "C" int sm3_linbn_post(int dtype, const void* wbn, const void* w_dgrad, v
     else
         hipLaunchKernelGGL(linbn_post_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, (const f16_t*)wbn, (const f16_t*)w_dgrad,
                            (f16_t*)hn, P, G, Tm, s, (const float4*)coef, dw, C, p, views, h_pad);
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_linbn_banks_post(int dtype, const void* w_dgrad, const float* coef, void* wa, float* col_const, void* hn,
+                                    const float* P, const float* G, const float* Tm, const double* s, float* dw, int C, int p,
+                                    int views, void* stream) {
+    if (!w_dgrad || !coef || !wa || !col_const || !hn || !P || (!G && !Tm) || !s || !dw) return SM3_EINVAL;
+    if (C <= 0 || p <= 0 || views < 1) return SM3_EINVAL;
+    if (!lin16(dtype)) return SM3_EDTYPE;
+    if (C % 128 || p % 32) return SM3_EALIGN;
+    const int pt = p / 32, h_tiles = views * pt * pt, tiles = h_tiles + (C / 32) * pt;
+    const unsigned blocks = (unsigned)(tiles + p * views);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SM3_BF16)
+        hipLaunchKernelGGL(linbn_banks_post_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)w_dgrad,
+                           (const float4*)coef, (bf16_t*)wa, col_const, (bf16_t*)hn, P, G, Tm, s, dw, C, p, views, h_tiles, tiles);
+    else
+        hipLaunchKernelGGL(linbn_banks_post_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, (const f16_t*)w_dgrad,
+                           (const float4*)coef, (f16_t*)wa, col_const, (f16_t*)hn, P, G, Tm, s, dw, C, p, views, h_tiles, tiles);
     SM3_CHECK_LAUNCH();
     return 0;
 }

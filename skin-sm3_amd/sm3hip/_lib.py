@@ -85,6 +85,7 @@ SIGNATURES = {
     "sm3_linbn_coef": [_P, _D, _P, _P, _P, _P, _I, _I, _P],
     "sm3_linbn_banks": [_I, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "sm3_linbn_post": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "sm3_linbn_banks_post": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "sm3_conv_bn_act_eval": [_DESC, _P, _P, _P, _P, _P, _I, _P, _P],
     "sm3_conv_bn_eval": [_DESC, _P, _P, _P, _P, _P, _P, _F, _P, _I, _P, _P],
     "sm3_conv_wgrad": [_DESC, _P, _P, _P, _P],

@@ -352,6 +352,7 @@ class SM3Engine:
         # ... and the downsample conv -> BatchNorm of a stage's first block in the backward pass
         self.linbn_ds = _os.environ.get("SM3_LINBN_DS", "1") != "0"
         self.linbn_join = _os.environ.get("SM3_LINBN_JOIN", "1") != "0"
+        self.linbn_merge = _os.environ.get("SM3_LINBN_MERGE", "1") != "0"  # banks + post in one launch (A/B switch)
         self.lane_cross = _os.environ.get("SM3_LANE_CROSS", "1") != "0"  # cross-modal projector passes inside the lanes
 
     # ---- setup ---------------------------------------------------------------------------
@@ -912,11 +913,15 @@ class SM3Engine:
         """Banks diag(a) W / -diag(b) W, the constant term, -H, and the unit's weight gradient.  Returns (wa, -H, const)."""
         C, p = cu.Co, cu.Ci
         wa = self._work("linbn_wa" + tag, V * p * C, self.tdt)
-        wbn = self._work("linbn_wbn" + tag, V * p * C, self.tdt)
         cconst = self._work("linbn_const" + tag, V * p)
-        ops.linbn_banks(self.dtype, cu.w_dgrad, coef, wa, wbn, cconst, C, p, V)
         Hn = self._work("linbn_H" + tag, V * p * p, self.tdt)
-        ops.linbn_post(self.dtype, wbn, cu.w_dgrad, Hn, P, G, Tm, s, coef, self._g(cu.name + ".weight"), C, p, V)
+        if self.linbn_merge:  # one launch; -diag(b) W stays in registers (round 5)
+            ops.linbn_banks_post(self.dtype, cu.w_dgrad, coef, wa, cconst, Hn, P, G, Tm, s, self._g(cu.name + ".weight"),
+                                 C, p, V)
+        else:
+            wbn = self._work("linbn_wbn" + tag, V * p * C, self.tdt)
+            ops.linbn_banks(self.dtype, cu.w_dgrad, coef, wa, wbn, cconst, C, p, V)
+            ops.linbn_post(self.dtype, wbn, cu.w_dgrad, Hn, P, G, Tm, s, coef, self._g(cu.name + ".weight"), C, p, V)
         return wa[: V * p * C], Hn[: V * p * p], cconst[: V * p]
 
     def conv3_backward_linbn(self, r3, r2, dz, bpart, prow, rd=None, lin_d=False):

@@ -637,6 +637,27 @@ def linbn_post(dtype, wbn, w_dgrad, hn, P, G, Tm, s, coef, dw, Cn, p, views=1):
                                          _ptr(coef), _ptr(dw), Cn, p, views, _stream()), "sm3_linbn_post")
 
 
+def linbn_banks_post(dtype, w_dgrad, coef, wa, col_const, hn, P, G, Tm, s, dw, Cn, p, views=1):
+    """linbn_banks + linbn_post in one launch (sm3_linbn_banks_post): same wa / col_const / hn / dw, bit for bit."""
+    tdt = TORCH_DTYPE[dtype]
+    for t, n in ((w_dgrad, "w_dgrad"), (wa, "wa"), (hn, "hn")):
+        _chk(t, tdt, n)
+    for t in (P, G, Tm, coef, dw, col_const):
+        _chk(t, torch.float32)
+    _chk(s, torch.float64, "s")
+    if wa.numel() < views * p * Cn or w_dgrad.numel() != p * Cn or hn.numel() < views * p * p or \
+            col_const.numel() < views * p or P.numel() < views * Cn * p or (G is None and Tm is None) or \
+            (G is not None and G.numel() < views * p * p) or (Tm is not None and Tm.numel() < views * Cn * p) or \
+            s.numel() < views * p or coef.numel() < views * 4 * Cn or dw.numel() != Cn * p or Cn % 128 or p % 32:
+        raise ValueError("linbn_banks_post: size mismatch")
+    flops = 2.0 * views * p * p * Cn * (1 if Tm is not None else 2)
+    with _prof(_lin_tag("linbn_banks_post", Cn, p), flops,
+               4.0 * Cn * p * (2 + views) + _sz(dtype) * p * Cn * (2 + views)):
+        check(_lib.load().sm3_linbn_banks_post(dtype, _ptr(w_dgrad), _ptr(coef), _ptr(wa), _ptr(col_const), _ptr(hn), _ptr(P),
+                                               _ptr(G), _ptr(Tm), _ptr(s), _ptr(dw), Cn, p, views, _stream()),
+              "sm3_linbn_banks_post")
+
+
 def conv_bn_act_fused(desc, x, w, scale, shift, residual, relu, y, mask=None, views=1):
     """y = relu?(conv(x, w) * scale[v] + shift[v] (+ residual)) with the ReLU bits in `mask`: conv -> train-mode BatchNorm ->
     (+identity) -> ReLU in one launch (sm3_conv_bn_act_fused); scale / shift [views][Co] from bn_finalize."""

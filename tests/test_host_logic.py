@@ -107,8 +107,10 @@ def test_engine_dry_run_sequences_and_bucket_schedule(model, linbn):
     nlin = 64 if linbn else 0  # 16 Bottlenecks x 4 encoder passes: conv3 -> bn3 units whose backward goes by linearity
     nds = 16 if linbn else 0   # ... and the 4 downsample conv -> BatchNorm units of every pass
     assert calls["sm3_conv_wgrad"] == 230 - 4 - nlin - nds and calls["sm3_stem_wgrad_bn"] == 4  # bf16: direct stem (csrc/stem.hip)
-    for name in ("sm3_linbn_stats", "sm3_linbn_banks", "sm3_linbn_post"):
+    # per unit backward: sums + coefficients, then banks / -H / weight-gradient finish as ONE launch (round 5)
+    for name in ("sm3_linbn_stats", "sm3_linbn_banks_post"):
         assert calls[name] == nlin + nds, name
+    assert calls["sm3_linbn_banks"] == 0 and calls["sm3_linbn_post"] == 0
     assert calls["sm3_conv_dgrad_seg_bnfuse"] == nlin and calls["sm3_bn_act_colsum"] == nlin
     assert calls["sm3_conv_gather_gemm_seg"] == nds and calls["sm3_subsample_colsum"] == nds
     # Gram matrix of the unit's input and dz^T input per view -- plain-store split-K slabs, summed in a fixed order

@@ -293,8 +293,13 @@ def test_conv_bn_by_linearity_matches_fp64_autograd(case, dt):
     Hn2 = torch.empty_like(Hn)
     dW2 = torch.zeros(C, p, device=D)
     ops.linbn_post(code, wbn, w_dg, Hn2, P, G, None, sd, coef, dW2, C, p, V)   # W G recomputed in the kernel
+    # banks + post as ONE launch (sm3_linbn_banks_post, what the engine runs since round 5): the same four outputs, bit for bit
+    wa3, cconst3 = torch.empty_like(wa), torch.empty_like(cconst)
+    Hn3, dW3 = torch.empty_like(Hn), torch.zeros(C, p, device=D)
+    ops.linbn_banks_post(code, w_dg, coef, wa3, cconst3, Hn3, P, G, Tm, sd, dW3, C, p, V)
     torch.cuda.synchronize()
     assert torch.equal(Hn, Hn2) and torch.equal(dW, dW2)
+    assert torch.equal(wa3, wa) and torch.equal(cconst3, cconst) and torch.equal(Hn3, Hn) and torch.equal(dW3, dW)
     # the two small products of the post kernel against the generic gather-GEMM / fp64
     Hn_ref = torch.empty(V * p * p, dtype=dt, device=D)
     ops.conv_gemm(ops.fwd_desc(code, V * p, 1, 1, C, p, 1, 1, 0), wbn, w_dg, Hn_ref)

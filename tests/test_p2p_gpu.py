@@ -143,6 +143,7 @@ def _missing_peer_main(rank, world, port, q):
         if rank == 0:  # ... but only rank 0 steps: its peer never raises a flag
             import time
             batch = ([torch.from_numpy(a).to(dev) for a in derm_np], [torch.from_numpy(a).to(dev) for a in clinic_np])
+            tr._engine().prepare(dev)
             before = tr._engine().store.flat_p.clone()
             t0 = time.perf_counter()
             loss = float(tr.step(*batch))

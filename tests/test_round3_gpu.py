@@ -98,9 +98,13 @@ def test_fp16_mode_against_the_oracle_448():
     print(f"448x448 B=16 fp16: loss {loss:.4f} vs fp32 oracle {ref_loss:.4f}; gradient cosine {cos:.3f}; |g| {float(g.norm()):.4f} vs "
           f"{float(gref.norm()):.4f}; loss scale in force {scale} after {attempt} skipped step(s)")
     assert taken == 1 and bool(torch.isfinite(g).all())
-    assert abs(loss - ref_loss) < 0.2            # measured 0.109 of 13.37 (logits behind a 1 / 0.1 temperature)
-    assert cos >= 0.65                           # measured 0.745
-    assert abs(float(g.norm()) - float(gref.norm())) < 0.10 * float(gref.norm())   # measured +4.7 %
+    # These figures are reproducible run to run on one build (the only run-to-run noise of a single step is 4e-7 of |g|);
+    # they move from BUILD to build with where the 16-bit roundings fall: r04 0.109 / 0.745 / +4.7 %, r05 (K order of the
+    # 3x3 launches that do not fit the halo kernel changed) 0.116 / 0.724 / +7.2 %.  Bounds = about twice the largest
+    # deviation seen; a wrong gradient (cosine ~ 0) or a wrong scale (|g| off by 2x) is far outside them.
+    assert abs(loss - ref_loss) < 0.3            # of 13.37 (logits behind a 1 / 0.1 temperature)
+    assert cos >= 0.6
+    assert abs(float(g.norm()) - float(gref.norm())) < 0.15 * float(gref.norm())   # measured +4.7 % (r04), +7.2 % (r05 build)
 
 
 def test_fp16_gradscaler_backoff_sequence_b4():
@@ -214,25 +218,35 @@ def _probe_auroc(model, train_set, test_set):
 
 
 def test_T2_linear_probe_auroc_after_stream_training():
-    """SURVEY.md 8c T2, the AUROC half: 128 SSL steps on a STREAM of 16 distinct batches of 64 learnable
-    pairs (1 024 samples) from one initialisation in exact f32 (twice: the run-to-run spread of float-atomic weight
-    gradients), fp16 + loss scaling and bf16; then a linear probe on the frozen encoders, 2 048 training and 2 048 held-out
-    labelled samples of the same distribution.  The probe must be informative -- f32 AUROC >= 0.85, above the untrained
-    encoder's -- and fp16 must end within 2e-2 of the f32 runs, bf16 within 4.5e-2 (measured: f32 0.910 / 0.918 and 0.916 /
-    0.918, fp16 0.916 / 0.917, bf16 0.903 / 0.884; untrained 0.863).  north_star's 1e-3 is below the f32 run-to-run spread
-    of this stochastic pipeline (0.002 - 0.008: float-atomic weight gradients)."""
+    """SURVEY.md 8c T2, the AUROC half: 128 SSL steps on a STREAM of 16 distinct batches of 64
+    learnable pairs (1 024 samples) from one initialisation in exact f32 (twice), fp16 + loss scaling and bf16 (twice); then a
+    linear probe on the frozen encoders, 2 048 training and 4 096 held-out labelled samples of the same distribution, AUROC
+    by the reference's rule (src/utils/misc.py:299-327).
+
+    What the statistic can resolve was measured in round 5 (scratch/r5_auroc_spread.py, three trainings per mode on one
+    build, plus the pairs earlier rounds recorded): a single training's AUROC scatters with sigma ~ 0.004 (f32, fp16) and
+    ~ 0.009 (bf16) from run to run -- the float-atomic weight-gradient sums of the stem / layer 1 decide which of the
+    model's trajectories a run falls into -- and moves by < 0.005 between 2 048 and 8 192 held-out
+    samples: the noise is the TRAINING's, not the estimator's, so a larger held-out set does not tighten anything.
+      untrained 0.863;  f32 0.898 .. 0.918 (12 runs, 3 builds; within a build the two runs differ by 0.001 .. 0.009);
+      fp16 0.909 .. 0.918 (6 runs);  bf16 0.884 .. 0.910 (6 runs: mean 0.898, i.e. 0.012 below f32's 0.910).
+    Asserted (k sigma in brackets): every run >= 0.85 and the mode means above the untrained encoder + 0.01 (bf16 mean of
+    two: 3.6); the two f32 runs within 2e-2 (3.6); fp16 within 2.5e-2 of the f32 mean (3.8); the bf16 MEAN OF TWO within
+    4.5e-2 (its expected offset 0.012 + 3.8 sigma of the difference of the two means, 0.0086).  north_star's 1e-3 is a
+    quarter of the f32 run-to-run sigma of this pipeline."""
     from sm3hip.trainer import SM3Trainer
     from src.models.simclr import SimCLRSkinV32
     S, nb, B, steps = 64, 16, 64, 128
     torch.manual_seed(5)
     init = {k: v.clone() for k, v in SimCLRSkinV32("resnet50", None, 128, 0.1).state_dict().items()}
     tr_d, tr_c, tr_y = _latent_set(2048, S, 7, dc=1.0)
-    te_d, te_c, te_y = _latent_set(2048, S, 8, dc=1.0)
+    te_d, te_c, te_y = _latent_set(4096, S, 8, dc=1.0)
     train_set, test_set = (tr_d[0], tr_c[0], tr_y), (te_d[0], te_c[0], te_y)
     stream = [_latent_set(B, S, 100 + i, views=2, dc=1.0)[:2] for i in range(nb)]
     untrained = _probe_auroc(_build(0, torch.float32, init), train_set, test_set)
     aucs, last = {}, {}
-    for name, dt in (("f32", torch.float32), ("f32_again", torch.float32), ("f16", torch.float16), ("bf16", torch.bfloat16)):
+    for name, dt in (("f32", torch.float32), ("f32_again", torch.float32), ("f16", torch.float16), ("bf16", torch.bfloat16),
+                     ("bf16_again", torch.bfloat16)):
         model = _build(0, dt, init)
         tr = SM3Trainer(model, lr=1e-3, weight_decay=5e-2, eps=1e-5, style=0, init_scale=1024.0)
         losses = [float(tr.step(*stream[s % nb])) for s in range(steps)]
@@ -246,14 +260,14 @@ def test_T2_linear_probe_auroc_after_stream_training():
           {k: round(v, 3) for k, v in last.items()})
     assert untrained > 0.75
     for k in aucs:
-        assert aucs[k] >= 0.85 and aucs[k] > untrained + 0.01, (k, aucs, untrained)    # the SSL steps helped, in every mode
+        assert aucs[k] >= 0.85, (k, aucs, untrained)                                     # an informative probe in every run
         assert last[k] < 6.0, (k, last)                                                  # ... and the loss came down (13 -> ~3)
     ref = 0.5 * (aucs["f32"] + aucs["f32_again"])
+    bf16 = 0.5 * (aucs["bf16"] + aucs["bf16_again"])
+    assert ref > untrained + 0.02 and aucs["f16"] > untrained + 0.02 and bf16 > untrained + 0.01, (aucs, untrained)
     assert abs(aucs["f32"] - aucs["f32_again"]) < 2e-2, aucs
-    assert abs(aucs["f16"] - ref) < 2e-2, aucs
-    # bf16 ends systematically a little lower (8 significand bits in every activation and in the probe's features): measured
-    # -0.011 and -0.033 in two runs against f32 runs that differ by 0.002 / 0.008 from each other
-    assert abs(aucs["bf16"] - ref) < 4.5e-2 and aucs["bf16"] > untrained + 0.01, aucs
+    assert abs(aucs["f16"] - ref) < 2.5e-2, aucs
+    assert abs(bf16 - ref) < 4.5e-2, aucs
 
 
 def test_T2_loss_trajectories():
@@ -294,6 +308,9 @@ def test_T2_loss_trajectories():
         d = np.abs(c - f32)
         print(f"loss {name}", np.round(c[pick], 3), "max |d|", round(float(d.max()), 3), "max |d| / f32",
               round(float((d / np.maximum(f32, 1e-3)).max()), 3))
+        # (how much of the band is used: 1.0 = on its edge; printed so that a shrinking margin is seen before it fails)
+        used = np.maximum((0.65 * lo - 0.05 - c) / (0.35 * lo + 0.05) + 1.0, (c - 1.35 * hi - 0.05) / (0.35 * hi + 0.05) + 1.0)
+        print(f"     {name}: band use {float(used.max()):.2f} at step {int(used.argmax())}")
         assert ((c >= 0.65 * lo - 0.05) & (c <= 1.35 * hi + 0.05)).all(), (name, np.round(c, 3), np.round(f32, 3))
         assert abs(c[0] - f32[0]) < (0.3 if name == "f16" else 1.0)               # same starting point (B = 16: 0.09 / ~0.3)
         assert c[-3:].mean() < 0.3                                                  # same end state
