@@ -49,6 +49,15 @@ struct WgradParams {
     int slab_cap;      // slabs available per view
 };
 
+#ifdef SM3_STAMP
+// Diagnostic build only (scratch/build_stamp.sh, scratch/stamp_wgrad.py; in the product library no stamp executes): s_memtime
+// at the segment boundaries of the ring loop, summed per wave -- wait (counted vmcnt), barrier, issue (DMA of the stage NST - 1
+// ahead), compute (transposing fragment reads + MFMA issue) -- plus entry / loop / exit marks; one 16-word record per wave.
+__device__ unsigned long long* g_wstamp_buf = nullptr;
+__device__ long g_wstamp_cap = 0;
+#define SM3_WSTAMP_NOW() __builtin_amdgcn_s_memtime()
+#endif
+
 using sm3conv::dma16;       // LDS-DMA from inline asm, zero-fill by the buffer range check: see conv_common.h
 using sm3conv::dma_drain;
 using sm3conv::kOOB;
@@ -74,7 +83,9 @@ template <typename T, int BMW, int BNW, int KP, bool DENSE, int NST, int KG = 1>
 #ifndef SM3_WGRAD_OCC
 #define SM3_WGRAD_OCC 0  // build-time A/B: 4 = cap the tap-shifted (3x3 / strided) kernel at 128 registers -> 4 workgroups per CU
 #endif
-__global__ __launch_bounds__(256 * KG, (NST == 1 || (SM3_WGRAD_OCC && !DENSE && KG == 1)) ? 4 : 1) void conv_wgrad_kernel(const WgradParams p) {
+// (two K-groups on a 2-stage ring of 32-pixel steps: 64 KB of LDS, two 512-thread workgroups = 4 waves per SIMD at <= 128
+// registers -- the round-5 variant of the dense kernel, see launch_wgrad)
+__global__ __launch_bounds__(256 * KG, (NST == 1 || (SM3_WGRAD_OCC && !DENSE && KG == 1)) ? 4 : (DENSE && KG == 2 && NST == 2 && KP == 32) ? 4 : 1) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int SZ = sizeof(T);
     constexpr bool kBf16 = (SZ == 2);
     constexpr int RA = BMW * SZ, RB = BNW * SZ;                 // bytes per tile row (one pixel)
@@ -88,6 +99,10 @@ __global__ __launch_bounds__(256 * KG, (NST == 1 || (SM3_WGRAD_OCC && !DENSE && 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave = wave_all & 3, grp = wave_all >> 2;  // role inside the group of 4 waves; K-group
+#ifdef SM3_STAMP
+    const unsigned long long st_entry = SM3_WSTAMP_NOW(), st_rentry = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st_seg[4] = {0, 0, 0, 0}, st_loop0 = 0, st_loop1 = 0;
+#endif
     const int wm = wave >> 1, wn = wave & 1;
 
     // Block -> (tile, pixel slice).  Workgroups are dealt round-robin over the 8 XCDs, so id & 7 labels the
@@ -242,8 +257,15 @@ __global__ __launch_bounds__(256 * KG, (NST == 1 || (SM3_WGRAD_OCC && !DENSE && 
     // NST = 1 (round 4, the lesson of the forward kernel): ONE stage of KP pixels, nothing in flight while it is computed --
     // the workgroups of a CU (four at 32 KB and 128 registers) overlap each other instead of a ring overlapping itself
     for (int s = 0; s < NST - 1 && s < nsteps; ++s) dma_stage(s, s);
+#ifdef SM3_STAMP
+    st_loop0 = SM3_WSTAMP_NOW();
+#endif
 
     for (int s = 0; s < nsteps; ++s) {
+#ifdef SM3_STAMP
+        const unsigned long long q0 = SM3_WSTAMP_NOW();
+        unsigned long long q1 = q0, q2 = q0, q3 = q0;
+#endif
         if constexpr (NST == 1) {
             if (s > 0) __syncthreads();  // everyone is done computing stage s - 1
             dma_stage(0, s);
@@ -254,9 +276,18 @@ __global__ __launch_bounds__(256 * KG, (NST == 1 || (SM3_WGRAD_OCC && !DENSE && 
             if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
             else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
             else dma_drain();
+#ifdef SM3_STAMP
+            q1 = SM3_WSTAMP_NOW();
+#endif
             __syncthreads();  // stage s has landed for everyone; everyone is done computing stage s - 1
+#ifdef SM3_STAMP
+            q2 = SM3_WSTAMP_NOW();
+#endif
             if (s + NST - 1 < nsteps) dma_stage((s + NST - 1) % NST, s + NST - 1);
         }
+#ifdef SM3_STAMP
+        q3 = SM3_WSTAMP_NOW();
+#endif
         const char* sS = smem + (grp * NST + s % NST) * STAGE;
         if constexpr (kBf16) {
 #pragma unroll
@@ -301,12 +332,33 @@ __global__ __launch_bounds__(256 * KG, (NST == 1 || (SM3_WGRAD_OCC && !DENSE && 
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }
         }
+#ifdef SM3_STAMP
+        const unsigned long long q4 = SM3_WSTAMP_NOW();
+        st_seg[0] += q1 - q0; st_seg[1] += q2 - q1; st_seg[2] += q3 - q2; st_seg[3] += q4 - q3;
+#endif
     }
+#ifdef SM3_STAMP
+    st_loop1 = SM3_WSTAMP_NOW();
+    struct WStampOut {
+        unsigned long long e, re, l0, l1, *seg; int ns, grp, wave;
+        __device__ ~WStampOut() {
+            const long w = (long)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+            if ((threadIdx.x & 63) == 0 && g_wstamp_buf && w < g_wstamp_cap) {
+                unsigned long long* o = g_wstamp_buf + w * 16;
+                o[0] = e; o[1] = l0; o[2] = l1; o[3] = __builtin_amdgcn_s_memtime();
+                o[4] = seg[0]; o[5] = seg[1]; o[6] = seg[2]; o[7] = seg[3];
+                o[8] = (unsigned long long)ns; o[9] = blockIdx.x; o[10] = re; o[11] = __builtin_amdgcn_s_memrealtime();
+                o[12] = (unsigned long long)grp; o[13] = (unsigned long long)wave;
+            }
+        }
+    } st_out{st_entry, st_rentry, st_loop0, st_loop1, st_seg, nsteps, grp, wave};
+#endif
 
     if constexpr (KG == 2) {
-        static_assert(NST * STAGE >= BMW * BNW * 4, "group 1's tile must fit its own stage ring");
+        static_assert(KG * NST * STAGE >= BMW * BNW * 4, "group 1's tile must fit the workgroup's LDS");
         __syncthreads();  // both groups are done with their rings
-        float* xch = reinterpret_cast<float*>(smem + NST * STAGE);  // group 1's ring: [wave][register][lane]
+        // hand-over area [wave][register][lane]: group 1's own ring where that is large enough, else the whole LDS
+        float* xch = reinterpret_cast<float*>(smem + (NST * STAGE >= BMW * BNW * 4 ? NST * STAGE : 0));
         if (grp == 1) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -448,6 +500,13 @@ int launch_wgrad(WgradParams p, hipStream_t st) {
         // five workgroups per CU (A/B switches, read at every launch)
         const char* kgv = getenv("SM3_WGRAD_KG");
         const bool kg2 = !(kgv && atoi(kgv) == 1);
+        if constexpr (sizeof(T) == 2) {
+            // SM3_WGRAD_DENSE_VAR (A/B, read at every launch): 1 = two K-groups on a 2-stage ring of 32-pixel steps (64 KB: two
+            // workgroups = 4 waves per SIMD overlap each other), 2 = the same ring with 64-pixel steps (128 KB, half the barriers)
+            const int var = env_int("SM3_WGRAD_DENSE_VAR", 0);
+            if (kg2 && var == 1) return launch_wgrad_kp<T, BMW, BNW, 32, true, 2, 2>(p, st);
+            if (kg2 && var == 2) return launch_wgrad_kp<T, BMW, BNW, 64, true, 2, 2>(p, st);
+        }
         if (kg2) return launch_wgrad_kp<T, BMW, BNW, KP, true, 4, 2>(p, st);
         const char* nv = getenv("SM3_WGRAD_DENSE_NST");
         if (nv && atoi(nv) == 2) return launch_wgrad_kp<T, BMW, BNW, KP, true, 2>(p, st);
@@ -521,6 +580,15 @@ static int wgrad_impl(const sm3_conv_desc* d, const void* x, const void* dy, flo
     if (nci) return launch_wgrad<float, 128, 64>(p, st);
     return launch_wgrad<float, 128, 128>(p, st);
 }
+
+#ifdef SM3_STAMP
+extern "C" int sm3_debug_set_wgrad_stamps(void* buf, long capacity_waves) {
+    unsigned long long* b = (unsigned long long*)buf;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_wstamp_buf), &b, sizeof(b)) != hipSuccess) return SM3_EINVAL;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_wstamp_cap), &capacity_waves, sizeof(long)) != hipSuccess) return SM3_EINVAL;
+    return 0;
+}
+#endif
 
 extern "C" int sm3_conv_wgrad(const sm3_conv_desc* d, const void* x, const void* dy, float* dw, void* stream) {
     return wgrad_impl(d, x, dy, dw, nullptr, 0, nullptr, 1, 0, 0, stream);

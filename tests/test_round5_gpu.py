@@ -3,11 +3,17 @@
 The whole-step comparisons of bf16 against f32 (tests/test_round3_gpu.py, test_round4_gpu.py) go through the 1 / 0.1
 temperature behind BatchNorm1d + L2-normalise: a 3 % feature error becomes an O(1) logit error and the gradient's direction
 is lost at ANY state (whole-gradient cosine 0.1 - 0.4, torch's own bf16 autocast included), so their floors (0.15) pass
-almost anything.  What those floors cannot see -- a tap, halo or stride addressing bug confined to one stage of the encoder
--- is well conditioned once the loss is taken out of the loop: the SAME upstream gradient d(features) through the bf16
-encoder and through the exact-f32 encoder, at the network's real map sizes (224 x 224: the halo-resident 3x3 kernels, the
-pointwise 1x1 variants, the strided data gradients, the linear BatchNorm forms -- what bench.py runs), compared tensor by
-tensor.
+almost anything.  What those floors cannot see is a tap, halo or stride addressing bug confined to one stage of the encoder.
+Two comparisons of a 16-bit ResNet-50 encoder against the exact-f32 encoder, tensor by tensor, at the network's real map
+sizes (224 x 224: the halo-resident 3x3 kernels, the pointwise 1x1 variants, the strided data gradients, the direct stem --
+what bench.py runs), same weights, same images, same upstream gradient, NO loss in the loop:
+
+  * frozen BatchNorm statistics (eval mode with trainable parameters): well conditioned -- bf16 agrees with f32 to a cosine
+    of 0.9998 or better in EVERY parameter tensor, fp16 to 0.99999.  This is the anchor that can fail.
+  * batch statistics (train mode): what was measured is that taking the loss out does NOT restore bf16's direction (cosine
+    0.14 over the whole gradient, about 0 for some BatchNorm tensors) while fp16 keeps 0.67 - 0.81 per stage: the
+    amplification sits in the 53 train-mode BatchNorms themselves.  fp16 (same kernel templates) carries per-stage floors,
+    bf16 the magnitudes.
 """
 import pytest
 import torch
@@ -48,14 +54,15 @@ def _stage(name):
 
 @pytest.mark.parametrize("dtname", ["bf16", "f16"])
 def test_16bit_encoder_gradients_per_tensor_against_exact_f32_at_224(dtname):
-    """ResNet-50 encoder, 16 images of 224 x 224 as two views of 8 (per-view BatchNorm statistics, both views in one batch:
-    the benchmarked form), train mode, one upstream gradient for all modes.  Per parameter tensor: cosine and norm ratio of
+    """ResNet-50 encoder, 16 images of 224 x 224 in one pass (one view: two views in one batch need 128 images each for
+    the 7 x 7 maps to fill whole tiles -- tests/test_config_gpu.py runs that form at B = 256), train mode, one upstream
+    gradient for all modes.  Per parameter tensor: cosine and norm ratio of
     the 16-bit gradient against the exact-f32 mode's; per stage the WORST tensor is what is asserted.  A gradient that is
     wrong in one stage (a shifted tap, a halo row read from the neighbouring image, a mask bit off by one channel) drops
     that stage's cosine to ~0; rounding noise does not: measured values in the assertion's comment."""
     dt = {"bf16": torch.bfloat16, "f16": torch.float16}[dtname]
     g = torch.Generator().manual_seed(17)
-    N, views = 16, 2
+    N, views = 16, 1
     # image-like inputs (per-image colour offset + a smooth pattern + noise): N(0,1) noise images are the worst-conditioned
     # input there is for 53 train-mode BatchNorms (SURVEY.md 8c)
     base = torch.nn.functional.interpolate(torch.randn(N, 3, 7, 7, generator=g), size=(224, 224), mode="bilinear")
@@ -87,11 +94,69 @@ def test_16bit_encoder_gradients_per_tensor_against_exact_f32_at_224(dtname):
         assert lim["ratio"][0] < w[2] and w[3] < lim["ratio"][1], (s, w)
 
 
-# measured on MI355X (round 5, gpurun_out/r5c): see the print of the test; bounds = measured value minus a margin of about
-# a third of its distance to 1 (cosines), features / ratios likewise
+def _eval_grads(dtype, state, x):
+    import resnet
+    m = resnet.resnet50(weights=None)
+    m.fc = torch.nn.Identity()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    m.sm3_dtype = dtype
+    m.to(DEV).eval()
+    f = m(x.to(DEV))
+    (f.double() ** 2).sum().backward()
+    torch.cuda.synchronize()
+    return f.detach().double().cpu(), {k: p.grad.detach().double().cpu() for k, p in m.named_parameters()}
+
+
+@pytest.mark.parametrize("dtname", ["bf16", "f16"])
+def test_16bit_eval_mode_encoder_gradients_per_tensor_at_224(dtname):
+    """The same comparison with FROZEN BatchNorm statistics (module.eval() with trainable parameters: the frozen-encoder
+    modes of tools/backbone_eval.py / mlc_train.py, src/models/simclr.py:393-396).  Without batch statistics in the loop the
+    backward pass is well conditioned (the exact-f32 path holds 2e-3 per tensor against fp64 here:
+    tests/test_config_gpu.py::test_eval_mode_backward_through_an_encoder), so THIS is where a 16-bit gradient can be pinned
+    tensor by tensor: every convolution's data- and weight-gradient kernel at the network's real map sizes (halo-resident
+    and strided 3x3, pointwise 1x1, the direct stem), bf16 and fp16 against exact f32 on the same weights and images."""
+    from oracle import procedural
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16}[dtname]
+    state = procedural.make_state_dict(procedural.resnet50_spec(""), seed=17)
+    x = torch.from_numpy(procedural.make_images(16, 224, 17, "derm0"))
+    f32, g32 = _eval_grads(torch.float32, state, x)
+    f16, g16 = _eval_grads(dt, state, x)
+    ferr = float((f16 - f32).norm() / f32.norm())
+    worst = {}
+    for n, ref in g32.items():
+        got = g16[n]
+        cos = float((got * ref).sum() / (got.norm() * ref.norm() + 1e-300))
+        ratio = float(got.norm() / (ref.norm() + 1e-300))
+        w = worst.setdefault(_stage(n), [1.0, n, 1.0, 1.0])
+        if cos < w[0]:
+            w[0], w[1] = cos, n
+        w[2], w[3] = min(w[2], ratio), max(w[3], ratio)
+    print(f"{dtname} eval-mode encoder at 224: features rel. error {ferr:.5f}; per stage "
+          + "; ".join(f"{s}: worst cosine {w[0]:.5f} ({w[1]}), |g| ratio {w[2]:.4f}..{w[3]:.4f}" for s, w in sorted(worst.items())))
+    lim = EVAL_BOUNDS[dtname]
+    assert ferr < lim["features"], ferr
+    for s, w in worst.items():
+        assert w[0] > lim["cos"], (s, w)
+        assert lim["ratio"][0] < w[2] and w[3] < lim["ratio"][1], (s, w)
+
+
+# measured (r5d, MI355X): bf16 features 5.0e-3, worst tensor per stage 0.99979 .. 0.99992, |g| ratio 0.989 .. 1.000;
+# fp16 6.2e-4, 0.99999 .. 1.00000, 0.998 .. 1.001.  Bounds: about 5x the measured distance from 1 -- a tap shifted by one
+# pixel or one stage's mask off by a channel leaves its tensors at cosine < 0.9.
+EVAL_BOUNDS = {"bf16": {"features": 2e-2, "cos": 0.999, "ratio": (0.97, 1.02)},
+               "f16": {"features": 3e-3, "cos": 0.9999, "ratio": (0.995, 1.005)}}
+
+# TRAIN mode, measured (r5d): fp16 features 1.8e-2, whole-gradient cosine 0.714, worst tensor per stage 0.665 (layer1) /
+# 0.676 / 0.717 / 0.805 (layer4) / 0.710 (stem), |g| ratio 0.85 .. 1.21 -- floors at about 3/4 of the measured values: an
+# addressing bug in ONE stage drops that stage's worst tensor to ~0 while fp16's rounding noise does not, and bf16 and fp16
+# run the SAME kernel templates (the MFMA builtin and the conversions are all that differs).
+# bf16: features 9.3e-2, |g| ratio 0.82 .. 1.23 -- and NO direction: whole-gradient cosine 0.138, worst tensors -0.02 ..
+# 0.35, although the loss is not in the loop.  Batch statistics through 53 BatchNorms amplify 8-bit significands to O(1)
+# direction errors at random init (PyTorch's own fp32 run is 1.6 % off its fp64 run here: tests/test_config_gpu.py::
+# test_train_mode_encoder_gradients_...), so for bf16 the train-mode test pins magnitudes only; its direction is pinned
+# where it is defined -- frozen statistics, above -- and its training behaviour by T2 (tests/test_round3_gpu.py).
+_ST = ("stem", "layer1", "layer2", "layer3", "layer4")
 BOUNDS = {
-    "bf16": {"features": 1.0, "whole": -1.0, "stage": {"stem": -1.0, "layer1": -1.0, "layer2": -1.0, "layer3": -1.0, "layer4": -1.0},
-             "ratio": (0.0, 1e9)},
-    "f16": {"features": 1.0, "whole": -1.0, "stage": {"stem": -1.0, "layer1": -1.0, "layer2": -1.0, "layer3": -1.0, "layer4": -1.0},
-            "ratio": (0.0, 1e9)},
+    "bf16": {"features": 0.2, "whole": -1.0, "stage": {s: -1.0 for s in _ST}, "ratio": (0.6, 1.6)},
+    "f16": {"features": 0.04, "whole": 0.6, "stage": {s: 0.5 for s in _ST}, "ratio": (0.7, 1.4)},
 }
