@@ -395,6 +395,19 @@ int sm3_weight_prep_batch_if(int dtype, const sm3_wprep_item* items_device, int 
 int sm3_cast_from_f32(int dtype, const float* src, void* dst, int64_t n, void* stream);
 int sm3_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, void* stream);
 
+/* conv2 of a Bottleneck reading conv1's RAW output (resnet.py:144-150: conv1 -> bn1 -> relu -> conv2): ONE launch computes
+ *   act = relu(x_raw * in_scale[v] + in_shift[v])  (bn1's train-mode apply + ReLU, the arithmetic of sm3_bn_act),
+ *   y = conv3x3(act) + BatchNorm partial sums of y (as sm3_conv_gather_gemm),
+ * writing act (same layout as x_raw) and its ReLU bits (1 byte per 16-byte vector, as sm3_bn_act's mask) on the side: the
+ * affine runs on the halo-resident A image in LDS, so bn1's separate apply pass (one read of x_raw, one launch) disappears.
+ * Bit-identical to sm3_bn_act followed by sm3_conv_gather_gemm.  Only for launches the halo-resident kernel takes --
+ * stride-1 full 3 x 3, 16-bit, more than 256 workgroups, the A image within a quarter of a CU's LDS:
+ * sm3_conv3x3_bnin_ok(d, views) == 1; anything else returns SM3_EINVAL and the caller keeps the two-pass form.
+ * in_scale / in_shift: [views][Ci]; views = 2: two views back to back, each a multiple of 128 rows. */
+int sm3_conv3x3_bnin_ok(const sm3_conv_desc* d, int views);
+int sm3_conv3x3_bnin(const sm3_conv_desc* d, const void* x_raw, const float* in_scale, const float* in_shift, int views,
+                     void* act_out, uint8_t* mask_out, const void* w, void* y, float* stat_partials, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * NT-Xent.  replaces F.normalize + matmul + mask/select + /T (simclr.py:62-88, 294-320) and
  * nn.CrossEntropyLoss (tools/backbone_train.py:531, applied :101-102,119-120).

@@ -58,6 +58,13 @@ struct ConvParams {
     uint32_t w_view_bytes, w1_view_bytes;
     const float* col_bias;  // [views][Co] f32 added to the accumulators (before the addend), or null
     int halo_rows, halo_a_bytes, halo_stat_off;  // kVarHalo (conv_igemm.hip): rows of the A image, its bytes, statistics scratch
+    // kVarHaloBn (sm3_conv3x3_bnin): x is the PRODUCER convolution's raw output; its train-mode BatchNorm + ReLU
+    // (in_scale / in_shift [views][Ci]) is applied to the staged A image in LDS, and the activation (in_act, same layout as
+    // x) + its ReLU bits (in_mask, 1 byte per 16-byte vector) are written for the rows of this tile
+    const float* in_scale;
+    const float* in_shift;
+    char* in_act;
+    uint8_t* in_mask;
     // K order of a 16-bit stride-1 3 x 3 launch: 1 = chunk outer, tap inner -- the order of kVarHalo, taken by EVERY lean kernel
     // such a launch can reach (general gather, 4-stage deep, 8-wave; every epilogue), so that the bits of a layer's output do
     // not depend on which of them the grid size selects (B vs 2B, both views in one batch vs per-view passes); 0 = tap outer

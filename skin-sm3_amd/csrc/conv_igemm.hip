@@ -95,13 +95,19 @@ struct StampRec {
 //              tap falls outside the image read the zero row); only the B tile is staged per K-step.  18 - 22 KB of A per
 //              nine K-steps instead of 144: these launches drew ~15 TB/s through L2 -> LDS, 85 % of what LDS-DMA delivers
 //              from L2 (MI355X_MICROARCH.md, "Indexed rows: gather into LDS").  K order: chunk outer, tap inner.
-constexpr int kVarSplit = 1, kVarPw = 2, kVarNoX = 4, kVarM16 = 8, kVarHalo = 16;
+//   kVarHaloBn (with kVarHalo, plain epilogue): the A tensor is the RAW output of the producer convolution; every thread
+//              applies the producer's BatchNorm affine + ReLU to the LDS-DMA pieces IT staged (after its own vmcnt wait,
+//              before the barrier that publishes the image: no extra barrier), in the arithmetic of bn_act_kernel, and
+//              writes the activation and its ReLU bits for the tile's own 128 rows -- the producer's separate apply pass
+//              (one read of that tensor and one launch per Bottleneck) disappears (forward half).
+constexpr int kVarSplit = 1, kVarPw = 2, kVarNoX = 4, kVarM16 = 8, kVarHalo = 16, kVarHaloBn = 32;
 template <typename T, int BM, int BN, int WM, int WN, int STAGES, int EPI, bool SEG = false, int VAR = 0>
 // registers: the 1-stage kernels (34 KB of LDS) run 4 workgroups per CU = 4 waves per SIMD, so their epilogues must fit 128
 // registers; the 2- and 4-stage kernels are limited to 2 / 1 workgroups per CU by their LDS and may use 256
 __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * WN == 8 && STAGES == 1) ? 8 : ((EPI >= 1 && STAGES == 1) || (VAR & kVarSplit)) ? 4 : 2)) void conv_igemm_kernel(const ConvParams p) {
     constexpr bool SPLIT = (VAR & kVarSplit) != 0, PW = (VAR & kVarPw) != 0, NOX = (VAR & kVarNoX) != 0;
-    constexpr bool M16 = (VAR & kVarM16) != 0, HALO = (VAR & kVarHalo) != 0;
+    constexpr bool M16 = (VAR & kVarM16) != 0, HALO = (VAR & kVarHalo) != 0, HALOBN = (VAR & kVarHaloBn) != 0;
+    static_assert(!HALOBN || (HALO && EPI == 1), "kVarHaloBn: the plain forward epilogue of the halo kernel");
     static_assert(!HALO || (EPI >= 1 && STAGES == 1 && !SEG && !(VAR & (kVarSplit | kVarPw | kVarM16)) && sizeof(T) == 2 && WM * WN == 4),
                   "kVarHalo: 16-bit lean one-stage kernels, 4 waves");
     static_assert(!M16 || (EPI >= 1 && sizeof(T) == 2 && !SPLIT), "kVarM16: 16-bit lean epilogues");
@@ -415,6 +421,17 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
                 const unsigned long long q1 = SM3_STAMP_NOW();
 #endif
                 if (tt == 0) halo_issue((uint32_t)c * 128u);
+                // kVarHaloBn: the producer's scale / shift of this lane's 8 channels of the chunk, requested before the wait
+                float4 bsc0 = make_float4(0.f, 0.f, 0.f, 0.f), bsc1 = bsc0, bsh0 = bsc0, bsh1 = bsc0;
+                if constexpr (HALOBN) {
+                    if (tt == 0) {
+                        const int ch0 = tile_view * p.Ci + c * (128 / SZ) + (int)(a_chunk >> 4) * (16 / SZ);
+                        bsc0 = *reinterpret_cast<const float4*>(p.in_scale + ch0);
+                        bsc1 = *reinterpret_cast<const float4*>(p.in_scale + ch0 + 4);
+                        bsh0 = *reinterpret_cast<const float4*>(p.in_shift + ch0);
+                        bsh1 = *reinterpret_cast<const float4*>(p.in_shift + ch0 + 4);
+                    }
+                }
                 const uint32_t soff_b = (uint32_t)p.wtap[tt] * row_bytes + (uint32_t)c * 128u;
 #pragma unroll
                 for (int i = 0; i < BI; ++i) dma16(rw, sBw + i * (RPP * 128), b_off[i], soff_b);
@@ -433,6 +450,45 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
                 const unsigned long long q2 = SM3_STAMP_NOW();
 #endif
                 dma_drain();
+                if constexpr (HALOBN) {
+                    if (tt == 0) {
+                        // y = relu(x * scale + shift) on the pieces THIS thread staged (they have landed: vmcnt(0) above), in
+                        // place, before the barrier publishes the image.  Rows outside the tensor keep their zero fill (no tap
+                        // that is inside its image ever reads them); rows HR.. are the zero rows.
+                        const float sc[8] = {bsc0.x, bsc0.y, bsc0.z, bsc0.w, bsc1.x, bsc1.y, bsc1.z, bsc1.w};
+                        const float sh[8] = {bsh0.x, bsh0.y, bsh0.z, bsh0.w, bsh1.x, bsh1.y, bsh1.z, bsh1.w};
+                        char* const lbase = smem + wave * (8 * 128) + lane * 16;
+                        const long gch = (long)c * 128 + (long)a_chunk;  // byte offset of the lane's vector inside a row
+                        // (one pass at a time: unrolled, the eight passes' vectors and products are all live at once and the
+                        // kernel spills 57 registers into its K loop's neighbourhood)
+#pragma unroll 1
+                        for (int i = 0; i < npass; ++i) {
+                            {
+                                const int j = (tid >> 3) + i * 32, q = q0 + j;
+                                if (j < HR && (unsigned)q < (unsigned)p.M) {
+                                    uint4* lp = reinterpret_cast<uint4*>(lbase + i * 4096);
+                                    float v[8];
+                                    unpack16<T>(*lp, v);
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+                                    const bool own = j >= hoff && j < hoff + BM;
+                                    const long goff = (long)q * row_bytes + gch;
+                                    if (own) {
+                                        unsigned mk = 0;
+#pragma unroll
+                                        for (int e = 0; e < 8; ++e) mk |= (v[e] > 0.f ? 1u : 0u) << e;
+                                        p.in_mask[goff >> 4] = (uint8_t)mk;
+                                    }
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                                    const uint4 pk = pack16<T>(v);
+                                    *lp = pk;
+                                    if (own) stg16<true>(p.in_act + goff, pk);
+                                }
+                            }
+                        }
+                    }
+                }
 #ifdef SM3_STAMP
                 const unsigned long long q3 = SM3_STAMP_NOW();
 #endif
@@ -1387,10 +1443,49 @@ struct EvalBn {  // BatchNorm folded into the epilogue: precomputed vectors ([vi
     int views = 1;
 };
 
+struct BnIn {  // sm3_conv3x3_bnin: the producer's BatchNorm + ReLU applied to the A image in LDS (kVarHaloBn)
+    const float *scale, *shift;
+    int views;
+    void* act;
+    uint8_t* mask;
+    bool probe;  // true: launch nothing, return 0 iff the launch would take the halo kernel
+};
+
+// the launches sm3_conv3x3_bnin can take: what launch_conv would route to the halo-resident kernel with the plain epilogue
+template <typename T>
+static int launch_bnin(const ConvParams& p_in, int Co, bool probe, hipStream_t st) {
+    if constexpr (sizeof(T) != 2) {
+        return SM3_EDTYPE;
+    } else {
+        ConvParams p = p_in;
+        const char* lv = getenv("SM3_CONV_LEAN");
+        const char* sv = getenv("SM3_CONV_SINGLE_STAGE_MAX");
+        if ((lv && atoi(lv) == 0) || (sv && p.ntaps * p.kchunks > atoi(sv))) return SM3_EINVAL;
+        p.kord = conv_halo_geometry(p) ? 1 : 0;
+        const long tiles128 = (long)((p.M + kBM - 1) / kBM) * ((Co + 127) / 128);
+        const bool narrow = Co <= 64 || (tiles128 <= 96 && p.ntaps * p.kchunks >= 6);
+        const long nblocks = (long)((p.M + kBM - 1) / kBM) * ((Co + (narrow ? 63 : 127)) / (narrow ? 64 : 128));
+        const char* dv = getenv("SM3_CONV_DEEP");
+        const bool deep = !(dv && atoi(dv) == 0) && nblocks <= 256 && p.ntaps * p.kchunks >= 6;
+        if (deep || !p.kord) return SM3_EINVAL;
+        // SM3_CONV_BNIN (A/B, read at every launch): 2 = only the 64-column launches (layer 1: no spills, the largest tensors),
+        // 3 = only the 128-column ones
+        const char* bv = getenv("SM3_CONV_BNIN");
+        const int bmode = bv ? atoi(bv) : 1;
+        if ((bmode == 2 && !narrow) || (bmode == 3 && narrow)) return SM3_EINVAL;
+        if (narrow) {
+            if (!conv_halo_ok<kBM, 64>(p)) return SM3_EINVAL;
+            return probe ? 0 : launch_conv_st<T, kBM, 64, 2, 2, 1, 1, false, kVarHalo | kVarHaloBn>(p, st);
+        }
+        if (!conv_halo_ok<kBM, 128>(p)) return SM3_EINVAL;
+        return probe ? 0 : launch_conv_st<T, kBM, 128, 2, 2, 1, 1, false, kVarHalo | kVarHaloBn>(p, st);
+    }
+}
+
 static int conv_gather_gemm_impl(const sm3_conv_desc* d, const void* x, const void* w, void* y, const void* addend,
                                  float* stat_partials, const sm3_bn_bwd_fuse* fuse, void* stream,
-                                 const EvalBn* ebn = nullptr, const sm3_conv_seg* seg = nullptr) {
-    if (!d || !x || !w || !y) return SM3_EINVAL;
+                                 const EvalBn* ebn = nullptr, const sm3_conv_seg* seg = nullptr, const BnIn* bnin = nullptr) {
+    if (!d || ((!x || !w || !y) && !(bnin && bnin->probe))) return SM3_EINVAL;
     // fuse->x NULL: ReLU mask + sum(dz) only (the sum(dz * xhat) slot of the partial rows is written as 0)
     if (fuse && ((fuse->x && (!fuse->mean || !fuse->invstd)) || !fuse->partials || fuse->partial_row_offset < 0))
         return SM3_EINVAL;
@@ -1474,6 +1569,23 @@ static int conv_gather_gemm_impl(const sm3_conv_desc* d, const void* x, const vo
         p.col_bias = seg->col_bias;
     }
     hipStream_t st = (hipStream_t)stream;
+    p.in_scale = p.in_shift = nullptr;
+    p.in_act = nullptr;
+    p.in_mask = nullptr;
+    if (bnin) {
+        if (addend || fuse || ebn || seg) return SM3_EINVAL;
+        if (bnin->views > 1) {
+            if (bnin->views != 2 || (p.M % 2) || ((p.M / 2) % kBM)) return SM3_EALIGN;
+            p.fz_view_tiles = p.M / 2 / kBM;
+        }
+        p.in_scale = bnin->scale;
+        p.in_shift = bnin->shift;
+        p.in_act = (char*)bnin->act;
+        p.in_mask = bnin->mask;
+        if (d->dtype == SM3_BF16) return launch_bnin<bf16_t>(p, d->Co, bnin->probe, st);
+        if (d->dtype == SM3_F16) return launch_bnin<f16_t>(p, d->Co, bnin->probe, st);
+        return SM3_EDTYPE;
+    }
     // 64-column tiles for Co <= 64, and for the small-M Linears whose 128-column grid would leave most CUs idle
     const long tiles128 = (long)((p.M + kBM - 1) / kBM) * ((d->Co + 127) / 128);
     const bool narrow = d->Co <= 64 || (tiles128 <= 96 && p.ntaps * p.kchunks >= 6);
@@ -1505,6 +1617,22 @@ extern "C" int sm3_conv_gather_gemm_seg(const sm3_conv_desc* d, const void* x0, 
                                         void* y, const void* addend, void* stream) {
     if (!seg) return SM3_EINVAL;
     return conv_gather_gemm_impl(d, x0, w0, y, addend, nullptr, nullptr, stream, nullptr, seg);
+}
+
+// conv2 of a Bottleneck reading conv1's RAW output: y = conv3x3(relu(x_raw * in_scale[v] + in_shift[v])) with the activation
+// and its ReLU bits written on the side (kVarHaloBn).  Only for the launches the halo-resident kernel takes
+// (sm3_conv3x3_bnin_ok: stride-1 3 x 3, 16-bit, more than 256 workgroups, the A image within a quarter of a CU's LDS);
+// everything else returns SM3_EINVAL and the caller keeps the two-pass form (sm3_bn_act, then sm3_conv_gather_gemm).
+extern "C" int sm3_conv3x3_bnin_ok(const sm3_conv_desc* d, int views) {
+    const BnIn b{nullptr, nullptr, views, nullptr, nullptr, true};
+    return conv_gather_gemm_impl(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &b) == 0 ? 1 : 0;
+}
+extern "C" int sm3_conv3x3_bnin(const sm3_conv_desc* d, const void* x_raw, const float* in_scale, const float* in_shift,
+                                int views, void* act_out, uint8_t* mask_out, const void* w, void* y, float* stat_partials,
+                                void* stream) {
+    if (!in_scale || !in_shift || !act_out || !mask_out || views < 1) return SM3_EINVAL;
+    const BnIn b{in_scale, in_shift, views, act_out, mask_out, false};
+    return conv_gather_gemm_impl(d, x_raw, w, y, nullptr, stat_partials, nullptr, stream, nullptr, nullptr, &b);
 }
 
 #ifdef SM3_STAMP

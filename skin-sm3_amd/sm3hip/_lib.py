@@ -64,6 +64,8 @@ SIGNATURES = {
     "sm3_linbn_fold": [_P, _I, _I, _I, _P, _P],
     "sm3_p2p_mailbox_bytes": [],
     "sm3_p2p_max_elems": [],
+    "sm3_conv3x3_bnin_ok": [_P, _I],
+    "sm3_conv3x3_bnin": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P],
     "sm3_p2p_max_world": [],
     "sm3_p2p_layout": [_I, _I, _I, _P, _P, _P, _P],
     "sm3_p2p_alloc": [_P, _P, _P],

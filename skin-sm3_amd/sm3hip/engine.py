@@ -353,6 +353,12 @@ class SM3Engine:
         self.linbn_ds = _os.environ.get("SM3_LINBN_DS", "1") != "0"
         self.linbn_join = _os.environ.get("SM3_LINBN_JOIN", "1") != "0"
         self.linbn_merge = _os.environ.get("SM3_LINBN_MERGE", "1") != "0"  # banks + post in one launch (A/B switch)
+        # bn1's apply + ReLU inside conv2's halo-resident A image (sm3_conv3x3_bnin; VERDICT r4 item 2, forward half).
+        # Bit-identical to the two-pass form and MEASURED SLOWER (profiles/r05_bnin_ab.txt: 26 bn_act launches / 0.5 ms of
+        # HBM-bound work less, but the 3x3 forward launches drop from 740-1 013 to 538-817 TFLOP/s -- every wave transforms
+        # its pieces between their landing and the barrier, where no MFMA can overlap it; two-lane step -0.3 ... -1.1 %):
+        # opt-in, SM3_CONV_BNIN=1 (2 / 3: only the 64- / 128-column launches)
+        self.bnin = _os.environ.get("SM3_CONV_BNIN", "0") != "0"
         self.lane_cross = _os.environ.get("SM3_LANE_CROSS", "1") != "0"  # cross-modal projector passes inside the lanes
 
     # ---- setup ---------------------------------------------------------------------------
@@ -520,13 +526,16 @@ class SM3Engine:
 
     # ---- conv + BN (+residual) (+ReLU) ---------------------------------------------------
     def conv_bn(self, cu, bu, x, N, H, W, relu, residual=None, train=True, save=None, out_f32=False, y_out=None,
-                apply=True, scale_shift=None, res_affine=None, pending=None, colsum=None):
+                apply=True, scale_shift=None, res_affine=None, pending=None, colsum=None, bn_in=None):
         """One conv + BatchNorm (+residual) (+ReLU) unit on N images.  With self._V == 2 the batch is two views back
         to back (N = 2B): one convolution launch, BatchNorm statistics / running-statistics updates per view.
         apply=False: stop after the statistics -- returns the pre-BatchNorm tensor, scale/shift are left in
         `scale_shift` for the consumer that applies them (the join of a downsample block, the stem's fused
         BN+ReLU+maxpool).  res_affine=(scale2, shift2): `residual` is such a pre-BatchNorm tensor and is normalised
         inside this unit's apply pass.
+        bn_in=(x_raw, scale, shift, mask): x is still EMPTY -- it is the activation relu(x_raw * scale[v] + shift[v]) of the
+        producer unit (called with apply=False), which this unit's convolution computes on its staged input image and writes
+        to x / mask on the side (sm3_conv3x3_bnin: the producer's apply pass disappears).
         pending (data parallel only): a list shared by the two BatchNorms that meet at a residual join.  The unit called
         with apply=False (the downsample branch) leaves its per-rank statistic sums in the first half of a shared buffer
         and queues its finalize there instead of synchronising; the unit called next with the same list (conv3) puts
@@ -559,6 +568,8 @@ class SM3Engine:
             partials = self._work("partials", prow * 2 * C)
             if direct:
                 ops.stem_conv_fwd(self.dtype, x, cu.w_fwd, xo, partials)
+            elif bn_in is not None:
+                ops.conv3x3_bnin(d, bn_in[0], bn_in[1], bn_in[2], x, bn_in[3], cu.w_fwd, xo, partials, views=V)
             else:
                 ops.conv_gemm(d, x, cu.w_fwd, xo, None, partials)
             count, groups = rows_v, 1
@@ -1170,14 +1181,31 @@ class SM3Engine:
                   for b in plan.blocks]
         for bi, (blk, lin) in enumerate(zip(plan.blocks, lin_ok)):
             br = [] if save is not None else None
-            y1, h1, w1 = self.conv_bn(blk["c1"], blk["b1"], cur, N, h, w, True, None, train, br)
+            # conv1 -> bn1 -> relu -> conv2 (resnet.py:144-150).  Where conv2 runs on the halo-resident kernel, bn1's apply +
+            # ReLU happens on conv2's staged input image: conv1 stops after its statistics, conv2 reads conv1's RAW output
+            # and writes the activation + ReLU bits that its weight gradient and bn1's backward need on the side
+            bn_in = None
+            if self.bnin and train and save is not None and self.dtype != ops.SM3_F32 and blk["c2"].stride == 1:
+                d1 = blk["c1"].fwd_desc(self.dtype, N, h, w)
+                if ops.conv3x3_bnin_ok(blk["c2"].fwd_desc(self.dtype, N, d1.Ho, d1.Wo), Vt):
+                    C1 = blk["c1"].Co
+                    sc1 = torch.empty(Vt * C1, dtype=torch.float32, device=x.device)
+                    sh1 = torch.empty(Vt * C1, dtype=torch.float32, device=x.device)
+                    x1, h1, w1 = self.conv_bn(blk["c1"], blk["b1"], cur, N, h, w, True, None, train, br, apply=False,
+                                              scale_shift=(sc1, sh1))
+                    y1 = torch.empty_like(x1)
+                    mk1 = torch.empty(x1.numel() // (16 // ops._sz(self.dtype)), dtype=torch.uint8, device=x.device)
+                    br[0].y, br[0].mask = y1, mk1
+                    bn_in = (x1, sc1, sh1, mk1)
+            if bn_in is None:
+                y1, h1, w1 = self.conv_bn(blk["c1"], blk["b1"], cur, N, h, w, True, None, train, br)
             pp = blk["c3"].Ci
             cs = crow = None
             if lin:
                 d2 = blk["c2"].fwd_desc(self.dtype, N, h1, w1)
                 crow = ops.bn_act_colsum_rows(self.dtype, N * d2.Ho * d2.Wo // Vt, pp)
                 cs = self._work("linbn_cs", Vt * crow * pp)
-            y2, h2, w2 = self.conv_bn(blk["c2"], blk["b2"], y1, N, h1, w1, True, None, train, br, colsum=cs)
+            y2, h2, w2 = self.conv_bn(blk["c2"], blk["b2"], y1, N, h1, w1, True, None, train, br, colsum=cs, bn_in=bn_in)
             if lin:
                 slabs, cap = self._slab_buf(pp * pp, Vt)
                 ns = ops.conv_wgrad_slabs(self._lin_conv_desc(self.dtype, N, h2, w2, pp, pp), y2, y2, slabs, views=Vt, cap=cap)

@@ -637,6 +637,35 @@ def linbn_post(dtype, wbn, w_dgrad, hn, P, G, Tm, s, coef, dw, Cn, p, views=1):
                                          _ptr(coef), _ptr(dw), Cn, p, views, _stream()), "sm3_linbn_post")
 
 
+def conv3x3_bnin_ok(desc, views=1):
+    """True iff conv3x3_bnin can take this launch (the halo-resident kernel would run it: sm3_conv3x3_bnin_ok)."""
+    return bool(_lib.load().sm3_conv3x3_bnin_ok(C.byref(desc), int(views)))
+
+
+def conv3x3_bnin(desc, x_raw, in_scale, in_shift, act_out, mask_out, w, y, stat_partials, views=1):
+    """y = conv3x3(relu(x_raw * in_scale[v] + in_shift[v])) + BatchNorm partial sums of y; the activation and its ReLU bits
+    written on the side (sm3_conv3x3_bnin): bn_act + conv_gemm in one launch, bit for bit."""
+    tdt = TORCH_DTYPE[desc.dtype]
+    _chk(x_raw, tdt, "x_raw"); _chk(act_out, tdt, "act_out"); _chk(w, tdt, "w"); _chk(y, tdt, "y")
+    _chk(in_scale, torch.float32, "in_scale"); _chk(in_shift, torch.float32, "in_shift")
+    _chk(mask_out, torch.uint8, "mask_out"); _chk(stat_partials, torch.float32, "stat_partials")
+    M = desc.N * desc.Ho * desc.Wo
+    n_in = desc.N * desc.Hi * desc.Wi * desc.Ci
+    if x_raw.numel() != n_in or act_out.numel() != n_in or mask_out.numel() != n_in // 8 or y.numel() != M * desc.Co or \
+            in_scale.numel() < views * desc.Ci or in_shift.numel() < views * desc.Ci or w.numel() != desc.Co * desc.w_row_stride:
+        raise ValueError("conv3x3_bnin: operand size does not match descriptor")
+    if stat_partials is not None and stat_partials.numel() < conv_partial_rows(desc) * 2 * desc.Co:
+        raise ValueError("conv3x3_bnin: partials workspace too small")
+    sz = _sz(desc.dtype)
+    tag = _conv_tag(desc)
+    if _PROFILER is not None and getattr(_PROFILER, "detail", False):
+        tag += f"|M{M}_K{desc.ntaps}x{desc.Ci}_N{desc.Co}_s{desc.osy}_bnin"
+    with _prof(tag, 2.0 * M * desc.Co * desc.ntaps * desc.Ci, sz * (2 * n_in + M * desc.Co) + n_in // 8):
+        check(_lib.load().sm3_conv3x3_bnin(C.byref(desc), _ptr(x_raw), _ptr(in_scale), _ptr(in_shift), int(views),
+                                           _ptr(act_out), _ptr(mask_out), _ptr(w), _ptr(y), _ptr(stat_partials), _stream()),
+              "sm3_conv3x3_bnin")
+
+
 def linbn_banks_post(dtype, w_dgrad, coef, wa, col_const, hn, P, G, Tm, s, dw, Cn, p, views=1):
     """linbn_banks + linbn_post in one launch (sm3_linbn_banks_post): same wa / col_const / hn / dw, bit for bit."""
     tdt = TORCH_DTYPE[dtype]

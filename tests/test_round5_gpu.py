@@ -160,3 +160,100 @@ BOUNDS = {
     "bf16": {"features": 0.2, "whole": -1.0, "stage": {s: -1.0 for s in _ST}, "ratio": (0.6, 1.6)},
     "f16": {"features": 0.04, "whole": 0.6, "stage": {s: 0.5 for s in _ST}, "ratio": (0.7, 1.4)},
 }
+
+
+# ---- VERDICT r4 item 2, forward half: bn1's apply + ReLU inside conv2's halo-resident A image (sm3_conv3x3_bnin) ---------
+@pytest.mark.parametrize("dtname", ["bf16", "f16"])
+def test_conv3x3_bnin_equals_bn_act_then_conv(dtname):
+    """conv2 reading conv1's RAW output -- BatchNorm affine + ReLU applied to the staged input image in LDS, activation and
+    ReLU bits written on the side -- against the two launches it replaces (sm3_bn_act, then sm3_conv_gather_gemm): the
+    convolution output, its BatchNorm partial sums, the activation and the mask bit for bit.  Geometries: every stage's
+    width, one and two views (scale / shift per view), images that end inside a tile, M not a multiple of 128; launches
+    the halo kernel would not take (small grids, a W that does not fit, stride 2) are refused by sm3_conv3x3_bnin_ok."""
+    import math
+    from sm3hip import ops
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16}[dtname]
+    code = ops.dtype_code(dt)
+    D = torch.device(DEV)
+    cases = [(40, 56, 56, 64, 64, 1), (64, 28, 28, 128, 128, 2), (200, 14, 14, 256, 256, 1), (768, 7, 7, 512, 512, 2),
+             (42, 30, 28, 128, 128, 1), (256, 14, 14, 256, 256, 2)]
+    for ci_, (N, H, W, Ci, Co, V) in enumerate(cases):
+        g = torch.Generator().manual_seed(50 + ci_)
+        d = ops.fwd_desc(code, N, H, W, Ci, Co, 3, 1, 1)
+        assert ops.conv3x3_bnin_ok(d, V), (N, H, W, Ci, Co, V)
+        M = N * H * W
+        x = torch.randn(M, Ci, generator=g).to(dt).to(D)
+        w = (torch.randn(Co, 9 * Ci, generator=g) / math.sqrt(9 * Ci)).to(dt).to(D)
+        scale = (torch.rand(V * Ci, generator=g) + 0.5).to(D)
+        shift = (torch.randn(V * Ci, generator=g) * 0.5).to(D)
+        # two launches
+        act = torch.empty(M, Ci, dtype=dt, device=D)
+        mask = torch.empty(M * Ci // 8, dtype=torch.uint8, device=D)
+        ops.bn_act(code, x, scale, shift, None, True, act, M // V, Ci, mask=mask, views=V)
+        y = torch.empty(M, Co, dtype=dt, device=D)
+        part = torch.zeros(ops.conv_partial_rows(d) * 2 * Co, device=D)
+        ops.conv_gemm(d, act, w, y, None, part)
+        # one launch
+        act2 = torch.full((M, Ci), float("nan"), dtype=dt, device=D)
+        mask2 = torch.full((M * Ci // 8,), 0xAA, dtype=torch.uint8, device=D)
+        y2 = torch.empty(M, Co, dtype=dt, device=D)
+        part2 = torch.zeros_like(part)
+        ops.conv3x3_bnin(d, x, scale, shift, act2, mask2, w, y2, part2, views=V)
+        torch.cuda.synchronize()
+        what = (dtname, N, H, W, Ci, Co, V)
+        assert torch.equal(act2, act), ("activation",) + what
+        assert torch.equal(mask2, mask), ("relu bits",) + what
+        assert torch.equal(y2, y), ("conv output",) + what
+        assert torch.equal(part2, part), ("bn partial sums",) + what
+    # refused: a grid of at most 256 workgroups (the deep kernel's), stride 2, a 1x1, the exact-f32 type
+    assert not ops.conv3x3_bnin_ok(ops.fwd_desc(code, 2, 14, 14, 256, 256, 3, 1, 1))
+    assert not ops.conv3x3_bnin_ok(ops.fwd_desc(code, 64, 28, 28, 128, 128, 3, 2, 1))
+    assert not ops.conv3x3_bnin_ok(ops.fwd_desc(code, 64, 28, 28, 128, 128, 1, 1, 0))
+    assert not ops.conv3x3_bnin_ok(ops.fwd_desc(code, 64, 112, 112, 64, 64, 3, 1, 1))          # W = 112: the image does not fit
+    assert not ops.conv3x3_bnin_ok(ops.fwd_desc(ops.dtype_code(torch.float32), 64, 28, 28, 128, 128, 3, 1, 1))
+
+
+@pytest.mark.parametrize("dtname", ["bf16", "f16"])
+def test_step_with_and_without_bnin_is_the_same_step(dtname):
+    """A whole SM3 step (B = 32 pairs of 224 x 224, both views in one batch) with bn1's apply fused into conv2
+    (SM3_CONV_BNIN=1; measured slower, so opt-in: DESIGN.md 3.6.5) and with the separate apply pass: the forward is bit-identical -- same loss, same running
+    statistics -- and the gradients agree to the float-atomic noise of the weight-gradient sums."""
+    from sm3hip.trainer import SM3Trainer
+    from src.models.simclr import SimCLRSkinV32
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16}[dtname]
+    B, S = 32, 224
+    g = torch.Generator(device=DEV).manual_seed(9)
+    derm = [torch.randn(B, 3, S, S, device=DEV, generator=g) for _ in range(2)]
+    clinic = [torch.randn(B, 3, S, S, device=DEV, generator=g) for _ in range(2)]
+    torch.manual_seed(9)
+    init = {k: v.clone() for k, v in SimCLRSkinV32("resnet50", None, 128, 0.1).state_dict().items()}
+    runs = {}
+    for on in (True, False):
+        model = SimCLRSkinV32("resnet50", None, 128, 0.1)
+        model.load_state_dict(init)
+        model.sm3_dtype = dt
+        model.to(DEV)
+        tr = SM3Trainer(model, lr=0.0, init_scale=1024.0)
+        eng = tr._engine()
+        eng.bnin = on
+        calls = []
+        from sm3hip import ops
+        real = ops.conv3x3_bnin
+        ops.conv3x3_bnin = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        try:
+            loss = float(tr.step(derm, clinic))
+        finally:
+            ops.conv3x3_bnin = real
+        torch.cuda.synchronize()
+        runs[on] = (loss, eng.store.flat_g.double().clone(),
+                    {k: v.clone() for k, v in model.state_dict().items() if "running" in k}, len(calls))
+        del tr, eng, model
+        torch.cuda.empty_cache()
+    # the stride-1 3x3 units of layers 1 and 2 (3 + 3 per encoder, two branches, both views per launch); at this batch the
+    # grids of layers 3 and 4 stay below 257 workgroups and keep the two-pass form
+    assert runs[True][3] == 2 * 6 and runs[False][3] == 0
+    for k, v in runs[True][2].items():
+        assert torch.equal(v, runs[False][2][k]), k
+    assert runs[True][0] == runs[False][0], (runs[True][0], runs[False][0])
+    rel = float((runs[True][1] - runs[False][1]).norm() / runs[False][1].norm())
+    assert rel < 1e-5, rel
