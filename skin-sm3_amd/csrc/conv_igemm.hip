@@ -374,8 +374,9 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
         // invariants the compiler would keep in registers across the K loop)
         auto halo_issue = [&](uint32_t chunk_off) {
             const uint32_t base = (uint32_t)(q0 + (tid >> 3)) * row_bytes + a_chunk + chunk_off;
+            constexpr int kMaxPass = BM == 256 ? 12 : 8;  // 32-row passes of the image: BM + 2 (W + 1) + 2 rows
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < kMaxPass; ++i) {
                 if (i < npass) {
                     const int j = (tid >> 3) + i * 32, q = q0 + j;
                     const bool ok = j < HR && (unsigned)q < (unsigned)p.M;
@@ -842,14 +843,23 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
         __syncthreads();
         SM3_MARK(3);
         if (p.partials && tid < BN && n0 + tid < p.Co) {
-            float s1 = 0.f, s2 = 0.f;
+            // one partial row per 128 tile rows, summed over their wave rows in wave order: a 256-row tile (kVarHalo, tall)
+            // leaves the same two rows, bit for bit, as the two 128-row tiles it replaces
+            constexpr int G = BM / 128 > 0 ? BM / 128 : 1, WPG = WM / G;
 #pragma unroll
-            for (int w = 0; w < WM; ++w) {
-                s1 += sStat[(w * BN + tid) * 2 + 0];
-                s2 += sStat[(w * BN + tid) * 2 + 1];
+            for (int g = 0; g < G; ++g) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WPG; ++w) {
+                    s1 += sStat[((g * WPG + w) * BN + tid) * 2 + 0];
+                    s2 += sStat[((g * WPG + w) * BN + tid) * 2 + 1];
+                }
+                const long prow = (long)bm * G + g;
+                if (G == 1 || prow * 128 < p.M) {
+                    p.partials[(prow * 2 + 0) * p.Co + n0 + tid] = s1;
+                    p.partials[(prow * 2 + 1) * p.Co + n0 + tid] = s2;
+                }
             }
-            p.partials[((long)bm * 2 + 0) * p.Co + n0 + tid] = s1;
-            p.partials[((long)bm * 2 + 1) * p.Co + n0 + tid] = s2;
         }
         const char* sp = sC + r0 * LEAN_PITCH + cc * 16;
         if constexpr (EPI == 3) {
@@ -1179,6 +1189,7 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
 }
 
 constexpr int kHaloLdsMax = 40960;  // a quarter of a CU's LDS: the halo kernels keep 4 workgroups per CU
+constexpr int kHaloLdsMaxTall = 53248;  // 256-row tiles (SM3_CONV_HALO_TALL): a third of a CU's LDS, 3 workgroups per CU
 
 // SM3_CONV_HALO (A/B switch, read at every launch): the halo-resident A image (kVarHalo) for the launches it fits:
 // nine taps at (-1..1, -1..1) over one tensor, stride 1, same geometry in and out, dense output and addend.
@@ -1206,7 +1217,16 @@ template <int BM, int BN>
 static bool conv_halo_ok(const ConvParams& p) {
     if (!p.kord) return false;
     const int rows = BM + 2 * (p.Wi + 1) + 2;
-    return ((rows + 31) / 32) * 4096 + BN * 128 <= kHaloLdsMax;
+    return ((rows + 31) / 32) * 4096 + BN * 128 <= (BM == 256 ? kHaloLdsMaxTall : kHaloLdsMax);
+}
+// SM3_CONV_HALO_TALL (A/B switch, read at every launch): the plain-epilogue 3x3 forward launches on 256 x 64 tiles (4 x 1
+// waves of 64 x 64: the same wave tile, accumulators and fragment traffic as 128 x 128) -- per nine K-steps a workgroup stages
+// an A image of 256 + 2 (W + 1) rows once and nine 8 KB B tiles, 108 - 112 KB for the FLOPs the 128 x 128 tile stages 168 KB
+// for (the B tiles are the larger stream since the image became resident, and L2 -> LDS bytes are what these launches and
+// their co-runners contend for: profiles/r05_corun_regs.txt), at three workgroups per CU instead of four.
+static int conv_halo_tall_mode() {
+    const char* v = getenv("SM3_CONV_HALO_TALL");
+    return v ? atoi(v) : 0;
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int STAGES, int EPI, bool SEG = false, int VAR = 0>
@@ -1232,7 +1252,7 @@ int launch_conv_st(const ConvParams& p0, hipStream_t st) {
         p.halo_a_bytes = ((p.halo_rows + 2 + 31) / 32) * 4096;  // + two zero rows (one 256-byte bank row)
         const int image = p.halo_a_bytes + BN * 128;
         LDS = image > C_BYTES + STAT ? image : C_BYTES + STAT;
-        if (LDS > kHaloLdsMax) return SM3_EINVAL;  // (conv_halo_ok() is asked first)
+        if (LDS > (BM == 256 ? kHaloLdsMaxTall : kHaloLdsMax)) return SM3_EINVAL;  // (conv_halo_ok() is asked first)
         p.halo_stat_off = LDS - STAT;
     }
     p.tilesM = (p.M + BM - 1) / BM;
@@ -1244,7 +1264,7 @@ int launch_conv_st(const ConvParams& p0, hipStream_t st) {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 31) dev = 0;
     if (!(attr_set.load(std::memory_order_acquire) & (1u << dev))) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (VAR & kVarHalo) ? kHaloLdsMax : LDS_STATIC);
+                                           (VAR & kVarHalo) ? (BM == 256 ? kHaloLdsMaxTall : kHaloLdsMax) : LDS_STATIC);
         if (e != hipSuccess) return (int)e;
         attr_set.fetch_or(1u << dev, std::memory_order_release);
     }
@@ -1300,6 +1320,15 @@ static int conv_m16_mode() {
 // 16-bit lean epilogues on the 1- or 2-stage K loop
 template <typename T, int BM, int BN, int WM, int WN, int EPI, bool SEG>
 int launch_conv_lean(const ConvParams& p, hipStream_t st, bool single) {
+    if constexpr (!SEG && EPI == 1 && BM == 128 && WM == 2 && WN == 2) {
+        // 256 x 64 tiles: whole 64-column tiles only, and at least two rounds of them (3 workgroups x 256 CUs)
+        if (single && conv_halo_tall_mode() && p.Co % 64 == 0 && conv_halo_ok<256, 64>(p) &&
+            (long)((p.M + 255) / 256) * (p.Co / 64) >= 1536) {  // (784 tiles on 768 slots: +16 % alone, profiles/r05_tall_tiles.txt)
+            ConvParams q = p;
+            if (q.fz_view_tiles) q.fz_view_tiles = (q.fz_view_tiles % 2) ? 0 : q.fz_view_tiles / 2;  // (unused by this epilogue)
+            return launch_conv_st<T, 256, 64, 4, 1, 1, 1, false, kVarHalo>(q, st);
+        }
+    }
     if constexpr (!SEG && (EPI == 1 || EPI == 3) && WM * WN == 4) {
         if (single && conv_halo_ok<BM, BN>(p)) return launch_conv_st<T, BM, BN, WM, WN, 1, EPI, false, kVarHalo>(p, st);
     }
@@ -1588,7 +1617,10 @@ static int conv_gather_gemm_impl(const sm3_conv_desc* d, const void* x, const vo
     }
     // 64-column tiles for Co <= 64, and for the small-M Linears whose 128-column grid would leave most CUs idle
     const long tiles128 = (long)((p.M + kBM - 1) / kBM) * ((d->Co + 127) / 128);
-    const bool narrow = d->Co <= 64 || (tiles128 <= 96 && p.ntaps * p.kchunks >= 6);
+    // SM3_CONV_FORCE_NARROW=1 (experiment switch, scratch/r5_corun_regs.py): 64-column tiles everywhere -- 74-83 registers per
+    // wave instead of 110-127, to measure whether a lighter gather-GEMM shares a CU better with the other lane's kernels
+    const char* fnv = getenv("SM3_CONV_FORCE_NARROW");
+    const bool narrow = d->Co <= 64 || (tiles128 <= 96 && p.ntaps * p.kchunks >= 6) || (fnv && atoi(fnv) == 1);
     if (d->dtype == SM3_BF16)
         return narrow ? launch_conv<bf16_t, kBM, 64, 2, 2>(p, st) : launch_conv<bf16_t, kBM, 128, 2, 2>(p, st);
     if (d->dtype == SM3_F16)
