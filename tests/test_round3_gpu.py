@@ -298,20 +298,24 @@ def test_T2_loss_trajectories():
     pick = [0, 2, 4, 9, 14, 19, 29]
     print("loss f32 ", np.round(f32[pick], 3))
     assert f32[0] > 5.0 and f32[-3:].mean() < 0.3
-    # the loss falls by a factor of ~2 per step in mid-descent, so a curve that is half a step ahead or behind differs by
-    # tens of per cent there: the band around the f32 curve is taken over a +-1 step window, x0.65 .. x1.35 (+-0.05)
-    lo = np.minimum.reduce([np.roll(f32, 1), f32, np.roll(f32, -1)])
-    hi = np.maximum.reduce([np.roll(f32, 1), f32, np.roll(f32, -1)])
-    lo[0], hi[0], lo[-1], hi[-1] = min(f32[0], f32[1]), max(f32[0], f32[1]), min(f32[-2:]), max(f32[-2:])
+    # the loss falls by a factor of ~2 per step in mid-descent, so a curve that is one step ahead or behind differs by a factor
+    # of two there, and which of the model's discrete trajectories a run falls into (float-atomic weight gradients, DESIGN.md
+    # section 4) moves it by a good part of a step from run to run: round 5 measured the bf16 curve at 0.90 of the +-1-step,
+    # x0.65 .. x1.35 band of rounds 3-4 (a landmine of the kind that turned round 4's gate red).  The band is taken over a
+    # +-2-step window of the f32 curve, x0.6 .. x1.5 (+-0.05): "the loss comes down at the f32 rate, at most two steps early
+    # or late" -- a run that does not train (loss ~ 10 where f32 is below 0.3 from step 9 on) is a factor of 30 outside it
+    n = len(f32)
+    lo = np.array([f32[max(0, i - 2): i + 3].min() for i in range(n)])
+    hi = np.array([f32[max(0, i - 2): i + 3].max() for i in range(n)])
     for name in ("f16", "bf16"):
         c = np.array(curves[name])
         d = np.abs(c - f32)
         print(f"loss {name}", np.round(c[pick], 3), "max |d|", round(float(d.max()), 3), "max |d| / f32",
               round(float((d / np.maximum(f32, 1e-3)).max()), 3))
         # (how much of the band is used: 1.0 = on its edge; printed so that a shrinking margin is seen before it fails)
-        used = np.maximum((0.65 * lo - 0.05 - c) / (0.35 * lo + 0.05) + 1.0, (c - 1.35 * hi - 0.05) / (0.35 * hi + 0.05) + 1.0)
+        used = np.maximum((lo - c) / (0.4 * lo + 0.05), (c - hi) / (0.5 * hi + 0.05))
         print(f"     {name}: band use {float(used.max()):.2f} at step {int(used.argmax())}")
-        assert ((c >= 0.65 * lo - 0.05) & (c <= 1.35 * hi + 0.05)).all(), (name, np.round(c, 3), np.round(f32, 3))
+        assert ((c >= 0.6 * lo - 0.05) & (c <= 1.5 * hi + 0.05)).all(), (name, np.round(c, 3), np.round(f32, 3))
         assert abs(c[0] - f32[0]) < (0.3 if name == "f16" else 1.0)               # same starting point (B = 16: 0.09 / ~0.3)
         assert c[-3:].mean() < 0.3                                                  # same end state
 
