@@ -18,12 +18,12 @@ def _bench():
     return m
 
 
-def _run(extra_env, timeout=240):
+def _run(extra_env, timeout=240, gpus=2):
     env = dict(os.environ, SM3_BENCH_DRYRUN="1", **extra_env)
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     t0 = time.monotonic()
-    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "0"],
                         env=env, capture_output=True, text=True, timeout=timeout)
     return pr, time.monotonic() - t0
 
@@ -40,6 +40,40 @@ def test_two_ranks_end_to_end_dry_run():
     w = out["config"]["witness"]
     assert w["rccl_ranks"] == 2 and w["backend"] == "gloo" and w["syncbn_exchange"] == "gloo"
     assert len(w["ms_per_step_per_rank"]) == 2 and w["ms_per_step_min"] <= w["ms_per_step_max"]
+
+
+def test_eight_ranks_end_to_end_dry_run():
+    """BASELINE config 3's rank count through bench.py's own launcher (CPU, gloo, kernels stubbed): eight ranks start, count
+    each other with a collective, run the data-parallel step's whole control flow and rank 0 prints ONE line for n_gpus = 8.
+    (No 8-GPU node was available to any round: this is the control flow only, config 3 stays unmeasured.)"""
+    pr, _ = _run({"OMP_NUM_THREADS": "1"}, timeout=480, gpus=8)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, pr.stdout
+    out = json.loads(lines[0])
+    assert out["dry_run"] is True and out["n_gpus"] == 8 and out["config"]["parallelism"] == "dp8"
+    w = out["config"]["witness"]
+    assert w["rccl_ranks"] == 8 and len(w["ms_per_step_per_rank"]) == 8
+
+
+def test_two_ranks_under_a_torchrun_style_environment():
+    """How the driver starts N > 1: one process per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment
+    (python -m torch.distributed.run ... bench.py --gpus N).  bench.py must then NOT spawn ranks of its own: each process is
+    one rank, rank 0 prints the line."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, SM3_BENCH_DRYRUN="1", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=240) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    lines = [[l for l in o[0].splitlines() if l.startswith("{")] for o in outs]
+    assert len(lines[0]) == 1 and len(lines[1]) == 0, lines
+    out = json.loads(lines[0][0])
+    assert out["n_gpus"] == 2 and out["config"]["witness"]["rccl_ranks"] == 2
 
 
 def test_a_rank_that_dies_stops_the_run_quickly():
