@@ -146,6 +146,38 @@ def test_extract_eval_T0(compat_run):
     np.testing.assert_allclose(fc.double().cpu().numpy(), g["extract_clinic"], rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("dtname", ["bf16", "f16"])
+@pytest.mark.parametrize("case", ["b4_s64_f64", "b8_s64_style1_f64", "b3_s96_style2_f64"])
+def test_extract_eval_16bit_against_the_reference_golden(golden_dir, case, dtname):
+    """The 16-bit arithmetic modes against the REFERENCE's own numbers (not against this repository's f32 mode): the same
+    sequence the goldens were generated with -- one train-mode forward (running statistics take their first momentum
+    update), then `model.extract` in eval mode (src/models/simclr.py:399-413: frozen statistics, the fused conv + BatchNorm
+    inference launches) -- in bf16 and fp16, features against the reference's fp64 features.  Measured relative L2 error
+    (printed; reproducible on a build): bf16 3.0e-2 - 4.5e-2, fp16 5.0e-3 - 8.8e-3 over the three cases -- about 8x the
+    figures of the 224 x 224 eval-mode test (tests/test_round5_gpu.py: 5.0e-3 / 6e-4), because the goldens' batches are 3 - 8
+    images of 64 - 96 pixels (2 x 2 maps in layer 4) and the running statistics the eval pass normalises with come from one
+    16-bit batch of that size.  Bounds: about twice the largest value seen."""
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16}[dtname]
+    g = _load(golden_dir, case)
+    batch, size, seed, style = [int(v) for v in g["meta"]]
+    model = _build(seed, dt)
+    model.train()
+    derm, clinic = _batch(batch, size, seed)
+    with torch.no_grad():
+        model(derm, clinic, style)
+    model.eval()
+    with torch.no_grad():
+        fd, fc = model.extract(derm[0], clinic[0])
+    torch.cuda.synchronize()
+    errs = []
+    for got, key in ((fd, "extract_derm"), (fc, "extract_clinic")):
+        ref = g[key]
+        assert got.dtype == torch.float32 and tuple(got.shape) == ref.shape
+        errs.append(float(np.linalg.norm(got.double().cpu().numpy() - ref) / np.linalg.norm(ref)))
+    print(f"{case} {dtname}: extract features, relative L2 error against the reference's fp64 run: derm {errs[0]:.2e}, clinic {errs[1]:.2e}")
+    assert max(errs) < (0.1 if dtname == "bf16" else 2e-2), errs
+
+
 def test_fused_trainer_matches_golden_and_compat(golden_dir):
     """The fused step (no autograd, fused NT-Xent, fused AdamW) gives the reference's loss and post-step
     parameters."""
