@@ -151,7 +151,8 @@ int sm3_conv_bn_eval(const sm3_conv_desc* d, const void* x, const void* w, const
 
 /* Weight gradient of the forward conv described by d (autograd of the same call sites):
  *   dw[co*w_row_stride + wtap[t]*Ci + ci] += sum_{n,oy,ox} dy[(n,oy,ox), co] * x[n, oy*sy+dy[t], ox*sx+dx[t], ci]
- * dy is dense [N*Ho*Wo, Co]; dw is fp32 and is accumulated into (float atomics, split over pixels).
+ * dy is dense [N*Ho*Wo, Co]; dw is fp32 and is accumulated into (float atomics, split over pixels: run-to-run
+ * differences of 1 ulp; sm3_conv_wgrad_det below is the fixed-order form).
  * Columns wtap[t]*Ci+ci >= w_row_stride are dropped (the zero-padded K tail of the stem im2col). */
 int sm3_conv_wgrad(const sm3_conv_desc* d, const void* x, const void* dy, float* dw, void* stream);
 /* The same product over `views` equal pixel ranges that accumulate into dw + v * dw_view_stride (per-view weight-gradient
@@ -167,6 +168,17 @@ int sm3_conv_wgrad_cat(const sm3_conv_desc* d, const void* x, const void* dy, fl
  * the same way whether the launch holds one view or two. */
 int sm3_conv_wgrad_slabs(const sm3_conv_desc* d, const void* x, const void* dy, float* slabs, int slab_capacity, int views,
                          int* slabs_used, void* stream);
+/* out[e] = (accumulate ? out[e] : 0) + sum_j slabs[j * n + e], j ascending on a fixed tree that depends on (nslabs, e)
+ * only; n a multiple of 4, both pointers 16-byte aligned.  The fixed-order sum behind every split-K product of the
+ * training step (ABI 8). */
+int sm3_slab_reduce(const float* slabs, int nslabs, int64_t n, float* out, int accumulate, void* stream);
+/* sm3_conv_wgrad as a FUNCTION OF ITS INPUTS (ABI 8; what the training step uses): the pixel slices store plain slabs
+ * into `slabs` (room for slab_capacity matrices [Co][taps * Ci] fp32; d->w_row_stride == taps * Ci) and one
+ * sm3_slab_reduce adds them to dw.  The partition depends on the geometry and the device only, so two runs of the same
+ * step produce the same bits -- the autograd backward of nn.Conv2d / nn.Linear it replaces (tools/backbone_train.py:125)
+ * is a fixed-order reduction too.  A launch that needs a single slice adds its tiles to dw directly (no slab). */
+int sm3_conv_wgrad_det(const sm3_conv_desc* d, const void* x, const void* dy, float* dw, float* slabs, int slab_capacity,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm (2d and 1d: rows x C), train and eval.  replaces nn.BatchNorm2d/1d (+SyncBatchNorm,
@@ -341,12 +353,16 @@ int sm3_stem_conv_fwd(int dtype, const float* x_nchw, const void* w_stem, void* 
                       int W, void* stream);
 /* Stem weight gradient with phase 2 of bn1's backward fused into its operand load:
  *   dxo = gamma*invstd*(dz - sum_dz/count - xhat*sum_dz_xhat/count)   (never written to HBM: the stem has no data
- *   gradient, so this tensor has no other consumer),  dw[64][147] += dxo^T * im2col(x)  (float atomics),
- *   dgamma += local sum(dz*xhat), dbeta += local sum(dz).  Arguments as sm3_bn_bwd_apply; dz, xo: [N*Ho*Wo, 64]. */
+ *   gradient, so this tensor has no other consumer),  dw[64][147] += dxo^T * im2col(x),
+ *   dgamma += local sum(dz*xhat), dbeta += local sum(dz).  Arguments as sm3_bn_bwd_apply; dz, xo: [N*Ho*Wo, 64].
+ *   dw_slabs (ABI 8; nullable): room for SM3_STEM_WGRAD_SLABS matrices [64][147] fp32 -- every workgroup of the persistent
+ *   grid stores its partial product there and one sm3_slab_reduce adds them to dw in a fixed order (what the training step
+ *   uses); NULL: float atomics straight into dw. */
+#define SM3_STEM_WGRAD_SLABS 768
 int sm3_stem_wgrad_bn(int dtype, const float* x_nchw, const void* dz, const void* xo, const float* mean,
                       const float* invstd, const float* gamma, const double* global_sums, double count,
-                      const double* local_sums, float* dgamma, float* dbeta, float* dw, int N, int H, int W, int views,
-                      void* stream);
+                      const double* local_sums, float* dgamma, float* dbeta, float* dw, float* dw_slabs, int N, int H, int W,
+                      int views, void* stream);
 /* argmax (nullable): [N,Ho,Wo,C] bytes, window position kh*3+kw of the first maximum in scan order (ATen's tie rule) */
 int sm3_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* argmax, int N, int H, int W, int C, void* stream);
 /* dx[n,iy,ix,c] = sum of dy over the windows whose recorded argmax is (iy,ix); gather form, no atomics */

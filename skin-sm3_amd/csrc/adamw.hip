@@ -161,4 +161,4 @@ extern "C" int sm3_check_finite(const float* g, int64_t n, int32_t* found_inf, v
     return 0;
 }
 
-extern "C" int sm3_abi_version(void) { return 7; }
+extern "C" int sm3_abi_version(void) { return 8; }

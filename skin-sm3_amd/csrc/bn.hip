@@ -578,13 +578,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         k1[e] = (float)(gsums[c] * inv_count);              // (no fp64 divide per thread: 16 of them cost more
         q[e] = k0[e] * is * (float)(gsums[C + c] * inv_count);  //  than the rows a thread walks)
     }
-    if (blockIdx.y == 0 && ty == 0 && lsums) {  // parameter gradients from the LOCAL sums, once per channel
+    if (blockIdx.y == 0 && blockIdx.z == 0 && ty == 0 && lsums) {
+        // parameter gradients from the LOCAL sums, once per channel: ONE thread adds the views of the launch in view order
+        // (a fixed order: a step's gradients are a function of its inputs).  Still atomics, because two launches may add to
+        // the same parameter from two streams (SM3_VIEW_LANES=1) -- within a stream the order is the launch order.
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int c = cv * E + e;
-            // atomics: the two views of an encoder may run their backward on two streams at once
-            if (dbeta) atomicAdd(&dbeta[c], (float)lsums[c]);
-            if (dgamma) atomicAdd(&dgamma[c], (float)lsums[C + c]);
+            for (int v = 0; v < (int)gridDim.z; ++v) {
+                if (dbeta) atomicAdd(&dbeta[c], (float)lsums[(int64_t)v * 2 * C + c]);
+                if (dgamma) atomicAdd(&dgamma[c], (float)lsums[(int64_t)v * 2 * C + C + c]);
+            }
         }
     }
     const int64_t rstep = (int64_t)gridDim.y * tby;
@@ -649,9 +653,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const T* __restrict_
             k0[e] = g * is;
             k1[e] = (float)(s.gsums[v2 + c] * inv_count);
             q[e] = k0[e] * is * (float)(s.gsums[v2 + C + c] * inv_count);
-            if (blockIdx.y == 0 && ty == 0 && s.lsums) {
-                if (s.dbeta) atomicAdd(&s.dbeta[c], (float)s.lsums[v2 + c]);
-                if (s.dgamma) atomicAdd(&s.dgamma[c], (float)s.lsums[v2 + C + c]);
+            if (blockIdx.y == 0 && blockIdx.z == 0 && ty == 0 && s.lsums) {  // one thread, views in order (see bn_bwd_apply_kernel)
+                for (int v = 0; v < (int)gridDim.z; ++v) {
+                    if (s.dbeta) atomicAdd(&s.dbeta[c], (float)s.lsums[(int64_t)v * 2 * C + c]);
+                    if (s.dgamma) atomicAdd(&s.dgamma[c], (float)s.lsums[(int64_t)v * 2 * C + C + c]);
+                }
             }
         }
     };

@@ -47,6 +47,11 @@ struct WgradParams {
     // (every slab a full [Co][w_row_stride] matrix); the caller sums the slabs in a fixed order (deterministic results)
     long slab_stride;  // 0: accumulate with float atomics
     int slab_cap;      // slabs available per view
+    // sm3_conv_wgrad_det: the slabs are an intermediate of ONE gradient (all views add into the same dw), so the pixel axis is
+    // cut for the launch as it is (pair_rule = 0: no "as if two views" rule), and a launch that ends up with a single
+    // slice adds its tiles to dw_direct itself (rmw: plain read-modify-write, one writer per element) -- no slab, no reduce
+    float* dw_direct;
+    int pair_rule, rmw;
 };
 
 #ifdef SM3_STAMP
@@ -391,6 +396,7 @@ __global__ __launch_bounds__(256 * KG, (NST == 1 || (SM3_WGRAD_OCC && !DENSE && 
                 const long kcol = (long)p.wtap[tap] * p.Ci + ci;  // column inside the dw row
                 if (co < dyC && ci < p.Ci && kcol < p.w_row_stride) {
                     if (p.slab_stride) dw_out[(long)co * p.w_row_stride + kcol] = acc[i][j][r];
+                    else if (p.rmw) dw_out[(long)co * p.w_row_stride + kcol] += acc[i][j][r];
                     else atomicAdd(dw_out + (long)co * p.w_row_stride + kcol, acc[i][j][r]);
                 }
             }
@@ -466,7 +472,7 @@ int launch_wgrad_kp(WgradParams p, hipStream_t st) {
     else splits = 8 * slots_xcd / gx;  // < 8 slices: tiles go round-robin over the XCDs (see the kernel)
     // per view from here on.  Slab mode: as if the launch always held two views, so that a view's pixels are cut into the
     // same slices -- and its slabs add up to the same bits -- whether the two views of a branch share a launch or not
-    splits = p.slab_stride ? (splits + 1) / 2 : (splits + p.views - 1) / p.views;
+    splits = (p.slab_stride && p.pair_rule) ? (splits + 1) / 2 : (splits + p.views - 1) / p.views;
     if (p.slab_stride && splits > p.slab_cap) splits = p.slab_cap;
     const long max_splits = (p.Mv + KP * 8 * KG - 1) / (KP * 8 * KG);
     if (splits > max_splits) splits = max_splits;
@@ -480,6 +486,12 @@ int launch_wgrad_kp(WgradParams p, hipStream_t st) {
     g_last_slabs = (int)splits;
     splits *= p.views;
     p.splits = (int)splits;
+    if (p.slab_stride && p.dw_direct && splits == 1) {  // one slice: its tiles are the whole product
+        p.slab_stride = 0;
+        p.rmw = 1;
+        p.dw = p.dw_direct;
+        g_last_slabs = 0;
+    }
     const long nblocks = gx * (splits >= 8 ? (splits + 7) / 8 * 8 : splits);
     if (gx > 0x7fffffffL || nblocks > 0x7fffffffL) return SM3_EINVAL;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256 * KG), LDS, st, p);
@@ -532,7 +544,8 @@ int launch_wgrad(WgradParams p, hipStream_t st) {
 }  // namespace
 
 static int wgrad_impl(const sm3_conv_desc* d, const void* x, const void* dy, float* dw, const void* dy1, int Co1,
-                      float* dw1, int views, long dw_view_stride, long dw1_view_stride, void* stream, int slab_cap = 0) {
+                      float* dw1, int views, long dw_view_stride, long dw1_view_stride, void* stream, int slab_cap = 0,
+                      float* dw_direct = nullptr) {
     if (!d || !x || !dy || !dw) return SM3_EINVAL;
     if (!SM3_DTYPE_OK(d->dtype)) return SM3_EDTYPE;
     const int sz = d->dtype == SM3_F32 ? 4 : 2;
@@ -551,6 +564,9 @@ static int wgrad_impl(const sm3_conv_desc* d, const void* x, const void* dy, flo
     p.dw_view_stride = dw_view_stride; p.dw1_view_stride = dw1_view_stride;
     p.slab_cap = slab_cap;
     p.slab_stride = slab_cap > 0 ? (long)d->Co * d->w_row_stride : 0;
+    p.dw_direct = dw_direct;
+    p.pair_rule = dw_direct ? 0 : 1;
+    p.rmw = 0;
     p.M = (int)M; p.Hi = d->Hi; p.Wi = d->Wi; p.Ci = d->Ci; p.Co = d->Co;
     p.sy = d->sy; p.sx = d->sx; p.ntaps = d->ntaps;
     for (int t = 0; t < SM3_MAX_TAPS; ++t) { p.dyt[t] = d->dy[t]; p.dxt[t] = d->dx[t]; p.wtap[t] = d->wtap[t]; }
@@ -601,6 +617,71 @@ extern "C" int sm3_conv_wgrad_slabs(const sm3_conv_desc* d, const void* x, const
     const int rc = wgrad_impl(d, x, dy, slabs, nullptr, 0, nullptr, views, 0, 0, stream, slab_capacity);
     if (rc == 0) *slabs_used = g_last_slabs;
     return rc;
+}
+
+// ---- sm3_slab_reduce ------------------------------------------------------------------------------------------------
+// out[e] (+)= sum_j slabs[j][e], j = 0 .. nslabs - 1, in an order that depends on nothing but (nslabs, e): a workgroup owns
+// 128 consecutive elements (32 float4 columns) x 8 slab lanes; lane l adds slabs l, l + 8, ... on four interleaved
+// accumulators, the eight lane sums are added in lane order through LDS.  One writer per element: plain stores.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int nslabs, long n,
+                                                          float* __restrict__ out, int accumulate) {
+    __shared__ float4 red[8][32];
+    const int col = threadIdx.x & 31, jl = threadIdx.x >> 5;
+    const long e4 = ((long)blockIdx.x * 32 + col) * 4;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    auto add = [](float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+    if (e4 < n) {
+        const float* src = slabs + e4;
+        int j = jl;
+        for (; j + 24 < nslabs; j += 32) {
+            const float4 v0 = *reinterpret_cast<const float4*>(src + (long)j * n);
+            const float4 v1 = *reinterpret_cast<const float4*>(src + (long)(j + 8) * n);
+            const float4 v2 = *reinterpret_cast<const float4*>(src + (long)(j + 16) * n);
+            const float4 v3 = *reinterpret_cast<const float4*>(src + (long)(j + 24) * n);
+            add(a0, v0); add(a1, v1); add(a2, v2); add(a3, v3);
+        }
+        for (; j < nslabs; j += 8) add(a0, *reinterpret_cast<const float4*>(src + (long)j * n));
+        add(a0, a1);
+        add(a2, a3);
+        add(a0, a2);
+    }
+    red[jl][col] = a0;
+    __syncthreads();
+    if (jl == 0 && e4 < n) {
+        float4 t = red[0][col];
+#pragma unroll
+        for (int l = 1; l < 8; ++l) add(t, red[l][col]);
+        float4* o = reinterpret_cast<float4*>(out + e4);
+        if (accumulate) {
+            float4 g = *o;
+            add(g, t);
+            t = g;
+        }
+        *o = t;
+    }
+}
+
+extern "C" int sm3_slab_reduce(const float* slabs, int nslabs, int64_t n, float* out, int accumulate, void* stream) {
+    if (!slabs || !out || nslabs < 1 || n < 4 || n % 4) return SM3_EINVAL;
+    if (((uintptr_t)slabs | (uintptr_t)out) & 15) return SM3_EALIGN;
+    const long blocks = (n / 4 + 31) / 32;
+    if (blocks > 0x7fffffffL) return SM3_EINVAL;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, slabs, nslabs, (long)n,
+                       out, accumulate);
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+// dw += dY^T X as a function of its inputs: plain-store split-K slabs (one per pixel slice, the partition a function of the
+// geometry and the device) and ONE fixed-order sum into dw -- no float atomics, so two runs of a step give the same bits.
+extern "C" int sm3_conv_wgrad_det(const sm3_conv_desc* d, const void* x, const void* dy, float* dw, float* slabs,
+                                  int slab_capacity, void* stream) {
+    if (!slabs || !dw || slab_capacity < 1) return SM3_EINVAL;
+    if (d && d->ntaps * d->Ci != d->w_row_stride) return SM3_EINVAL;  // every slab a dense [Co][taps * Ci] matrix
+    if (((uintptr_t)slabs | (uintptr_t)dw) & 15) return SM3_EALIGN;
+    const int rc = wgrad_impl(d, x, dy, slabs, nullptr, 0, nullptr, 1, 0, 0, stream, slab_capacity, dw);
+    if (rc != 0 || g_last_slabs == 0) return rc;  // 0 slabs: a single slice added its tiles to dw itself
+    return sm3_slab_reduce(slabs, g_last_slabs, (int64_t)d->Co * d->w_row_stride, dw, 1, stream);
 }
 
 extern "C" int sm3_conv_wgrad_cat(const sm3_conv_desc* d, const void* x, const void* dy, float* dw, const void* dy1,

@@ -184,30 +184,34 @@ __global__ __launch_bounds__(256) void linbn_stats_kernel(const float* __restric
                                                           float* dbeta, double inv_count, float4* __restrict__ coef, int C,
                                                           int p, int views) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);  // (view, co)
-    if (row >= views * C) return;
-    const int v = row / C, co = row - v * C;
-    const float* pr = P + ((long)v * C + co) * p;
+    const int co = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (co >= C) return;
     const T* wr = w + (long)co * p;
-    double acc = 0.0, s1 = 0.0;
-    for (int k = lane; k < p; k += 64) acc += (double)pr[k] * (double)ElemTraits<T>::load(wr + k);
-    for (int g = lane; g < groups; g += 64) s1 += ws[((long)v * groups + g) * 2 * C + co];
+    // one wave per channel walks the views of the launch IN ORDER, so d(gamma) / d(beta) receive their addends in a fixed
+    // order (a step's gradients are a function of its inputs); atomics only because both lanes of a SHARED projector may add
+    // to the same parameter from two streams
+    for (int v = 0; v < views; ++v) {
+        const float* pr = P + ((long)v * C + co) * p;
+        double acc = 0.0, s1 = 0.0;
+        for (int k = lane; k < p; k += 64) acc += (double)pr[k] * (double)ElemTraits<T>::load(wr + k);
+        for (int g = lane; g < groups; g += 64) s1 += ws[((long)v * groups + g) * 2 * C + co];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        acc += __shfl_xor(acc, o, 64);
-        s1 += __shfl_xor(s1, o, 64);
-    }
-    if (lane == 0) {
-        const float is = invstd[(long)v * C + co], mu = mean[(long)v * C + co];
-        const double s2 = (double)is * (acc - (double)mu * s1);
-        double* ls = lsums + (long)v * 2 * C;
-        ls[co] = s1;
-        ls[C + co] = s2;
-        if (dbeta) atomicAdd(&dbeta[co], (float)s1);   // atomics: both views (and both lanes of a shared projector) add
-        if (dgamma) atomicAdd(&dgamma[co], (float)s2);
-        if (inv_count > 0) {
-            const float a = (gamma ? gamma[co] : 1.f) * is;
-            coef[(long)v * C + co] = make_float4(a, a * is * (float)(s2 * inv_count), (float)(s1 * inv_count), mu);
+        for (int o = 32; o > 0; o >>= 1) {
+            acc += __shfl_xor(acc, o, 64);
+            s1 += __shfl_xor(s1, o, 64);
+        }
+        if (lane == 0) {
+            const float is = invstd[(long)v * C + co], mu = mean[(long)v * C + co];
+            const double s2 = (double)is * (acc - (double)mu * s1);
+            double* ls = lsums + (long)v * 2 * C;
+            ls[co] = s1;
+            ls[C + co] = s2;
+            if (dbeta) atomicAdd(&dbeta[co], (float)s1);
+            if (dgamma) atomicAdd(&dgamma[co], (float)s2);
+            if (inv_count > 0) {
+                const float a = (gamma ? gamma[co] : 1.f) * is;
+                coef[(long)v * C + co] = make_float4(a, a * is * (float)(s2 * inv_count), (float)(s1 * inv_count), mu);
+            }
         }
     }
 }
@@ -479,7 +483,7 @@ extern "C" int sm3_linbn_stats(int dtype, const float* P, const void* w_fwd, con
     if (!P || !w_fwd || !mean || !invstd || !reduce_ws || !lsums) return SM3_EINVAL;
     if (C <= 0 || p <= 0 || views < 1 || groups < 1 || (count > 0 && !coef)) return SM3_EINVAL;
     if (!lin16(dtype)) return SM3_EDTYPE;
-    const unsigned blocks = (unsigned)((views * C + 3) / 4);
+    const unsigned blocks = (unsigned)((C + 3) / 4);  // one wave per channel, views walked in order
     const double inv = count > 0 ? 1.0 / count : 0.0;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SM3_BF16)

@@ -183,7 +183,8 @@ struct StemWgradParams {
     const float *mean, *invstd, *gamma;       // [views][64], [views][64], [64] (nullable)
     const double *gsums, *lsums;              // [views][128]
     float *dgamma, *dbeta;                    // nullable
-    float* dw;                                // [64][147] fp32, accumulated into
+    float* dw;                                // [64][147] fp32, accumulated into (float atomics) -- or, dw_slabs given,
+    float* dw_slabs;                          // workgroup b STORES its partial product to dw_slabs + b * 64 * 147 (no atomics)
     double inv_count;
     int N, H, W, Ho, Wo, xblocks, n_per_view, views;
     long tiles;
@@ -331,7 +332,8 @@ __global__ __launch_bounds__(256, 3) void stem_wgrad_kernel(const StemWgradParam
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-            atomicAdd(p.dw + co * 147 + kcol, acc[j][r]);
+            if (p.dw_slabs) p.dw_slabs[(long)blockIdx.x * (64 * 147) + co * 147 + kcol] = acc[j][r];
+            else atomicAdd(p.dw + co * 147 + kcol, acc[j][r]);
         }
     }
 }
@@ -548,7 +550,8 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_f32_kernel(const StemWgradP
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int co = cb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-            atomicAdd(p.dw + co * 147 + kcol, acc[j][q]);
+            if (p.dw_slabs) p.dw_slabs[(long)blockIdx.x * (64 * 147) + co * 147 + kcol] = acc[j][q];
+            else atomicAdd(p.dw + co * 147 + kcol, acc[j][q]);
         }
     }
 }
@@ -633,28 +636,30 @@ extern "C" int sm3_stem_conv_fwd(int dtype, const float* x_nchw, const void* w_s
 
 extern "C" int sm3_stem_wgrad_bn(int dtype, const float* x_nchw, const void* dz, const void* xo, const float* mean,
                                  const float* invstd, const float* gamma, const double* global_sums, double count,
-                                 const double* local_sums, float* dgamma, float* dbeta, float* dw, int N, int H, int W,
-                                 int views, void* stream) {
+                                 const double* local_sums, float* dgamma, float* dbeta, float* dw, float* dw_slabs,
+                                 int N, int H, int W, int views, void* stream) {
     if (!x_nchw || !dz || !xo || !mean || !invstd || !global_sums || !dw || count <= 0 || views < 1 || N % views)
         return SM3_EINVAL;
+    if (dw_slabs && (((uintptr_t)dw_slabs | (uintptr_t)dw) & 15)) return SM3_EALIGN;
     if (dtype != SM3_BF16 && dtype != SM3_F16 && dtype != SM3_F32) return SM3_EDTYPE;
     StemWgradParams p;
     if (int rc = stem_geometry(N, H, W, p.Ho, p.Wo, p.xblocks, p.tiles)) return rc;
     p.x = x_nchw; p.dz = (const char*)dz; p.xo = (const char*)xo;
     p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.gsums = global_sums; p.lsums = local_sums;
-    p.dgamma = dgamma; p.dbeta = dbeta; p.dw = dw; p.inv_count = 1.0 / count;
+    p.dgamma = dgamma; p.dbeta = dbeta; p.dw = dw; p.dw_slabs = dw_slabs; p.inv_count = 1.0 / count;
     p.N = N; p.H = H; p.W = W; p.n_per_view = N / views; p.views = views;
     if (dtype == SM3_F32) {
         const unsigned gridf = (unsigned)(p.tiles < 512 ? p.tiles : 512);
         hipLaunchKernelGGL(stem_wgrad_f32_kernel, dim3(gridf), dim3(256), 0, (hipStream_t)stream, p);
         SM3_CHECK_LAUNCH();
-        return 0;
+        return dw_slabs ? sm3_slab_reduce(dw_slabs, (int)gridf, 64 * 147, dw, 1, stream) : 0;
     }
-    const unsigned grid = (unsigned)(p.tiles < 768 ? p.tiles : 768);
+    const unsigned grid = (unsigned)(p.tiles < SM3_STEM_WGRAD_SLABS ? p.tiles : SM3_STEM_WGRAD_SLABS);
     if (dtype == SM3_BF16)
         hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(stem_wgrad_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     SM3_CHECK_LAUNCH();
-    return 0;
+    // the persistent grid and its tile walk are functions of the geometry: the slabs add up to the same bits in every run
+    return dw_slabs ? sm3_slab_reduce(dw_slabs, (int)grid, 64 * 147, dw, 1, stream) : 0;
 }

@@ -91,6 +91,8 @@ SIGNATURES = {
     "sm3_conv_bn_act_eval": [_DESC, _P, _P, _P, _P, _P, _I, _P, _P],
     "sm3_conv_bn_eval": [_DESC, _P, _P, _P, _P, _P, _P, _F, _P, _I, _P, _P],
     "sm3_conv_wgrad": [_DESC, _P, _P, _P, _P],
+    "sm3_conv_wgrad_det": [_DESC, _P, _P, _P, _P, _I, _P],
+    "sm3_slab_reduce": [_P, _I, _L, _P, _I, _P],
     "sm3_bn_stats_reduce": [_P, _I, _I, _P, _P, _I, _P],
     "sm3_bn_reduce_groups": [_I],
     "sm3_bn_finalize": [_P, _I, _I, _D, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
@@ -110,7 +112,7 @@ SIGNATURES = {
     "sm3_stem_weight_prep": [_I, _P, _P, _P],
     "sm3_stem_weight_prep_if": [_I, _P, _P, _P, _P],
     "sm3_stem_conv_fwd": [_I, _P, _P, _P, _P, _I, _I, _I, _P],
-    "sm3_stem_wgrad_bn": [_I, _P, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "sm3_stem_wgrad_bn": [_I, _P, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "sm3_maxpool3x3s2_fwd": [_I, _P, _P, _P, _I, _I, _I, _I, _P],
     "sm3_maxpool3x3s2_bwd": [_I, _P, _P, _P, _I, _I, _I, _I, _P],
     "sm3_weight_prep_batch": [_I, _P, _I, _P],

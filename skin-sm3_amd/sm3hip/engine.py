@@ -360,6 +360,14 @@ class SM3Engine:
         # opt-in, SM3_CONV_BNIN=1 (2 / 3: only the 64- / 128-column launches)
         self.bnin = _os.environ.get("SM3_CONV_BNIN", "0") != "0"
         self.lane_cross = _os.environ.get("SM3_LANE_CROSS", "1") != "0"  # cross-modal projector passes inside the lanes
+        if self.cross is not None and self.cross[0] is self.cross[1]:
+            # SimCLRSkinV3: ONE cross projector for both modalities -- inside the lanes its parameter gradients would receive
+            # the two modalities' addends in whichever order the streams run; on the main stream the order is the program's
+            self.lane_cross = False
+        # Weight gradients as functions of their inputs (round 6): every split-K product of the step is combined by a
+        # fixed-order sum of plain-store slabs (sm3_conv_wgrad_det, sm3_stem_wgrad_bn with slabs) instead of float atomics,
+        # so two runs of a training produce the same bits.  SM3_WGRAD_DET=0: the atomic forms (A/B switch).
+        self.det_wgrad = _os.environ.get("SM3_WGRAD_DET", "1") != "0"
 
     # ---- setup ---------------------------------------------------------------------------
     def _all_conv_units(self):
@@ -1044,7 +1052,13 @@ class SM3Engine:
         desc = cu.wgrad_desc(self.dtype, r.N, r.H, r.W)
         gw = self._g(cu.name + ".weight")
         if side is None:
-            ops.conv_wgrad(desc, r.x_in, dxo, gw)
+            if self.det_wgrad and desc.w_row_stride == desc.ntaps * desc.Ci:
+                # fixed-order split-K sum (plain-store slabs + sm3_slab_reduce): the gradient is a function of the inputs
+                n = desc.Co * desc.w_row_stride
+                cap = ops.wgrad_det_cap(n)
+                ops.conv_wgrad_det(desc, r.x_in, dxo, gw, self._work("wgrad_slabs", cap * n), cap)
+            else:
+                ops.conv_wgrad(desc, r.x_in, dxo, gw)
             return
         cur = torch.cuda.current_stream()
         side.wait_stream(cur)  # dxo is ready
@@ -1358,7 +1372,8 @@ class SM3Engine:
             bn = rs.bu.name
             ops.stem_wgrad_bn(self.dtype, rs.x_in, dz, rs.xo, rs.mean, rs.invstd, self._p(bn + ".weight"), gsums, count,
                               lsums, self._g(bn + ".weight"), self._g(bn + ".bias"), self._g(rs.cu.name + ".weight"),
-                              views=rs.V)
+                              views=rs.V,
+                              slabs=self._work("stem_slabs", ops.STEM_WGRAD_SLABS * 64 * 147) if self.det_wgrad else None)
         else:
             dxo, _ = self.bn_backward(rs, dz, keep_dz=False, fused_rows=prow)
             self.conv_backward(rs, dxo, need_dx=False)

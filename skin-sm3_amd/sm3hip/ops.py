@@ -458,6 +458,49 @@ def conv_wgrad(desc, x, dy, dw):
         check(_lib.load().sm3_conv_wgrad(C.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _stream()), "sm3_conv_wgrad")
 
 
+WGRAD_SLAB_CAP = 256          # slabs a deterministic weight-gradient launch may use (sm3_conv_wgrad_det)
+WGRAD_SLAB_FLOATS = 1 << 26   # ... within a workspace of at most max(this, 8 slabs) floats
+
+
+def wgrad_det_cap(n):
+    """Slabs of n floats the deterministic weight gradient gets: a function of n alone."""
+    return max(8, min(WGRAD_SLAB_CAP, WGRAD_SLAB_FLOATS // max(n, 1)))
+
+
+def conv_wgrad_det(desc, x, dy, dw, slabs, cap):
+    """dw += dy^T x with a fixed-order split-K sum instead of float atomics (sm3_conv_wgrad_det): bit-reproducible.
+    slabs: fp32 workspace with room for `cap` matrices [Co][taps * Ci]."""
+    tdt = TORCH_DTYPE[desc.dtype]
+    _chk(x, tdt, "x"); _chk(dy, tdt, "dy"); _chk(dw, torch.float32, "dw"); _chk(slabs, torch.float32, "slabs")
+    n = desc.Co * desc.w_row_stride
+    if x.numel() != desc.N * desc.Hi * desc.Wi * desc.Ci:
+        raise ValueError("x size does not match descriptor")
+    if dy.numel() != desc.N * desc.Ho * desc.Wo * desc.Co:
+        raise ValueError("dy size does not match descriptor")
+    if dw.numel() < n or desc.w_row_stride != desc.ntaps * desc.Ci:
+        raise ValueError("dw too small / padded weight rows")
+    if cap < 1 or slabs.numel() < cap * n:
+        raise ValueError("conv_wgrad_det: slab buffer too small")
+    M = desc.N * desc.Ho * desc.Wo
+    sz = _sz(desc.dtype)
+    tag = "conv_wgrad"
+    if _PROFILER is not None and getattr(_PROFILER, "detail", False):
+        tag += f"|M{M}_K{desc.ntaps}x{desc.Ci}_N{desc.Co}"
+    with _prof(tag, 2.0 * M * desc.Co * desc.ntaps * desc.Ci, sz * (x.numel() + dy.numel()) + 4 * n):
+        check(_lib.load().sm3_conv_wgrad_det(C.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _ptr(slabs), int(cap), _stream()),
+              "sm3_conv_wgrad_det")
+
+
+def slab_reduce(slabs, nslabs, n, out, accumulate=False):
+    """out[:n] (+)= sum of nslabs slabs of n floats, fixed order (sm3_slab_reduce)."""
+    _chk(slabs, torch.float32, "slabs"); _chk(out, torch.float32, "out")
+    if slabs.numel() < nslabs * n or out.numel() < n or n % 4 or nslabs < 1:
+        raise ValueError("slab_reduce: size mismatch")
+    with _prof("slab_reduce", 0.0, 4.0 * n * (nslabs + 1)):
+        check(_lib.load().sm3_slab_reduce(_ptr(slabs), int(nslabs), int(n), _ptr(out), int(bool(accumulate)), _stream()),
+              "sm3_slab_reduce")
+
+
 def conv_wgrad_cat(desc, x, dy, dw, dy1=None, dw1=None, views=1):
     """P[v] = dy_v^T x_v -> dw [views][Co][Ci] (and, with dy1, G[v] = dy1_v^T x_v -> dw1 [views][Co1][Ci]) in one launch
     (sm3_conv_wgrad_cat), accumulated into fp32 buffers the caller zeroed."""
@@ -1058,8 +1101,12 @@ def stem_conv_fwd(dtype, x_nchw, w_stem, y, partials=None):
               "sm3_stem_conv_fwd")
 
 
-def stem_wgrad_bn(dtype, x_nchw, dz, xo, mean, invstd, gamma, gsums, count, lsums, dgamma, dbeta, dw, views=1):
-    """Stem weight gradient with bn1's backward apply fused into the operand load (sm3_stem_wgrad_bn; bf16 / fp16 / exact f32)."""
+STEM_WGRAD_SLABS = 768  # SM3_STEM_WGRAD_SLABS (include/sm3_hip.h)
+
+
+def stem_wgrad_bn(dtype, x_nchw, dz, xo, mean, invstd, gamma, gsums, count, lsums, dgamma, dbeta, dw, views=1, slabs=None):
+    """Stem weight gradient with bn1's backward apply fused into the operand load (sm3_stem_wgrad_bn; bf16 / fp16 / exact f32).
+    slabs: fp32 workspace of STEM_WGRAD_SLABS * 64 * 147 floats -> fixed-order sum instead of float atomics."""
     tdt = TORCH_DTYPE[dtype]
     _chk(x_nchw, torch.float32, "x"); _chk(dz, tdt, "dz"); _chk(xo, tdt, "xo"); _chk(dw, torch.float32, "dw")
     for t in (mean, invstd, gamma, dgamma, dbeta):
@@ -1072,11 +1119,14 @@ def stem_wgrad_bn(dtype, x_nchw, dz, xo, mean, invstd, gamma, gsums, count, lsum
     if mean.numel() < views * 64 or invstd.numel() < views * 64 or gsums.numel() < views * 128 or \
             (lsums is not None and lsums.numel() < views * 128):
         raise ValueError("stem_wgrad_bn: per-channel vector too small")
+    _chk(slabs, torch.float32, "slabs")
+    if slabs is not None and slabs.numel() < STEM_WGRAD_SLABS * 64 * 147:
+        raise ValueError("stem_wgrad_bn: slab workspace too small")
     M = N * Ho * Wo
     with _prof("stem_wgrad_bn", 2.0 * M * 64 * 147, 4.0 * x_nchw.numel() + 2 * _sz(dtype) * dz.numel()):
         check(_lib.load().sm3_stem_wgrad_bn(dtype, _ptr(x_nchw), _ptr(dz), _ptr(xo), _ptr(mean), _ptr(invstd), _ptr(gamma),
                                             _ptr(gsums), float(count), _ptr(lsums), _ptr(dgamma), _ptr(dbeta), _ptr(dw),
-                                            N, H, W, views, _stream()), "sm3_stem_wgrad_bn")
+                                            _ptr(slabs), N, H, W, views, _stream()), "sm3_stem_wgrad_bn")
 
 
 def maxpool_fwd(dtype, x, y, N, H, W, Cn, argmax=None):

@@ -187,14 +187,30 @@ class SM3Trainer:
             if p2p is not None:
                 # a statistics exchange that timed out: the kernel has poisoned its sums (this step's loss is NaN), and
                 # the flag raises here no later than the next step -- without a host wait inside the step
-                p2p.poll()
+                try:
+                    p2p.poll()
+                except RuntimeError:
+                    self._sync_step_count()
+                    raise
             return loss
 
     def check(self):
         """Raise if a peer-to-peer statistics exchange has failed so far (synchronises; no-op on the RCCL path)."""
         p2p = self.__dict__.get("_p2p")
         if p2p is not None:
-            p2p.check()
+            try:
+                p2p.check()
+            except RuntimeError:
+                self._sync_step_count()
+                raise
+
+    def _sync_step_count(self):
+        """After a failed peer-to-peer exchange: the host's step counter back to the optimizer steps really APPLIED (the device
+        counts them, `_p2p_taken`), so that a checkpoint written by a caller who catches the error resumes with the bias
+        correction of the last good step."""
+        taken = self.__dict__.get("_p2p_taken")
+        if taken is not None:
+            self.step_count = int(taken.item())
 
     def close(self, barrier=True):
         """Release the peer-to-peer mailboxes (SM3_SYNCBN_P2P=1); safe to call more than once."""
@@ -346,13 +362,20 @@ class SM3Trainer:
         if early or dp_buckets:
             pass  # every bucket has had its AdamW launch (on the lane that finished it / behind its all-reduce)
         elif sc is None:
-            self.step_count += 1
             skip = None
             if p2p is not None:
                 skip = p2p.err.clone()
                 ops.check_finite(st.flat_g, skip)
+                if self.__dict__.get("_p2p_taken") is None:
+                    self._p2p_taken = torch.full((1,), self.step_count, dtype=torch.int32, device=dev)
+            self.step_count += 1
             ops.adamw(st.flat_p, st.flat_g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
                       self.step_count, 1.0 / self.world, skip)
+            if skip is not None:
+                # optimizer steps APPLIED, counted where the decision was made (the error is sticky: once a step is skipped
+                # every later one is, so step_count - 1 == taken whenever an update is applied)
+                self._p2p_taken += (skip == 0).to(torch.int32)
+                self._p2p_skip = skip
         else:
             # GradScaler.step() + update() (backbone_train.py:126-127) without a host synchronisation: inf / nan check
             # of the (all-reduced, still scaled) gradients, unscale + AdamW skipped on overflow, scale update
@@ -363,14 +386,24 @@ class SM3Trainer:
                                   self.scaler_cfg[2], self.scaler_cfg[3])
             self.step_count += 1  # calls made; the number of optimizer steps TAKEN lives on the device (steps_taken())
         if self.target_momentum is not None:
-            ops.ema_update(self.flat_target, st.flat_p, self.target_momentum)
+            skip = self.__dict__.pop("_p2p_skip", None)
+            if skip is not None:
+                # a skipped step must not move the target either: the EMA factor becomes 0 on the device, no host read
+                w = (1.0 - self.target_momentum) * (skip == 0).to(torch.float32)
+                self.flat_target.add_((st.flat_p - self.flat_target) * w)
+            else:
+                ops.ema_update(self.flat_target, st.flat_p, self.target_momentum)
+        self.__dict__.pop("_p2p_skip", None)
         eng.weights_dirty = True  # raw-pointer writes: the engine's filter banks are stale
         self.loss = loss
         return loss
 
     def steps_taken(self):
         """Optimizer steps actually applied (a step skipped for an fp16 overflow does not count); synchronises."""
-        return int(self._scaler["steps"]) if self._scaler is not None else self.step_count
+        if self._scaler is not None:
+            return int(self._scaler["steps"])
+        taken = self.__dict__.get("_p2p_taken")
+        return int(taken.item()) if taken is not None else self.step_count
 
     # ---- checkpoint wire format: tools/backbone_train.py:578-587 ---------------------------
     def optimizer_state_dict(self):

@@ -28,7 +28,7 @@ def pytest_configure(config):
 _FILE_GROUP = {
     "test_oracle_golden": 0, "test_abi": 0, "test_host_logic": 0,
     "test_e2e_gpu": 0,
-    "test_kernels_gpu": 1, "test_linbn_gpu": 1,
+    "test_kernels_gpu": 1, "test_linbn_gpu": 1, "test_round6_gpu": 1,
     "test_augment": 2, "test_augment_pil": 2, "test_linear_probe": 2, "test_inference_model": 2, "test_mlc": 2,
     "test_config_gpu": 3, "test_round3_gpu": 3, "test_round4_gpu": 3,
     "test_more_gpu": 4, "test_layer_order_gpu": 4,

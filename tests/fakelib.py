@@ -30,7 +30,7 @@ class _FakeFn:
             args[6]._obj.value = 1  # slabs used per view
             return 0
         if self.name == "sm3_abi_version":
-            return 7
+            return 8
         return 0
 
 

@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_symbol():
     lib = _lib.load()
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.sm3_abi_version() == 7
+    assert lib.sm3_abi_version() == 8
 
 
 def test_arg_rejection_launches_nothing():

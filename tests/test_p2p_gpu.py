@@ -136,10 +136,10 @@ def _missing_peer_main(rank, world, port, q):
         model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
         model.sm3_dtype = torch.bfloat16
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model).to(dev)
-        tr = SM3Trainer(model, lr=1e-3)
+        tr = SM3Trainer(model, lr=1e-3, target_momentum=0.99)
         tr._engine()  # both ranks map each other's mailboxes ...
         tr._bucket_ready = lambda *a: None  # (no gradient all-reduce: this is about the statistics exchange, and rank 1 is absent)
-        out = {"nan": True, "check": True, "step": True, "s": 0.0, "params_kept": True}
+        out = {"nan": True, "check": True, "step": True, "s": 0.0, "params_kept": True, "count_kept": True}
         if rank == 0:  # ... but only rank 0 steps: its peer never raises a flag
             import time
             batch = ([torch.from_numpy(a).to(dev) for a in derm_np], [torch.from_numpy(a).to(dev) for a in clinic_np])
@@ -153,16 +153,22 @@ def _missing_peer_main(rank, world, port, q):
             st = tr._engine().store
             out["params_kept"] = bool(torch.equal(st.flat_p, before)) and float(tr.m.abs().max()) == 0.0 \
                 and float(tr.v.abs().max()) == 0.0 and not bool(torch.isfinite(st.flat_g).all())
+            # ... and the momentum target did not move: it started as a copy of the online parameters
+            out["params_kept"] = out["params_kept"] and bool(torch.equal(tr.flat_target, before))
             try:
                 tr.check()
                 out["check"] = False
             except RuntimeError:
                 pass
+            # the step counter a checkpoint would carry is that of the last APPLIED step: none
+            out["count_kept"] = tr.step_count == 0 and tr.steps_taken() == 0 and \
+                (tr.optimizer_state_dict()["state"][0]["step"].item() == 0.0)
             try:
                 tr.step(*batch)
                 out["step"] = False
             except RuntimeError:
                 pass
+            out["count_kept"] = out["count_kept"] and tr.step_count == 0
         dist.barrier()
         tr.close(barrier=False)
         dist.destroy_process_group()
@@ -179,6 +185,7 @@ def test_trainer_step_with_a_missing_peer_fails_loudly():
     res = _spawn(_missing_peer_main)
     assert res[0]["nan"] and res[0]["check"] and res[0]["step"], res[0]
     assert res[0]["params_kept"], res[0]
+    assert res[0]["count_kept"], res[0]
     assert res[0]["s"] < 15.0, res[0]  # 220 exchanges x 0.5 s would be 110 s
 
 

@@ -1,0 +1,168 @@
+"""Round-6 cases (GPU), through the C ABI: a training step is a FUNCTION OF ITS INPUTS.
+
+  * sm3_conv_wgrad_det (plain-store split-K slabs + one fixed-order sum) against fp64 `conv2d_weight` on the shapes of
+    test_kernels_gpu, bit-identical over repeats with and without a second stream keeping the chip busy, and within fp32
+    rounding of the float-atomic form it replaces;
+  * sm3_slab_reduce against an fp64 sum, store and accumulate forms;
+  * the stem weight gradient with slabs against the atomic form and over repeats;
+  * three optimizer steps of the whole model, twice from the same state, in the three arithmetic modes: every parameter
+    bit, every AdamW moment bit and all three losses equal (reference: tools/backbone_train.py:98-127 is a deterministic
+    program on the reference's CPU path, SURVEY.md 8c "fp32 CPU reruns are bitwise reproducible").
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_config_gpu import DEV, _batch, _build
+from test_kernels_gpu import CONV_CASES, DTYPES3, IDS3, _ops, dev, nhwc, rnd, tol
+
+pytestmark = pytest.mark.gpu
+
+
+def _busy(n=6):
+    """A second stream that keeps every CU busy while the kernels under test run (perturbs the order in which workgroups
+    are dispatched and retire -- what an order-dependent sum would be sensitive to)."""
+    st = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=DEV)
+    with torch.cuda.stream(st):
+        for _ in range(n):
+            a = (a @ a).clamp_(-1, 1)
+    return st, a
+
+
+DET_CASES = CONV_CASES + [
+    # many pixel slices: layer-1 shapes of the step at B = 32 / 64 x 64 and a 3x3 with 36 tiles
+    (64, 64, 64, 56, 56, 1, 1, 0),
+    (32, 64, 64, 56, 56, 3, 1, 1),
+    (64, 256, 128, 28, 28, 1, 1, 0),
+    (32, 256, 256, 14, 14, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES3, ids=IDS3)
+@pytest.mark.parametrize("case", DET_CASES)
+def test_conv_wgrad_det_is_exact_and_a_function_of_its_inputs(case, dt):
+    ops = _ops()
+    N, Ci, Co, H, W, k, s, p = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dy = torch.randn(N, Co, Ho, Wo, generator=g)
+    code = ops.dtype_code(dt)
+    xr, dyr = rnd(x, dt), rnd(dy, dt)
+    ref_dw = torch.nn.grad.conv2d_weight(xr.double(), (Co, Ci, k, k), dyr.double(), stride=s, padding=p)
+    xd, dyd = nhwc(x, dt), nhwc(dy, dt)
+    d = ops.fwd_desc(code, N, H, W, Ci, Co, k, s, p)
+    n = Co * k * k * Ci
+    cap = ops.wgrad_det_cap(n)
+    slabs = torch.full((cap * n,), float("nan"), device=dev())  # whatever is read must have been written by this launch
+    base = torch.randn(Co, k * k * Ci, generator=g).to(dev())   # the gradient buffer already holds something: dw += ...
+    outs = []
+    for rep in range(4):
+        dw = base.clone()
+        busy = _busy() if rep % 2 else None
+        ops.conv_wgrad_det(d, xd, dyd, dw, slabs, cap)
+        torch.cuda.synchronize()
+        del busy
+        outs.append(dw)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    got = (outs[0] - base).cpu().reshape(Co, k, k, Ci).permute(0, 3, 1, 2)
+    sc = ref_dw.abs().max().item()
+    assert (got.double() - ref_dw).abs().max().item() < tol(dt, sc) * 2
+    # the float-atomic form computes the same sum in another order
+    dwa = base.clone()
+    ops.conv_wgrad(d, xd, dyd, dwa)
+    torch.cuda.synchronize()
+    assert (dwa - outs[0]).abs().max().item() < 1e-5 * max(sc, 1.0) * math.sqrt(N * Ho * Wo / 64 + 1)
+
+
+@pytest.mark.parametrize("nslabs,n", [(1, 64), (3, 4096), (8, 9408), (37, 128 * 576), (256, 4096), (768, 9408)])
+def test_slab_reduce(nslabs, n):
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(nslabs * 7 + n)
+    slabs = torch.randn(nslabs, n, device=DEV, generator=g)
+    out = torch.full((n + 4,), 7.0, device=DEV)
+    ops.slab_reduce(slabs.view(-1), nslabs, n, out, accumulate=False)
+    ref = slabs.double().sum(0)
+    assert (out[:n].double() - ref).abs().max().item() < 1e-5 * math.sqrt(nslabs) * 4
+    assert bool((out[n:] == 7.0).all())                      # nothing past n is touched
+    first = out[:n].clone()
+    ops.slab_reduce(slabs.view(-1), nslabs, n, out, accumulate=True)
+    assert torch.equal(out[:n], first + first)               # out + (the same fixed-order sum)
+    again = torch.empty(n, device=DEV)
+    ops.slab_reduce(slabs.view(-1), nslabs, n, again, accumulate=False)
+    assert torch.equal(again, first)
+
+
+@pytest.mark.parametrize("dt", DTYPES3, ids=IDS3)
+@pytest.mark.parametrize("views", [1, 2])
+def test_stem_wgrad_with_slabs_equals_the_atomic_form_and_repeats_bit_for_bit(dt, views):
+    ops = _ops()
+    code = ops.dtype_code(dt)
+    N, H, W = 8 * views, 64, 64
+    Ho, Wo = H // 2, W // 2
+    g = torch.Generator(device=DEV).manual_seed(11 + views)
+    x = torch.randn(N, 3, H, W, device=DEV, generator=g)
+    dz = torch.randn(N * Ho * Wo, 64, device=DEV, generator=g).to(dt)
+    xo = torch.randn(N * Ho * Wo, 64, device=DEV, generator=g).to(dt)
+    mean = torch.randn(views * 64, device=DEV, generator=g) * 0.1
+    invstd = torch.rand(views * 64, device=DEV, generator=g) + 0.5
+    gamma = torch.rand(64, device=DEV, generator=g) + 0.5
+    gsums = torch.randn(views * 128, device=DEV, generator=g, dtype=torch.float64)
+    count = float(N // views * Ho * Wo)
+    slabs = torch.full((ops.STEM_WGRAD_SLABS * 64 * 147,), float("nan"), device=DEV)
+
+    def run(use_slabs, busy):
+        dw = torch.ones(64 * 147, device=DEV)
+        dg, db = torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
+        b = _busy() if busy else None
+        ops.stem_wgrad_bn(code, x, dz, xo, mean, invstd, gamma, gsums, count, gsums, dg, db, dw, views=views,
+                          slabs=slabs if use_slabs else None)
+        torch.cuda.synchronize()
+        del b
+        return dw, dg, db
+
+    ref = run(False, False)
+    outs = [run(True, i % 2 == 1) for i in range(4)]
+    for o in outs[1:]:
+        for a, b in zip(o, outs[0]):
+            assert torch.equal(a, b)
+    sc = float((ref[0] - 1).abs().max())
+    assert float((outs[0][0] - ref[0]).abs().max()) < 2e-5 * max(sc, 1.0)
+    assert torch.equal(outs[0][1], ref[1]) and torch.equal(outs[0][2], ref[2])   # d(gamma), d(beta): one thread, view order
+
+
+@pytest.mark.parametrize("dt", DTYPES3, ids=IDS3)
+def test_three_training_steps_are_a_function_of_their_inputs(dt):
+    """Two trainers from one state, three AdamW steps each on three different batches (the second one beside a stream that
+    keeps the chip busy): losses, parameters, moments and gradients equal to the last bit."""
+    from sm3hip.trainer import SM3Trainer
+    B, S = 32, 64
+    batches = [_batch(B, S, 60 + i) for i in range(3)]
+    runs = []
+    for rep in range(2):
+        model = _build(17, dt)
+        tr = SM3Trainer(model, lr=1e-3, weight_decay=5e-2, eps=1e-5, style=0, init_scale=256.0)
+        eng = tr._engine()
+        assert eng.det_wgrad
+        busy = _busy(40) if rep else None
+        losses = [float(tr.step(*b)) for b in batches]
+        torch.cuda.synchronize()
+        del busy
+        if dt == torch.float16:
+            assert tr.steps_taken() == 3
+        st = eng.store
+        runs.append((losses, st.flat_p.clone(), tr.m.clone(), tr.v.clone(), st.flat_g.clone(),
+                     {k: v.clone() for k, v in model.state_dict().items() if "running" in k}))
+        del tr, eng, model
+        torch.cuda.empty_cache()
+    a, b = runs
+    assert a[0] == b[0], (a[0], b[0])
+    for i, name in ((1, "parameters"), (2, "exp_avg"), (3, "exp_avg_sq"), (4, "gradients")):
+        assert torch.equal(a[i], b[i]), (name, int((a[i] != b[i]).sum()))
+    for k in a[5]:
+        assert torch.equal(a[5][k], b[5][k]), k
+    assert all(l == l for l in a[0]) and a[0][0] != a[0][1]
