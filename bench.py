@@ -251,7 +251,8 @@ def mlc_train_bench(args):
     dev = torch.device("cuda", 0)
     torch.manual_seed(3407)
     B, S = (128 if args.batch == 256 else args.batch), args.img
-    margs = mt.get_parser().parse_args(["-b", str(B), "--mlc-proj-dim", "512", "--sa-dim-ff", "128"])  # run.sh:39-47
+    margs = mt.get_parser().parse_args(["--data-name", "synthetic", "--data-path", "-", "-b", str(B), "--mlc-proj-dim", "512",
+                                       "--sa-dim-ff", "128"])  # run.sh:39-47
     ex = SimCLRSkinV32(arch="resnet50", proj_dim=128)
     ex.derm_backbone.projector = ex.clinic_backbone.projector = ex.cross_proj = None
     ex.sm3_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]

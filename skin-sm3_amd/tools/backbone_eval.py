@@ -26,26 +26,16 @@ from src.models.baseline import Baseline  # noqa: E402
 
 
 def get_parser():
-    p = argparse.ArgumentParser(description="SM3 linear probe / fine-tune (MI355X)")
-    p.add_argument("--data-name", type=str, required=True)
-    p.add_argument("--data-path", type=str, required=True)
-    p.add_argument("--img-sz", nargs=2, type=int, default=[224, 224])
-    p.add_argument("-a", "--arch", default="resnet50", type=str)
+    """src/utils/misc.py:get_parser + tools/backbone_eval.py:434-440 of the reference, then this build's own flags."""
+    from src.utils.misc import get_parser as base_parser
+    p = base_parser("SM3 linear probe / fine-tune (MI355X)")
     p.add_argument("--arch-weights", type=str, default=None)
-    p.add_argument("--finetune", default="fc", type=str)
-    p.add_argument("--epochs", default=50, type=int)
+    p.add_argument("--num-labels", type=int, default=8)
+    p.add_argument("--label-weights", type=float, nargs="*", default=[1.0] * 8)
+    # this build (synthetic data: an epoch is a number of steps)
     p.add_argument("--steps-per-epoch", default=8, type=int)
     p.add_argument("--val-steps", default=4, type=int)
-    p.add_argument("-b", "--batch-size", default=128, type=int)
-    p.add_argument("-lr", "--base-lr", default=1e-3, type=float)
-    p.add_argument("--wd", default=5e-2, type=float)
-    p.add_argument("--num-labels", type=int, default=8)
-    p.add_argument("--label-weights", type=float, nargs=8, default=[1.0] * 8)
-    p.add_argument("--pretrain-path", type=str, default=None)
-    p.add_argument("--amp", action="store_true")
-    p.add_argument("--seed", type=int, default=3407)
-    p.add_argument("--print-freq", type=int, default=50)
-    p.add_argument("--log-path", type=str, default="./logs")
+    p.set_defaults(arch="resnet50", epochs=50, batch_size=128)
     return p
 
 
@@ -85,8 +75,14 @@ def run_epoch(args, evaluator, criterion, optimizer, steps, gen, dev, train):
             loss = loss / args.num_labels
         if train:
             optimizer.zero_grad(set_to_none=True)
-            loss.backward()
-            optimizer.step()
+            scaler = getattr(args, "scaler", None)  # backbone_eval.py:100-112 of the reference: GradScaler(enabled=args.amp)
+            if scaler is None:
+                loss.backward()
+                optimizer.step()
+            else:
+                scaler.scale(loss).backward()
+                scaler.step(optimizer)
+                scaler.update()
         total += float(loss.detach())
         all_preds.append([o.detach() for o in outputs])
         all_targets.append(labels)
@@ -99,7 +95,11 @@ def run_epoch(args, evaluator, criterion, optimizer, steps, gen, dev, train):
 
 
 def main():
-    args = get_parser().parse_args()
+    parser = get_parser()
+    args = parser.parse_args()
+    from src.utils.misc import amp_dtype, describe_ignored
+    if describe_ignored(args, parser):
+        print("accepted for compatibility, without effect in this build:", " ".join(describe_ignored(args, parser)), flush=True)
     if args.data_name != "synthetic":
         raise SystemExit("only --data-name synthetic is available in this build (dataset pipeline is out of scope)")
     torch.manual_seed(args.seed)
@@ -111,7 +111,8 @@ def main():
     if args.finetune == "fc":
         evaluator.freeze_backbone()
     for m in (evaluator.derm_backbone, evaluator.clinic_backbone):
-        m.sm3_dtype = torch.bfloat16 if args.amp else torch.float32
+        m.sm3_dtype = amp_dtype(args)
+    args.scaler = torch.amp.GradScaler("cuda", enabled=amp_dtype(args) == torch.float16)  # backbone_eval.py:271
     evaluator.to(dev)
     params = [p for p in evaluator.parameters() if p.requires_grad]
     optimizer = torch.optim.AdamW(params, lr=args.base_lr, weight_decay=args.wd)

@@ -9,10 +9,11 @@ Differences, stated: the derm7pt dataset and its PIL augmentation pipeline are h
 (SURVEY.md 2.1 #9-10), so `--data-name synthetic` generates normalised image pairs on the device; `--engine fused`
 (default) runs the fused step of sm3hip.trainer.SM3Trainer, `--engine compat` runs the reference's literal loop
 (model(...) -> CrossEntropyLoss -> backward -> torch.optim.AdamW, backbone_train.py:98-127) on the same kernels.
-`--amp` selects 16-bit MFMA arithmetic: `--amp-dtype bf16` (default; BASELINE.json's benchmark type, needs no loss
-scaling) or `--amp-dtype fp16` -- the reference's own AMP recipe (fp16 autocast + GradScaler, backbone_train.py:27,98,
-125-127,480): fp16 storage + f16 MFMA with dynamic loss scaling, on the device in the fused engine and through
-torch.cuda.amp.GradScaler itself in the compat engine; without `--amp` the exact-f32 MFMA mode runs.
+`--amp` means what the reference's means (fp16 autocast + GradScaler, backbone_train.py:27,98,125-127,480): fp16 storage
++ f16 MFMA with dynamic loss scaling, on the device in the fused engine and through torch.cuda.amp.GradScaler itself in
+the compat engine; `--amp --amp-dtype bf16` selects bf16 (BASELINE.json's benchmark type, needs no loss scaling);
+without `--amp` the exact-f32 MFMA mode runs.  Every flag of the reference's parser is accepted (src/utils/misc.py); the
+ones without a meaning here (-j, --proj-name, --wandb, ...) are parsed, listed once at start-up, and ignored.
 """
 import argparse
 import os
@@ -33,41 +34,30 @@ from src.models.simclr import SimCLRSkinV3, SimCLRSkinV32  # noqa: E402
 
 
 def get_parser():
-    p = argparse.ArgumentParser(description="SM3 SSL pre-training (MI355X)")
-    p.add_argument("--data-name", type=str, required=True)
-    p.add_argument("--data-path", type=str, required=True)
-    p.add_argument("--img-sz", nargs=2, type=int, default=[224, 224])
-    p.add_argument("--mean", nargs=3, type=float, default=[0.485, 0.456, 0.406])  # src/utils/misc.py:get_parser
-    p.add_argument("--std", nargs=3, type=float, default=[0.229, 0.224, 0.225])
-    p.add_argument("-a", "--arch", default="resnet50", type=str)
+    """src/utils/misc.py:get_parser + tools/backbone_train.py:612-624 of the reference, then this build's own flags."""
+    from src.utils.misc import get_parser as base_parser
+    p = base_parser("SM3 SSL pre-training (MI355X)")
+    p.add_argument("--arch-version", default="v3", type=str, choices=["v3", "v311", "v312", "v32", "v321", "v322"])
     p.add_argument("--arch-weights", default=None, type=str)
-    p.add_argument("--arch-version", default="v32", type=str,
-                   choices=["v3", "v311", "v312", "v32", "v321", "v322"])
+    p.add_argument("--ft-lr", default=1e-3, type=float, help="finetune learning rate (unused by the reference's loop too)")
     p.add_argument("--proj-dim", default=128, type=int)
-    p.add_argument("--temperature", default=0.1, type=float)
+    p.add_argument("--temperature", default=0.5, type=float)
+    p.add_argument("--modality-weights", nargs=2, type=float, default=[1.0, 1.0])
+    p.add_argument("--num-labels", type=int, default=8)
+    p.add_argument("--label-weights", type=float, nargs="*", default=[1.0] * 8)
     p.add_argument("--use-checkpoint", action="store_true")
-    p.add_argument("--epochs", default=100, type=int)
+    # this build
     p.add_argument("--steps-per-epoch", default=100, type=int, help="synthetic data only")
     p.add_argument("--synthetic-kind", default="noise", choices=["noise", "latent"],
                    help="synthetic data: independent noise (throughput) or learnable latent-pattern pairs")
-    p.add_argument("-b", "--batch-size", default=64, type=int, help="global mini-batch size")
-    p.add_argument("-lr", "--base-lr", default=1e-3, type=float)
-    p.add_argument("--wd", default=5e-2, type=float)
-    p.add_argument("--port", default=29533, type=int)
-    p.add_argument("--seed", type=int, default=3407)
-    p.add_argument("--save-freq", type=int, default=50)
-    p.add_argument("--print-freq", type=int, default=50)
-    p.add_argument("--amp", action="store_true")
-    p.add_argument("--amp-dtype", default="bf16", choices=["bf16", "fp16"])
     p.add_argument("--global-negatives", action="store_true",
                    help="extension (not reference behaviour): NT-Xent against the all-gathered projections of all ranks; "
                         "world * 2 * batch and --proj-dim must be multiples of 32")
     p.add_argument("--gpu-augment", action="store_true",
                    help="synthetic uint8 source images + the reference's augmentation chain on the GPU instead of "
                         "ready-made normalised tensors")
-    p.add_argument("--resume-path", type=str, default=None)
-    p.add_argument("--log-path", type=str, default="./logs")
     p.add_argument("--engine", default="fused", choices=["fused", "compat"])
+    p.set_defaults(arch="resnet50", port=29533)
     return p
 
 
@@ -107,8 +97,9 @@ def main(local_rank, args):
     cls = SimCLRSkinV3 if args.arch_version in ("v3", "v311", "v312") else SimCLRSkinV32
     model = cls(arch=args.arch, weights=args.arch_weights, proj_dim=args.proj_dim, temperature=args.temperature,
                 use_checkpoint=args.use_checkpoint)
-    model.sm3_dtype = (torch.float16 if args.amp_dtype == "fp16" else torch.bfloat16) if args.amp else torch.float32
-    fp16 = args.amp and args.amp_dtype == "fp16"
+    from src.utils.misc import amp_dtype
+    model.sm3_dtype = amp_dtype(args)
+    fp16 = model.sm3_dtype == torch.float16
     if world > 1:
         model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
     model = model.to(dev)
@@ -186,7 +177,11 @@ def main(local_rank, args):
 
 
 if __name__ == "__main__":
-    args = get_parser().parse_args()
+    parser = get_parser()
+    args = parser.parse_args()
+    from src.utils.misc import describe_ignored
+    if describe_ignored(args, parser):
+        print("accepted for compatibility, without effect in this build:", " ".join(describe_ignored(args, parser)), flush=True)
     args.world_size = int(os.environ.get("SM3_WORLD_SIZE", torch.cuda.device_count()))
     try:
         if args.world_size > 1:

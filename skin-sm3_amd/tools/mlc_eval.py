@@ -54,32 +54,26 @@ class Model(nn.Module):
 
 
 def get_parser():
-    p = argparse.ArgumentParser("SM3 multi-label eval / fine-tune (MI355X)")
-    p.add_argument("--data-name", default="synthetic")
-    p.add_argument("--data-path", default="-")
-    p.add_argument("-a", "--arch", default="resnet50")
-    p.add_argument("-b", "--batch-size", type=int, default=128)
-    p.add_argument("-lr", "--base-lr", type=float, default=1e-3)
-    p.add_argument("--wd", type=float, default=5e-2)
-    p.add_argument("--epochs", type=int, default=100)
-    p.add_argument("--steps-per-epoch", type=int, default=8)
-    p.add_argument("--val-steps", type=int, default=4)
-    p.add_argument("--img-sz", nargs=2, type=int, default=[224, 224])
-    p.add_argument("--seed", type=int, default=3407)
-    p.add_argument("--log-path", default="./logs/mlc_eval")
-    p.add_argument("--amp", action="store_true", help="bf16 encoders")
-    p.add_argument("--num-labels", type=int, default=8)
-    p.add_argument("--label-weights", type=float, nargs=8, default=[1.0] * 8)
-    p.add_argument("--extractor-proj-dim", type=int, default=128)
+    """src/utils/misc.py:get_parser + tools/mlc_eval.py:509-524 of the reference, then this build's own flags."""
+    from src.utils.misc import get_parser as base_parser
+    p = base_parser("SM3 multi-label eval / fine-tune (MI355X)")
     p.add_argument("--mlc-proj", type=str, default="v4")
     p.add_argument("--mlc-proj-dim", type=int, default=256)
     p.add_argument("--num-heads", type=int, default=1)
     p.add_argument("--sa-dim-ff", type=int, default=256)
     p.add_argument("--sa-dropout", type=float, default=0.1)
+    p.add_argument("--arch-weights", type=str, default=None)
+    p.add_argument("--extractor-proj-dim", type=int, default=128)
+    p.add_argument("--num-labels", type=int, default=8)
+    p.add_argument("--label-weights", type=float, nargs="*", default=[1.0] * 8)
     p.add_argument("--l2-norm", action="store_true")
     p.add_argument("--init-prototype", action="store_true")
-    p.add_argument("--pretrain-path", type=str, default="")
-    p.add_argument("--finetune", default="projector", choices=["fc", "projector", "all"])
+    p.add_argument("--train-sz", type=int, default=224)
+    p.add_argument("--test-sz", type=int, default=224)
+    # this build (synthetic data: an epoch is a number of steps)
+    p.add_argument("--steps-per-epoch", type=int, default=8)
+    p.add_argument("--val-steps", type=int, default=4)
+    p.set_defaults(arch="resnet50", batch_size=128, finetune="projector", pretrain_path="", log_path="./logs/mlc_eval")
     return p
 
 
@@ -119,8 +113,14 @@ def run_epoch(args, evaluator, criterion, optimizer, steps, gen, dev, train):
             loss = loss / args.num_labels
         if train:
             optimizer.zero_grad(set_to_none=True)
-            loss.backward()
-            optimizer.step()
+            scaler = getattr(args, "scaler", None)  # mlc_eval.py:157-170 of the reference: GradScaler(enabled=args.amp)
+            if scaler is None:
+                loss.backward()
+                optimizer.step()
+            else:
+                scaler.scale(loss).backward()
+                scaler.step(optimizer)
+                scaler.update()
         total += float(loss.detach())
         preds_all.append([o.detach() for o in outputs])
         targets_all.append(labels)
@@ -143,7 +143,9 @@ def main(argv=None):
     extractor.derm_backbone.projector = None  # mlc_eval.py:339-341
     extractor.clinic_backbone.projector = None
     extractor.cross_proj = None
-    extractor.sm3_dtype = torch.bfloat16 if args.amp else torch.float32
+    from src.utils.misc import amp_dtype
+    extractor.sm3_dtype = amp_dtype(args)
+    args.scaler = torch.amp.GradScaler("cuda", enabled=amp_dtype(args) == torch.float16)  # mlc_eval.py:331
     feat_dim = extractor.derm_feat_dim + extractor.clinic_feat_dim
     evaluator = Model(extractor, MultiLabelProjector4(feat_dim, args.mlc_proj_dim, args.num_labels), args.mlc_proj_dim,
                       args.l2_norm, args.num_heads, args.sa_dim_ff, args.sa_dropout)

@@ -53,23 +53,9 @@ class Model(nn.Module):
 
 
 def get_parser():
-    p = argparse.ArgumentParser("SM3 DeepCluster Training v3 (MI355X)")
-    p.add_argument("--data-name", default="synthetic")
-    p.add_argument("--data-path", default="-")
-    p.add_argument("-a", "--arch", default="resnet50")
-    p.add_argument("-b", "--batch-size", type=int, default=256)
-    p.add_argument("-lr", "--base-lr", type=float, default=1e-4)
-    p.add_argument("--wd", type=float, default=5e-2)
-    p.add_argument("--epochs", type=int, default=150)
-    p.add_argument("--img-sz", nargs=2, type=int, default=[224, 224])
-    p.add_argument("--num-samples", type=int, default=413, help="size of the synthetic training split (derm7pt: 413)")
-    p.add_argument("--seed", type=int, default=3407)
-    p.add_argument("--save-freq", type=int, default=50)
-    p.add_argument("--print-freq", type=int, default=10)
-    p.add_argument("--log-path", default="./logs/mlc_train")
-    p.add_argument("--port", type=int, default=29512)
-    p.add_argument("--amp", action="store_true", help="bf16 encoders (the reference runs this tool in fp32)")
-    # mlc_train.py:446-457
+    """src/utils/misc.py:get_parser + tools/mlc_train.py:446-457 of the reference, then this build's own flags."""
+    from src.utils.misc import get_parser as base_parser
+    p = base_parser("SM3 DeepCluster Training v3 (MI355X)")
     p.add_argument("--num-labels", type=int, default=8)
     p.add_argument("--extractor-proj-dim", type=int, default=128)
     p.add_argument("--extractor-weights", type=str, default=None)
@@ -81,6 +67,10 @@ def get_parser():
     p.add_argument("--temperature", type=float, default=0.1)
     p.add_argument("--l2-norm", action="store_true")
     p.add_argument("--finetune-backbone", action="store_true")
+    # this build
+    p.add_argument("--num-samples", type=int, default=413, help="size of the synthetic training split (derm7pt: 413)")
+    p.set_defaults(arch="resnet50", batch_size=256, base_lr=1e-4, epochs=150, print_freq=10, log_path="./logs/mlc_train",
+                   port=29512)
     return p
 
 
@@ -165,7 +155,8 @@ def main(local_rank, args):
     extractor.derm_backbone.projector = None   # mlc_train.py:344-346
     extractor.clinic_backbone.projector = None
     extractor.cross_proj = None
-    extractor.sm3_dtype = torch.bfloat16 if args.amp else torch.float32
+    from src.utils.misc import amp_dtype
+    extractor.sm3_dtype = amp_dtype(args)  # frozen encoders: no gradient passes through the 16-bit arithmetic
     if not args.finetune_backbone:
         for p in extractor.parameters():
             p.requires_grad = False
@@ -244,7 +235,11 @@ def main(local_rank, args):
 
 
 if __name__ == "__main__":
-    args = get_parser().parse_args()
+    parser = get_parser()
+    args = parser.parse_args()
+    from src.utils.misc import describe_ignored
+    if describe_ignored(args, parser):
+        print("accepted for compatibility, without effect in this build:", " ".join(describe_ignored(args, parser)), flush=True)
     args.world_size = int(os.environ.get("SM3_WORLD_SIZE", torch.cuda.device_count()))
     try:
         if args.world_size > 1:

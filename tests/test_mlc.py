@@ -173,7 +173,7 @@ def test_mlc_train_tool_runs_and_learns(tmp_path):
     spec = importlib.util.spec_from_file_location("sm3_mlc_train", os.path.join(tools, "mlc_train.py"))
     mt = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mt)
-    args = mt.get_parser().parse_args(["--data-name", "synthetic", "--epochs", "3", "-b", "32", "--num-samples", "96",
+    args = mt.get_parser().parse_args(["--data-name", "synthetic", "--data-path", "-", "--epochs", "3", "-b", "32", "--num-samples", "96",
                                        "--img-sz", "64", "64", "--log-path", str(tmp_path), "--temperature", "1",
                                        "--mlc-proj-dim", "128", "--sa-dim-ff", "64", "--sa-dropout", "0.1", "-lr", "1e-3",
                                        "--save-freq", "1"])
@@ -232,11 +232,11 @@ def test_mlc_eval_tool_finetunes_from_an_mlc_train_checkpoint(tmp_path, mode):
         spec.loader.exec_module(mod)
         return mod
     mt, me = load("mlc_train"), load("mlc_eval")
-    targs = mt.get_parser().parse_args(["--epochs", "1", "-b", "16", "--num-samples", "32", "--img-sz", "64", "64",
+    targs = mt.get_parser().parse_args(["--data-name", "synthetic", "--data-path", "-", "--epochs", "1", "-b", "16", "--num-samples", "32", "--img-sz", "64", "64",
                                         "--log-path", str(tmp_path / "train"), "--mlc-proj-dim", "128", "--sa-dim-ff", "64"])
     targs.world_size = 1
     mt.main(0, targs)
-    hist = me.main(["--epochs", "2", "-b", "16", "--steps-per-epoch", "3", "--val-steps", "2", "--img-sz", "64", "64",
+    hist = me.main(["--data-name", "synthetic", "--data-path", "-", "--epochs", "2", "-b", "16", "--steps-per-epoch", "3", "--val-steps", "2", "--img-sz", "64", "64",
                     "--log-path", str(tmp_path / "eval"), "--mlc-proj-dim", "128", "--sa-dim-ff", "64", "--finetune", mode,
                     "--pretrain-path", str(tmp_path / "train" / "ckp_0.pth")])
     assert len(hist) == 2 and all(math.isfinite(t["loss"]) and 0.0 <= v["AUC_AVG"] <= 1.0 for t, v in hist)

@@ -47,7 +47,7 @@ def test_config4_mlc_train_step_b64_224_bf16_at_size():
     from src.models.simclr import SimCLRSkinV32
     torch.manual_seed(3407)
     B, S = 64, 224
-    margs = mt.get_parser().parse_args(["-b", str(B)] + RUN_SH)
+    margs = mt.get_parser().parse_args(["--data-name", "synthetic", "--data-path", "-", "-b", str(B)] + RUN_SH)
     ex = SimCLRSkinV32(arch="resnet50", proj_dim=128)
     ex.derm_backbone.projector = ex.clinic_backbone.projector = ex.cross_proj = None   # mlc_train.py:344-346
     ex.sm3_dtype = torch.bfloat16
@@ -114,7 +114,7 @@ def _rank_main(rank, world, port, q, log_path):
                 sys.path.insert(0, p)
         torch.set_num_threads(4)
         mt = _tool()
-        args = mt.get_parser().parse_args(["--data-name", "synthetic", "--epochs", "1", "-b", "128", "--num-samples", "128",
+        args = mt.get_parser().parse_args(["--data-name", "synthetic", "--data-path", "-", "--epochs", "1", "-b", "128", "--num-samples", "128",
                                            "--img-sz", "224", "224", "--amp", "--log-path", log_path, "--save-freq", "1"]
                                           + RUN_SH)
         args.world_size, args.port, args.probe = world, port, {}
