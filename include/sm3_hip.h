@@ -363,6 +363,23 @@ int sm3_stem_wgrad_bn(int dtype, const float* x_nchw, const void* dz, const void
                       const float* invstd, const float* gamma, const double* global_sums, double count,
                       const double* local_sums, float* dgamma, float* dbeta, float* dw, float* dw_slabs, int N, int H, int W,
                       int views, void* stream);
+/* The same two kernels on images rounded to the 16-bit type ONCE per step (ABI 8; what the training step uses in the
+ * 16-bit modes; every output bit equals sm3_stem_conv_fwd / sm3_stem_wgrad_bn on the fp32 images -- the rounding is the
+ * same, it only happens once instead of per staged tile, forward and again in the weight gradient):
+ *   sm3_stem_image_prep: ximg [views * n_per_view][3][H][Wp] dtype, Wp = sm3_stem_image_cols(W) = round_up(W + 6, 8),
+ *     ximg[.., q] = x[.., q - 3] for 3 <= q < W + 3, else 0 (the convolution's zero padding materialised); the views of a
+ *     branch come from two NCHW fp32 tensors (x_view1 NULL with views = 1) -- no concatenated copy of the images is made.
+ *   sm3_stem_conv_fwd16 / sm3_stem_wgrad_bn16: arguments as the fp32-image forms with ximg in place of x_nchw; the staged
+ *     rows are aligned 16-byte chunks of ximg moved by LDS-DMA one tile ahead.  resnet.py:208-213,294-295. */
+int sm3_stem_image_cols(int W);
+int sm3_stem_image_prep(int dtype, const float* x_view0, const float* x_view1, void* ximg, int n_per_view, int views, int H,
+                        int W, void* stream);
+int sm3_stem_conv_fwd16(int dtype, const void* ximg, const void* w_stem, void* y, float* stat_partials, int N, int H, int W,
+                        void* stream);
+int sm3_stem_wgrad_bn16(int dtype, const void* ximg, const void* dz, const void* xo, const float* mean, const float* invstd,
+                        const float* gamma, const double* global_sums, double count, const double* local_sums,
+                        float* dgamma, float* dbeta, float* dw, float* dw_slabs, int N, int H, int W, int views,
+                        void* stream);
 /* argmax (nullable): [N,Ho,Wo,C] bytes, window position kh*3+kw of the first maximum in scan order (ATen's tie rule) */
 int sm3_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* argmax, int N, int H, int W, int C, void* stream);
 /* dx[n,iy,ix,c] = sum of dy over the windows whose recorded argmax is (iy,ix); gather form, no atomics */

@@ -579,16 +579,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         q[e] = k0[e] * is * (float)(gsums[C + c] * inv_count);  //  than the rows a thread walks)
     }
     if (blockIdx.y == 0 && blockIdx.z == 0 && ty == 0 && lsums) {
-        // parameter gradients from the LOCAL sums, once per channel: ONE thread adds the views of the launch in view order
-        // (a fixed order: a step's gradients are a function of its inputs).  Still atomics, because two launches may add to
-        // the same parameter from two streams (SM3_VIEW_LANES=1) -- within a stream the order is the launch order.
+        // parameter gradients from the LOCAL sums, once per channel: ONE thread adds up the views of the launch in view order
+        // and issues ONE add per parameter (a fixed order: a step's gradients are a function of its inputs).  The add stays
+        // an atomic because two launches may meet on a parameter from two streams (SM3_VIEW_LANES=1).  All loads first, then
+        // the atomics: interleaved, each load would wait for the atomic before it (possible aliasing) -- 4 us per launch.
+        float db[E], dg[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) db[e] = dg[e] = 0.f;
+        for (int v = 0; v < (int)gridDim.z; ++v) {
+            const double* l = lsums + (int64_t)v * 2 * C + cv * E;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                db[e] += (float)l[e];
+                dg[e] += (float)l[C + e];
+            }
+        }
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const int c = cv * E + e;
-            for (int v = 0; v < (int)gridDim.z; ++v) {
-                if (dbeta) atomicAdd(&dbeta[c], (float)lsums[(int64_t)v * 2 * C + c]);
-                if (dgamma) atomicAdd(&dgamma[c], (float)lsums[(int64_t)v * 2 * C + C + c]);
-            }
+            if (dbeta) atomicAdd(&dbeta[cv * E + e], db[e]);
+            if (dgamma) atomicAdd(&dgamma[cv * E + e], dg[e]);
         }
     }
     const int64_t rstep = (int64_t)gridDim.y * tby;
@@ -653,16 +662,33 @@ __global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const T* __restrict_
             k0[e] = g * is;
             k1[e] = (float)(s.gsums[v2 + c] * inv_count);
             q[e] = k0[e] * is * (float)(s.gsums[v2 + C + c] * inv_count);
-            if (blockIdx.y == 0 && blockIdx.z == 0 && ty == 0 && s.lsums) {  // one thread, views in order (see bn_bwd_apply_kernel)
-                for (int v = 0; v < (int)gridDim.z; ++v) {
-                    if (s.dbeta) atomicAdd(&s.dbeta[c], (float)s.lsums[(int64_t)v * 2 * C + c]);
-                    if (s.dgamma) atomicAdd(&s.dgamma[c], (float)s.lsums[(int64_t)v * 2 * C + C + c]);
-                }
-            }
         }
     };
     coeffs(a, mua, k0a, k1a, qa);
     coeffs(b, mub, k0b, k1b, qb);
+    if (blockIdx.y == 0 && blockIdx.z == 0 && ty == 0) {  // one thread per channel, views in order, loads before atomics
+        auto param_grads = [&](const BnApplySide& s) {   // (see bn_bwd_apply_kernel)
+            if (!s.lsums) return;
+            float db[E], dg[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) db[e] = dg[e] = 0.f;
+            for (int v = 0; v < (int)gridDim.z; ++v) {
+                const double* l = s.lsums + (int64_t)v * 2 * C + cv * E;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    db[e] += (float)l[e];
+                    dg[e] += (float)l[C + e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (s.dbeta) atomicAdd(&s.dbeta[cv * E + e], db[e]);
+                if (s.dgamma) atomicAdd(&s.dgamma[cv * E + e], dg[e]);
+            }
+        };
+        param_grads(a);
+        param_grads(b);
+    }
     const int64_t rstep = (int64_t)gridDim.y * tby;
     auto finish = [&](int64_t r, const uint4& gu, const uint4& xau, const uint4& xbu) {
         float g[E], xv[E], o[E];

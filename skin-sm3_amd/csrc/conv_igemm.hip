@@ -22,9 +22,6 @@
 
 using namespace sm3conv;
 
-#ifndef SM3_CONV_PF
-#define SM3_CONV_PF 0  // 1: fragment double-buffering inside a K-step for the 2- / 4-stage 16-bit kernels (build-time A/B)
-#endif
 
 namespace {
 
@@ -72,12 +69,7 @@ struct StampRec {
 #define SM3_MARK(i) ((void)0)
 #endif
 
-// SPLIT (2-stage K loop only): the workgroup carries WM*WN extra LOADER waves (waves WM*WN ... 2*WM*WN-1).  They own the
-// tap bookkeeping and every LDS-DMA piece of the K loop and leave after it; the WM*WN CONSUMER waves (the only ones that
-// hold accumulators) issue nothing but ds_read_b128 + MFMA in the loop and run the epilogue alone.  Same stage ring,
-// same one barrier per K-step, same arithmetic in the same order: outputs are bit-identical to the unsplit kernel.
 // VAR (bit mask of variants that change instructions, never results):
-//   kVarSplit  the loader / consumer split above;
 //   kVarPw     POINTWISE launches (one tap at (0, 0) -- or two K segments over the same pixels --, stride 1, dense output, no
 //              compact addend): a tile row IS pixel m0 + r, so the loader state and the epilogue's row addresses are one
 //              multiply-add per row instead of the general gather's divisions and bounds tests.  These launches are the
@@ -86,9 +78,6 @@ struct StampRec {
 //   kVarNoX    EPI 3 without the producer's x (the linear BatchNorm forms: ReLU mask + sum(dz) only): no x operand stream,
 //              no sum(dz * xhat) arithmetic, and with the registers that frees ALL rows' operands are requested before the
 //              staging instead of half of them after it.
-//   kVarM16    the 16-bit MFMAs as v_mfma_f32_16x16x32 instead of 32x32x16: same LDS fragment traffic, same accumulator
-//              registers, same cycles per FLOP -- but the chip holds a higher clock on this shape under load
-//              (MI355X_MICROARCH.md, DVFS give-back item 7); lean epilogues only (the accumulator layout differs).
 //   kVarHalo   stride-1 3 x 3 launches (forward and data gradient): a tile's rows are 128 CONSECUTIVE pixels, so the nine taps
 //              of a channel chunk read the same W + 1 pixels either side of them.  The A image of a chunk (tile rows + that
 //              halo + one zero row) is staged ONCE and the nine K-steps of the chunk read it at a per-tap row shift (rows whose
@@ -100,24 +89,25 @@ struct StampRec {
 //              before the barrier that publishes the image: no extra barrier), in the arithmetic of bn_act_kernel, and
 //              writes the activation and its ReLU bits for the tile's own 128 rows -- the producer's separate apply pass
 //              (one read of that tensor and one launch per Bottleneck) disappears (forward half).
-constexpr int kVarSplit = 1, kVarPw = 2, kVarNoX = 4, kVarM16 = 8, kVarHalo = 16, kVarHaloBn = 32;
+// (bits 1 and 8 were the loader / consumer split and the 16 x 16 x 32 MFMA shape of round 4: measured slower two rounds
+// running and removed in round 6 -- profiles/r04a_split_ab_*.txt, r04a_mfma_16x16x32_ab_single_lane.txt, scratch/r6_pruned_variants.patch)
+constexpr int kVarPw = 2, kVarNoX = 4, kVarHalo = 16, kVarHaloBn = 32;
 template <typename T, int BM, int BN, int WM, int WN, int STAGES, int EPI, bool SEG = false, int VAR = 0>
 // registers: the 1-stage kernels (34 KB of LDS) run 4 workgroups per CU = 4 waves per SIMD, so their epilogues must fit 128
 // registers; the 2- and 4-stage kernels are limited to 2 / 1 workgroups per CU by their LDS and may use 256
-__global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * WN == 8 && STAGES == 1) ? 8 : ((EPI >= 1 && STAGES == 1) || (VAR & kVarSplit)) ? 4 : 2)) void conv_igemm_kernel(const ConvParams p) {
-    constexpr bool SPLIT = (VAR & kVarSplit) != 0, PW = (VAR & kVarPw) != 0, NOX = (VAR & kVarNoX) != 0;
-    constexpr bool M16 = (VAR & kVarM16) != 0, HALO = (VAR & kVarHalo) != 0, HALOBN = (VAR & kVarHaloBn) != 0;
+__global__ __launch_bounds__(WM* WN * 64, (EPI >= 1 && STAGES == 1) ? 4 : 2) void conv_igemm_kernel(const ConvParams p) {
+    static_assert(STAGES == 1 || STAGES == 4, "one-stage loop, or the 4-stage ring of the small-grid launches");
+    constexpr bool PW = (VAR & kVarPw) != 0, NOX = (VAR & kVarNoX) != 0;
+    constexpr bool HALO = (VAR & kVarHalo) != 0, HALOBN = (VAR & kVarHaloBn) != 0;
     static_assert(!HALOBN || (HALO && EPI == 1), "kVarHaloBn: the plain forward epilogue of the halo kernel");
-    static_assert(!HALO || (EPI >= 1 && STAGES == 1 && !SEG && !(VAR & (kVarSplit | kVarPw | kVarM16)) && sizeof(T) == 2 && WM * WN == 4),
+    static_assert(!HALO || (EPI >= 1 && STAGES == 1 && !SEG && !(VAR & kVarPw) && sizeof(T) == 2 && WM * WN == 4),
                   "kVarHalo: 16-bit lean one-stage kernels, 4 waves");
-    static_assert(!M16 || (EPI >= 1 && sizeof(T) == 2 && !SPLIT), "kVarM16: 16-bit lean epilogues");
     static_assert(!NOX || EPI == 3, "kVarNoX: the fused BN-backward epilogue");
 #ifdef SM3_STAMP
     StampRec stamp;
 #endif
     constexpr bool LEAN = EPI >= 1;
     static_assert(!(SEG && EPI == 1) && !(SEG && STAGES > 2), "segments: data-gradient epilogues, 1 or 2 stages");
-    static_assert(!SPLIT || STAGES == 2, "loader / consumer waves: 2-stage K loop");
     constexpr int NT = WM * WN * 64;
     constexpr int RPP = NT / 8;  // rows covered per loader pass
     constexpr int AI = BM / RPP, BI = BN / RPP;
@@ -135,11 +125,8 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int wave_all = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);  // provably wave-uniform
-    const bool is_loader = SPLIT && wave_all >= WM * WN;
-    // loader waves index the tile rows exactly like the unsplit kernel's waves do (tid 0 .. NT-1)
-    const int tid = SPLIT ? (int)threadIdx.x - (is_loader ? NT : 0) : (int)threadIdx.x, lane = tid & 63;
-    const int wave = SPLIT ? wave_all - (is_loader ? WM * WN : 0) : wave_all;  // (LDS-DMA base goes to M0)
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);  // provably wave-uniform (LDS-DMA base goes to M0)
+    const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wm = wave / WN, wn = wave % WN;
 
     // XCD-aware block remap (bijective): blocks that share an A row-panel run on one XCD's L2.
@@ -246,30 +233,13 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
         for (int i = 0; i < BI; ++i) dma16(rw, sB + i * (RPP * 128), b_off[i], soff_b);
     };
 
-    f32x16 acc[M16 ? 1 : TM][M16 ? 1 : TN];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < (M16 ? 1 : TM); ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < (M16 ? 1 : TN); ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // kVarM16: 16 x 16 tiles, four accumulator registers each; lane = (column j = lane & 15, row group g = lane >> 4),
-    // register r = row 4 g + r of the tile
-    constexpr int TM4 = WTM / 16, TN4 = WTN / 16;
-    f32x4 acc4[M16 ? TM4 : 1][M16 ? TN4 : 1];
-#pragma unroll
-    for (int i = 0; i < (M16 ? TM4 : 1); ++i)
-#pragma unroll
-        for (int j = 0; j < (M16 ? TN4 : 1); ++j) acc4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // fragment of a 16 x 16 x 32 MFMA: lane (row l & 15, K group l >> 4) holds 8 consecutive k = chunk 4 h + (l >> 4) of
-    // its row for K half h: base(l >> 4) ^ (h << 6), by the same XOR linearity as below
-    uint32_t fa4[M16 ? TM4 : 1], fb4[M16 ? TN4 : 1];
-    if constexpr (M16) {
-#pragma unroll
-        for (int i = 0; i < TM4; ++i) fa4[i] = lds_off(wm * WTM + i * 16 + (lane & 15), lane >> 4);
-#pragma unroll
-        for (int j = 0; j < TN4; ++j) fb4[j] = A_BYTES + lds_off(wn * WTN + j * 16 + (lane & 15), lane >> 4);
-    }
 
     // fragment read offsets: chunk (2*kk + fh) of row r sits at r*128 + (((2*kk+fh) ^ (r>>1)) & 7) * 16
     //   = base(r, fh) ^ (kk << 5)   (bits 5-6 of the offset carry kk; r*128 leaves them clear)
@@ -282,46 +252,6 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
 
     auto compute = [&](int stage) {
         const char* sS = smem + stage * STAGE;
-        if constexpr (SPLIT || (SM3_CONV_PF && STAGES >= 2 && sizeof(T) == 2)) {
-            // consumer waves: the fragments of K-quarter kk+1 are requested before the MFMAs of quarter kk are issued
-            // (a second fragment register set: the loop has them to spare, the epilogue sets the kernel's maximum)
-            uint4 fa[2][TM], fb[2][TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const uint4*>(sS + fa_base[i]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const uint4*>(sS + fb_base[j]);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                if (kk < 3) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        fa[(kk + 1) & 1][i] = *reinterpret_cast<const uint4*>(sS + (fa_base[i] ^ ((kk + 1) << 5)));
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        fb[(kk + 1) & 1][j] = *reinterpret_cast<const uint4*>(sS + (fb_base[j] ^ ((kk + 1) << 5)));
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) mma_frag<T>(fa[kk & 1][i], fb[kk & 1][j], acc[i][j]);
-            }
-            return;
-        }
-        if constexpr (M16) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                uint4 fa[TM4], fb[TN4];
-#pragma unroll
-                for (int i = 0; i < TM4; ++i) fa[i] = *reinterpret_cast<const uint4*>(sS + (fa4[i] ^ (h << 6)));
-#pragma unroll
-                for (int j = 0; j < TN4; ++j) fb[j] = *reinterpret_cast<const uint4*>(sS + (fb4[j] ^ (h << 6)));
-#pragma unroll
-                for (int i = 0; i < TM4; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN4; ++j) mma_frag16<T>(fa[i], fb[j], acc4[i][j]);
-            }
-            return;
-        }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             uint4 fa[TM], fb[TN];
@@ -519,28 +449,6 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
         stamp.t_loop1 = SM3_STAMP_NOW();
 #endif
         __syncthreads();  // the epilogue re-uses the image
-    } else if constexpr (SPLIT) {
-        if (is_loader) {
-            dma_stage(0, 0, wtap_off);
-            dma_drain();
-            __syncthreads();  // publishes stage 0
-            for (int s = 0; s < nsteps; ++s) {
-                if (s + 1 < nsteps) {
-                    advance();
-                    dma_stage((s + 1) & 1, (uint32_t)kc * 128u, wtap_off + (uint32_t)kc * 128u);
-                }
-                dma_drain();      // stage s+1 has landed (this wave's pieces)
-                __syncthreads();  // ... everyone's; the consumers are done reading stage s
-            }
-            return;  // a terminated wave no longer counts at s_barrier: the epilogue belongs to the consumers
-        }
-        if (p.dbg & 1) __builtin_amdgcn_s_setprio(1);
-        __syncthreads();
-        for (int s = 0; s < nsteps; ++s) {
-            compute(s & 1);
-            __syncthreads();
-        }
-        if (p.dbg & 1) __builtin_amdgcn_s_setprio(0);
     } else {
     dma_stage(0, 0, wtap_off);
     if constexpr (STAGES > 2) {
@@ -565,42 +473,6 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
             compute(s % STAGES);
         }
         __syncthreads();  // the epilogue re-uses the stage memory
-    } else if constexpr (STAGES == 2) {
-        dma_drain();
-        __syncthreads();  // publishes the stage
-#ifdef SM3_STAMP
-        stamp.t_loop0 = SM3_STAMP_NOW();
-        stamp.mark[1] = stamp.t_loop0;
-        stamp.nsteps = nsteps;
-#endif
-        for (int s = 0; s < nsteps; ++s) {
-#ifdef SM3_STAMP
-            const unsigned long long q0 = SM3_STAMP_NOW();
-#endif
-            if (s + 1 < nsteps) {
-                advance();
-                dma_stage((s + 1) & 1, (uint32_t)kc * 128u, wtap_off + (uint32_t)kc * 128u);
-            }
-#ifdef SM3_STAMP
-            const unsigned long long q1 = SM3_STAMP_NOW();
-#endif
-            compute(s & 1);
-#ifdef SM3_STAMP
-            const unsigned long long q2 = SM3_STAMP_NOW();
-#endif
-            dma_drain();      // this wave's part of stage s+1 has landed
-#ifdef SM3_STAMP
-            const unsigned long long q3 = SM3_STAMP_NOW();
-#endif
-            __syncthreads();  // everyone's has; and everyone is done reading stage s
-#ifdef SM3_STAMP
-            const unsigned long long q4 = SM3_STAMP_NOW();
-            stamp.seg[0] += q1 - q0; stamp.seg[1] += q2 - q1; stamp.seg[2] += q3 - q2; stamp.seg[3] += q4 - q3;
-#endif
-        }
-#ifdef SM3_STAMP
-        stamp.t_loop1 = SM3_STAMP_NOW();
-#endif
     } else {
         dma_drain();
         __syncthreads();  // publishes the stage
@@ -643,7 +515,7 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
         stamp.t_loop1 = SM3_STAMP_NOW();
 #endif
     }
-    }  // !SPLIT
+    }
     SM3_MARK(2);
 
     // ---- lean epilogue: bf16 forward convolution, dense output, no addend / BN-backward fusion ----------------
@@ -725,8 +597,8 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
         // phase of the fused-BatchNorm forward launches took) now hides behind the issue of the row requests
         const bool epl = p.ep_scale != nullptr || p.ep_rv != nullptr;
         const bool aff = epl || (SEG && p.col_bias);
-        constexpr int NCB = M16 ? TN4 : TN, CBW = M16 ? 16 : 32;  // column blocks of this lane, their width
-        const int lcol = M16 ? (lane & 15) : frow;
+        constexpr int NCB = TN, CBW = 32;  // column blocks of this lane, their width
+        const int lcol = frow;
         float esc_j[NCB], esh_j[NCB];
 #pragma unroll
         for (int j = 0; j < NCB; ++j) {
@@ -756,45 +628,6 @@ __global__ __launch_bounds__(WM* WN * 64 * ((VAR & kVarSplit) ? 2 : 1), ((WM * W
         const bool early_relu = epl && p.ep_relu && (EPI == 1 || !p.addend) && !p.ep_mask;
         auto stage_tile = [&](auto stats_c, auto aff_c) {
             constexpr bool STATS = decltype(stats_c)::value, AFF = decltype(aff_c)::value;
-            if constexpr (M16) {
-                const int g4 = lane >> 4;
-#pragma unroll
-                for (int j = 0; j < TN4; ++j) {
-                    float s1 = 0.f, s2 = 0.f;
-                    char* colp = sC + (wn * WTN + j * 16 + lcol) * 2 + (wm * WTM + 4 * g4) * LEAN_PITCH;
-                    const float esc = esc_j[j], esh = esh_j[j], elo = (AFF && early_relu) ? 0.f : -INFINITY;
-#pragma unroll
-                    for (int i = 0; i < TM4; ++i)
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {  // registers 2q, 2q+1 = rows 16 i + 4 g + 2q, +1 of this lane's column
-                            float v0 = acc4[i][j][2 * q], v1 = acc4[i][j][2 * q + 1];
-                            if constexpr (AFF) {
-                                v0 = fmaxf(v0 * esc + esh, elo);
-                                v1 = fmaxf(v1 * esc + esh, elo);
-                            }
-                            const uint32_t pk = pack2<T>(v0, v1);
-                            if constexpr (STATS) {
-                                s1 = dot2acc<T>(pk, ones, s1);
-                                s2 = dot2acc<T>(pk, pk, s2);
-                            }
-                            const int R = i * 16 + 2 * q;
-                            *reinterpret_cast<uint16_t*>(colp + R * LEAN_PITCH) = (uint16_t)pk;
-                            *reinterpret_cast<uint16_t*>(colp + (R + 1) * LEAN_PITCH) = (uint16_t)(pk >> 16);
-                        }
-                    if constexpr (STATS) {
-                        s1 += __shfl_xor(s1, 16, 64);
-                        s2 += __shfl_xor(s2, 16, 64);
-                        s1 += __shfl_xor(s1, 32, 64);
-                        s2 += __shfl_xor(s2, 32, 64);
-                        if (lane < 16) {
-                            const int col = wn * WTN + j * 16 + lane;
-                            sStat[(wm * BN + col) * 2 + 0] = s1;
-                            sStat[(wm * BN + col) * 2 + 1] = s2;
-                        }
-                    }
-                }
-                return;
-            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 float s1 = 0.f, s2 = 0.f;
@@ -1231,7 +1064,6 @@ static int conv_halo_tall_mode() {
 
 template <typename T, int BM, int BN, int WM, int WN, int STAGES, int EPI, bool SEG = false, int VAR = 0>
 int launch_conv_st(const ConvParams& p0, hipStream_t st) {
-    constexpr bool SPLIT = (VAR & kVarSplit) != 0;
     ConvParams p = p0;
     {
         const char* dv = getenv("SM3_CONV_DBG");
@@ -1270,24 +1102,9 @@ int launch_conv_st(const ConvParams& p0, hipStream_t st) {
     }
     const long nblocks = (long)p.tilesM * p.tilesN;
     if (nblocks <= 0 || nblocks > 0x7fffffffL) return SM3_EINVAL;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(WM * WN * 64 * (SPLIT ? 2 : 1)), LDS, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(WM * WN * 64), LDS, st, p);
     SM3_CHECK_LAUNCH();
     return 0;
-}
-
-// SM3_CONV_SPLIT (A/B switch, read at every launch): loader / consumer waves in the 2-stage K loop of
-//   bit 0: the plain forward launches (EPI 1) with >= 4 K-steps per tap on 128-column tiles -- where it measures faster
-//          (profiles/r04a_split_ab.txt: +3 ... +17 % at Ci >= 256, nothing at Ci = 128, -12 % on the 64-column tiles),
-//   bit 4: bit 0 without the shape rule.  (EPI 2 / EPI 3 / two-segment launches measured 12 - 37 % SLOWER split -- their
-//   epilogues spill at the 128 registers of 16 waves per CU -- and are no longer built.)
-static int conv_split_mode() {
-    const char* v = getenv("SM3_CONV_SPLIT");
-    return v ? atoi(v) : 0;  // default off: inside a step it equals the 8-wave variant on the 3x3 forward launches (+-0.5 %)
-}
-template <int EPI, int BN>
-static bool conv_split_wanted(const ConvParams& p) {
-    const int m = conv_split_mode();
-    return EPI == 1 && ((m & 16) || ((m & 1) && BN == 128 && p.kchunks >= 4));
 }
 
 // SM3_CONV_PW (A/B switch, read at every launch; default 3): bit 0 = the pointwise variants (kVarPw) for the launches that
@@ -1304,25 +1121,13 @@ static bool conv_is_pointwise(const ConvParams& p) {
     return dense && taps0 && p.sy == 1 && p.sx == 1 && p.Hi * p.Wi == p.HoWo && p.add_sp_h == 0;
 }
 
-// The 16 x 16 x 32 MFMA shape (kVarM16) in the one-stage lean launches: measured 4 % SLOWER over the convolution class
-// (3x3 forward 920 -> 870 TFLOP/s, step 4 346 -> 4 266 pairs/s, gpurun_out r4e15) -- twice the MFMA instructions per
-// K-step cost more issue slots than the shape's clock advantage returns in a loop that is not MFMA-dense -- and one
-// epilogue variant of it fails a kernel test.  Built only with -DSM3_CONV_M16_BUILD (then SM3_CONV_M16=1 selects it).
-static int conv_m16_mode() {
-#ifdef SM3_CONV_M16_BUILD
-    const char* v = getenv("SM3_CONV_M16");
-    return v ? atoi(v) : 0;
-#else
-    return 0;
-#endif
-}
-
-// 16-bit lean epilogues on the 1- or 2-stage K loop
+// 16-bit lean epilogues on the one-stage K loop (34 KB of LDS, 4 workgroups per CU overlapping each other: it won at every
+// K length measured in round 4, profiles/r04a_stage_choice_*; the double-buffered loop of rounds 1-3 was removed in round 6)
 template <typename T, int BM, int BN, int WM, int WN, int EPI, bool SEG>
-int launch_conv_lean(const ConvParams& p, hipStream_t st, bool single) {
+int launch_conv_lean(const ConvParams& p, hipStream_t st) {
     if constexpr (!SEG && EPI == 1 && BM == 128 && WM == 2 && WN == 2) {
         // 256 x 64 tiles: whole 64-column tiles only, and at least two rounds of them (3 workgroups x 256 CUs)
-        if (single && conv_halo_tall_mode() && p.Co % 64 == 0 && conv_halo_ok<256, 64>(p) &&
+        if (conv_halo_tall_mode() && p.Co % 64 == 0 && conv_halo_ok<256, 64>(p) &&
             (long)((p.M + 255) / 256) * (p.Co / 64) >= 1536) {  // (784 tiles on 768 slots: +16 % alone, profiles/r05_tall_tiles.txt)
             ConvParams q = p;
             if (q.fz_view_tiles) q.fz_view_tiles = (q.fz_view_tiles % 2) ? 0 : q.fz_view_tiles / 2;  // (unused by this epilogue)
@@ -1330,69 +1135,40 @@ int launch_conv_lean(const ConvParams& p, hipStream_t st, bool single) {
         }
     }
     if constexpr (!SEG && (EPI == 1 || EPI == 3) && WM * WN == 4) {
-        if (single && conv_halo_ok<BM, BN>(p)) return launch_conv_st<T, BM, BN, WM, WN, 1, EPI, false, kVarHalo>(p, st);
+        if (conv_halo_ok<BM, BN>(p)) return launch_conv_st<T, BM, BN, WM, WN, 1, EPI, false, kVarHalo>(p, st);
     }
     const int mode = conv_pw_mode();
-    const bool m16 = single && (conv_m16_mode() & 1);
-    (void)m16;
     if ((mode & 1) && conv_is_pointwise(p)) {
         if constexpr (EPI == 3 && !SEG) {
-            if ((mode & 2) && p.fz_partials && !p.fz_x) {
-#ifdef SM3_CONV_M16_BUILD
-                if (m16) return launch_conv_st<T, BM, BN, WM, WN, 1, 3, false, kVarPw | kVarNoX | kVarM16>(p, st);
-#endif
-                return single ? launch_conv_st<T, BM, BN, WM, WN, 1, 3, false, kVarPw | kVarNoX>(p, st)
-                              : launch_conv_st<T, BM, BN, WM, WN, 2, 3, false, kVarPw | kVarNoX>(p, st);
-            }
+            if ((mode & 2) && p.fz_partials && !p.fz_x) return launch_conv_st<T, BM, BN, WM, WN, 1, 3, false, kVarPw | kVarNoX>(p, st);
         }
-#ifdef SM3_CONV_M16_BUILD
-        if (m16) return launch_conv_st<T, BM, BN, WM, WN, 1, EPI, SEG, kVarPw | kVarM16>(p, st);
-#endif
-        return single ? launch_conv_st<T, BM, BN, WM, WN, 1, EPI, SEG, kVarPw>(p, st)
-                      : launch_conv_st<T, BM, BN, WM, WN, 2, EPI, SEG, kVarPw>(p, st);
+        return launch_conv_st<T, BM, BN, WM, WN, 1, EPI, SEG, kVarPw>(p, st);
     }
-#ifdef SM3_CONV_M16_BUILD
-    if (m16) return launch_conv_st<T, BM, BN, WM, WN, 1, EPI, SEG, kVarM16>(p, st);
-#endif
-    return single ? launch_conv_st<T, BM, BN, WM, WN, 1, EPI, SEG>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, EPI, SEG>(p, st);
+    return launch_conv_st<T, BM, BN, WM, WN, 1, EPI, SEG>(p, st);
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int EPI>
-int launch_conv_epi(const ConvParams& p, hipStream_t st, bool single, bool deep) {
+int launch_conv_epi(const ConvParams& p, hipStream_t st, bool deep) {
     if (deep) return launch_conv_st<T, BM, BN, WM, WN, 4, EPI>(p, st);
-    if constexpr (EPI >= 1 && sizeof(T) == 2) {
-        if constexpr (EPI == 1) {
-            if (!single && conv_split_wanted<EPI, BN>(p)) return launch_conv_st<T, BM, BN, WM, WN, 2, EPI, false, kVarSplit>(p, st);
-        }
-        return launch_conv_lean<T, BM, BN, WM, WN, EPI, false>(p, st, single);
-    }
-    return single ? launch_conv_st<T, BM, BN, WM, WN, 1, EPI>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, EPI>(p, st);
+    if constexpr (EPI >= 1 && sizeof(T) == 2) return launch_conv_lean<T, BM, BN, WM, WN, EPI, false>(p, st);
+    return launch_conv_st<T, BM, BN, WM, WN, 1, EPI>(p, st);
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_conv(const ConvParams& p_in, hipStream_t st) {
     ConvParams p = p_in;
     p.kord = 0;
-    // K-steps up to which the ONE-stage loop runs (34 KB of LDS, 4 workgroups per CU overlapping each other) instead of the
-    // double-buffered one (66 KB, 2 per CU).  Rounds 1-3 drew the line at 8 K-steps; with the lean / pointwise epilogues the
-    // one-stage loop wins at EVERY length measured (profiles/r04a_stage_choice_*: 3x3 256->256, 36 K-steps, 847 -> 950
-    // TFLOP/s; two-segment 1x1 launches -11 ... -20 %; whole step 4 239 -> 4 354 pairs/s), so the default is "always"; the
-    // 4-stage loop of the small-grid launches (deep, below) is not affected.  SM3_CONV_SINGLE_STAGE_MAX=8 restores round 3.
-    const char* v = getenv("SM3_CONV_SINGLE_STAGE_MAX");
-    const int single_max = v ? atoi(v) : (1 << 30);
     const char* lv = getenv("SM3_CONV_LEAN");
     const bool lean = !(lv && atoi(lv) == 0);  // SM3_CONV_LEAN=0: everything through the general epilogue (A/B, debugging)
     if (p.x1) {  // two K segments (16-bit types only: the exact-f32 parity mode never takes the linear BatchNorm backward)
         if constexpr (sizeof(T) == 2) {
-            const bool one = p.nsteps_seg <= single_max;
-            if (lean && p.fz_partials) return launch_conv_lean<T, BM, BN, WM, WN, 3, true>(p, st, one);
-            if (lean) return launch_conv_lean<T, BM, BN, WM, WN, 2, true>(p, st, one);
-            return one ? launch_conv_st<T, BM, BN, WM, WN, 1, 0, true>(p, st) : launch_conv_st<T, BM, BN, WM, WN, 2, 0, true>(p, st);
+            if (lean && p.fz_partials) return launch_conv_lean<T, BM, BN, WM, WN, 3, true>(p, st);
+            if (lean) return launch_conv_lean<T, BM, BN, WM, WN, 2, true>(p, st);
+            return launch_conv_st<T, BM, BN, WM, WN, 1, 0, true>(p, st);
         } else {
             return SM3_EDTYPE;
         }
     }
-    const bool single = p.ntaps * p.kchunks <= single_max;
     // at most one workgroup per CU and a K-loop worth pipelining: 3 stages in flight (128 KB of LDS, see the kernel)
     const long nblocks = (long)((p.M + BM - 1) / BM) * ((p.Co + BN - 1) / BN);
     const char* dv = getenv("SM3_CONV_DEEP");
@@ -1403,23 +1179,14 @@ int launch_conv(const ConvParams& p_in, hipStream_t st) {
             // 16-bit stride-1 3 x 3 launches sum chunk outer, tap inner in whichever kernel and with whichever epilogue the
             // tests below pick (the K order is a property of the layer, not of the grid)
             p.kord = conv_halo_geometry(p) ? 1 : 0;
-            if (p.fz_partials) return launch_conv_epi<T, BM, BN, WM, WN, 3>(p, st, single, deep);  // data gradient + BN-backward phase 1
+            if (p.fz_partials) return launch_conv_epi<T, BM, BN, WM, WN, 3>(p, st, deep);  // data gradient + BN-backward phase 1
             // per-row work on the read-back: an addend, ReLU bits, per-view affine, a strided output
             if (p.addend || p.ep_mask || !dense || (p.ep_scale && p.fz_view_tiles))
-                return launch_conv_epi<T, BM, BN, WM, WN, 2>(p, st, single, deep);
-            if constexpr (BN == 128 && WM == 2 && WN == 2) {
-                // 3x3 forward launches: 8 waves on the same 128 x 128 tile (64 x 32 wave tiles) -- each wave issues 4 of the
-                // stage's LDS-DMA pieces instead of 8, which is as long as its MFMA phase (profiles/r03b_smemtime_kloop_timeline.txt):
-                // +2 ... +8 % on these layers; the short-K 1x1 layers lose (their epilogue on 512 threads) and keep 4 waves.
-                const char* w8v = getenv("SM3_CONV_W8");
-                const int w8 = w8v ? atoi(w8v) : 1;  // bit 0: the 2-stage 8-wave kernel; bit 1: 8 waves on the 1-stage loop too (A/B)
-                if ((w8 & 1) && p.ntaps >= 9 && !single && !deep && !conv_split_wanted<1, BN>(p)) return launch_conv_st<T, BM, BN, 2, 4, 2, 1>(p, st);
-                if ((w8 & 2) && p.ntaps >= 9 && single && !deep) return launch_conv_st<T, BM, BN, 2, 4, 1, 1>(p, st);
-            }
-            return launch_conv_epi<T, BM, BN, WM, WN, 1>(p, st, single, deep);  // train-mode forward, conv + evalBN (+ReLU)
+                return launch_conv_epi<T, BM, BN, WM, WN, 2>(p, st, deep);
+            return launch_conv_epi<T, BM, BN, WM, WN, 1>(p, st, deep);  // train-mode forward, conv + evalBN (+ReLU)
         }
     }
-    return launch_conv_epi<T, BM, BN, WM, WN, 0>(p, st, single, deep);
+    return launch_conv_epi<T, BM, BN, WM, WN, 0>(p, st, deep);
 }
 
 constexpr int kBM = 128;
@@ -1488,8 +1255,7 @@ static int launch_bnin(const ConvParams& p_in, int Co, bool probe, hipStream_t s
     } else {
         ConvParams p = p_in;
         const char* lv = getenv("SM3_CONV_LEAN");
-        const char* sv = getenv("SM3_CONV_SINGLE_STAGE_MAX");
-        if ((lv && atoi(lv) == 0) || (sv && p.ntaps * p.kchunks > atoi(sv))) return SM3_EINVAL;
+        if (lv && atoi(lv) == 0) return SM3_EINVAL;
         p.kord = conv_halo_geometry(p) ? 1 : 0;
         const long tiles128 = (long)((p.M + kBM - 1) / kBM) * ((Co + 127) / 128);
         const bool narrow = Co <= 64 || (tiles128 <= 96 && p.ntaps * p.kchunks >= 6);

@@ -75,7 +75,7 @@ using sm3conv::kOOB;
 template <int ROW_BYTES, bool BF16>
 __device__ __forceinline__ uint32_t swz_bytes(int row) {
     if constexpr (!BF16) return 0u;
-    else if constexpr (ROW_BYTES == 256) return (uint32_t)(row & 3) << 6;
+    else if constexpr (ROW_BYTES >= 256) return (uint32_t)(row & 3) << 6;  // (512-byte rows: the same four 64-byte slots)
     else return (uint32_t)((row >> 1) & 1) << 6;
 }
 
@@ -85,12 +85,7 @@ __device__ __forceinline__ uint32_t swz_bytes(int row) {
 // and accumulators; group 1 hands its tile to group 0 through LDS and ONE set of f32 atomics leaves the workgroup --
 // the same waves per CU as two 4-wave workgroups at half the atomic traffic (the 1x1 layers paid 20 % for atomics).
 template <typename T, int BMW, int BNW, int KP, bool DENSE, int NST, int KG = 1>  // KP = pixels per K-step, NST = LDS stages
-#ifndef SM3_WGRAD_OCC
-#define SM3_WGRAD_OCC 0  // build-time A/B: 4 = cap the tap-shifted (3x3 / strided) kernel at 128 registers -> 4 workgroups per CU
-#endif
-// (two K-groups on a 2-stage ring of 32-pixel steps: 64 KB of LDS, two 512-thread workgroups = 4 waves per SIMD at <= 128
-// registers -- the round-5 variant of the dense kernel, see launch_wgrad)
-__global__ __launch_bounds__(256 * KG, (NST == 1 || (SM3_WGRAD_OCC && !DENSE && KG == 1)) ? 4 : (DENSE && KG == 2 && NST == 2 && KP == 32) ? 4 : 1) void conv_wgrad_kernel(const WgradParams p) {
+__global__ __launch_bounds__(256 * KG, NST == 1 ? 4 : 1) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int SZ = sizeof(T);
     constexpr bool kBf16 = (SZ == 2);
     constexpr int RA = BMW * SZ, RB = BNW * SZ;                 // bytes per tile row (one pixel)
@@ -501,42 +496,22 @@ int launch_wgrad_kp(WgradParams p, hipStream_t st) {
 
 template <typename T, int BMW, int BNW>
 int launch_wgrad(WgradParams p, hipStream_t st) {
-    // K-step: 32 pixels in bf16, 16 in f32 (8-16 KB of tile bytes per stage).  1x1 stride-1 layers: ring of 4 stages
-    // (3 in flight), two 64 KB workgroups per CU.  Tap-shifted layers (3x3, stride 2): 2 stages, 32 KB, four to five
-    // workgroups per CU -- more, shorter workgroups fill the single wave better (measured per shape, profiles/r02b).
+    // K-step: 32 pixels in bf16, 16 in f32 (8-16 KB of tile bytes per stage).
+    // 1x1 stride-1 layers: two K-groups of 4 waves on a ring of 4 stages each (3 in flight), one 128 KB workgroup per CU.
+    // Tap-shifted layers (3x3, strided): 16-bit with Ci >= 128: ONE stage of 64 pixels (32 KB, 124 registers: four workgroups
+    // per CU overlap each other -- the forward kernel's lesson of round 4, 1.5 - 3.5 % here); otherwise a 2-stage ring of 32
+    // (32 KB, four to five workgroups per CU: measured per shape, profiles/r02b).
+    // Measured slower and removed in round 6 (scratch/r6_pruned_variants.patch keeps the code): one K-group / 2-stage / 1-stage
+    // dense rings (+3 ... +40 % time), 2-stage dense rings at two workgroups per CU with 32- or 64-pixel steps (+8 ... +9 % over
+    // the class, profiles/r05_wgrad_dense_variants_ab.txt), two K-groups on the tap-shifted kernel (+4 ... +67 %), the
+    // 128-register cap of the tap-shifted kernel (+-0), and a 128 x 256 tile for the layer-3 / layer-4 dense shapes (3-stage
+    // ring x 2 K-groups, 256 registers with 8 spilled: +3 % over the class, profiles/r06_wgrad_wide_tile_ab.txt).
     constexpr int KP = sizeof(T) == 2 ? 32 : 16;
     const bool dense = p.ntaps == 1 && p.sy == 1 && p.sx == 1 && p.dyt[0] == 0 && p.dxt[0] == 0 &&
                        p.HoWo == p.Hi * p.Wi;
-    if (dense) {
-        // SM3_WGRAD_KG=1: one K-group (64 KB, two workgroups per CU); SM3_WGRAD_DENSE_NST=2 with it: 2 stages, 32 KB, four to
-        // five workgroups per CU (A/B switches, read at every launch)
-        const char* kgv = getenv("SM3_WGRAD_KG");
-        const bool kg2 = !(kgv && atoi(kgv) == 1);
-        if constexpr (sizeof(T) == 2) {
-            // SM3_WGRAD_DENSE_VAR (A/B, read at every launch): 1 = two K-groups on a 2-stage ring of 32-pixel steps (64 KB: two
-            // workgroups = 4 waves per SIMD overlap each other), 2 = the same ring with 64-pixel steps (128 KB, half the barriers)
-            const int var = env_int("SM3_WGRAD_DENSE_VAR", 0);
-            if (kg2 && var == 1) return launch_wgrad_kp<T, BMW, BNW, 32, true, 2, 2>(p, st);
-            if (kg2 && var == 2) return launch_wgrad_kp<T, BMW, BNW, 64, true, 2, 2>(p, st);
-        }
-        if (kg2) return launch_wgrad_kp<T, BMW, BNW, KP, true, 4, 2>(p, st);
-        const char* nv = getenv("SM3_WGRAD_DENSE_NST");
-        if (nv && atoi(nv) == 2) return launch_wgrad_kp<T, BMW, BNW, KP, true, 2>(p, st);
-        if constexpr (sizeof(T) == 2) {
-            if (nv && atoi(nv) == 1) return launch_wgrad_kp<T, BMW, BNW, 64, true, 1>(p, st);
-        }
-        return launch_wgrad_kp<T, BMW, BNW, KP, true, 4>(p, st);
-    }
-    // Tap-shifted layers (3x3, strided), 16-bit, Ci >= 128: ONE stage of 64 pixels (32 KB, 124 registers: four workgroups
-    // per CU overlap each other) instead of the 2-stage ring of 32 -- the forward kernel's lesson of round 4, worth 1.5 - 3.5 %
-    // here (2.000 / 1.333 / 0.940 -> 1.971 / 1.290 / 0.912 ms per step on the 256 / 128 / 512-channel layers; the 64-channel
-    // layer loses 1.5 % and keeps the ring).  SM3_WGRAD_TAP1=0 restores the ring everywhere; =2: two K-groups on a 4-stage
-    // ring (half the atomics; 4 - 67 % slower).  The dense layers keep their 4-stage two-group ring (one stage: +3 ... +40 %).
+    if (dense) return launch_wgrad_kp<T, BMW, BNW, KP, true, 4, 2>(p, st);
     if constexpr (sizeof(T) == 2) {
-        const char* tv = getenv("SM3_WGRAD_TAP1");
-        const int mode = tv ? atoi(tv) : 1;
-        if (mode == 1 && p.Ci >= 128) return launch_wgrad_kp<T, BMW, BNW, 64, false, 1>(p, st);
-        if (mode == 2) return launch_wgrad_kp<T, BMW, BNW, KP, false, 4, 2>(p, st);
+        if (p.Ci >= 128) return launch_wgrad_kp<T, BMW, BNW, 64, false, 1>(p, st);
     }
     return launch_wgrad_kp<T, BMW, BNW, KP, false, 2>(p, st);
 }

@@ -20,6 +20,8 @@
 //
 // Reference call sites replaced: nn.Conv2d(3, 64, 7, 2, 3) forward (src/models/resnet.py:208-210,294) and its
 // autograd weight gradient, plus phase 2 of bn1's backward (resnet.py:211,295).
+#include <atomic>
+
 #include "conv_common.h"
 
 namespace {
@@ -319,6 +321,319 @@ __global__ __launch_bounds__(256, 3) void stem_wgrad_kernel(const StemWgradParam
         }
         __syncthreads();  // everyone is done reading this tile's operands
         if (tn < p.tiles) store_tile(nx);
+    }
+
+    const int frow = lane & 31, fh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int k = 32 * (kb0 + j) + frow;
+        const int g = k >> 3, kw = k & 7;
+        if (g >= NG || kw >= 7) continue;
+        const int kh = g / 3, c = g - 3 * kh;
+        const int kcol = (kh * 7 + kw) * 3 + c;  // master layout [co][kh][kw][c]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            if (p.dw_slabs) p.dw_slabs[(long)blockIdx.x * (64 * 147) + co * 147 + kcol] = acc[j][r];
+            else atomicAdd(p.dw + co * 147 + kcol, acc[j][r]);
+        }
+    }
+}
+
+
+// ==== the 16-bit image path (round 6) ===================================================================================
+// The kernels above convert the fp32 images on the fly, per tile: 22 global loads and 22 LDS stores per thread to stage a
+// patch, fp32 -> 16-bit in front of every MFMA fragment, forward and again in the weight gradient.  Here the images are
+// rounded ONCE per step (sm3_stem_image_prep: the same round-to-nearest-even, so every output bit stays what it was) into
+//     ximg [N][3][H][Wp] 16-bit,  ximg[.., q] = x[.., q - 3] for 3 <= q < W + 3, else 0,   Wp = round_up(W + 6, 8)
+// i.e. with the convolution's left / right zero padding materialised.  The staged row of tile x0 is then the 264
+// CONSECUTIVE values ximg[.., 2*x0 .. 2*x0 + 264): 33 aligned 16-byte chunks that go global -> LDS by LDS-DMA (no VGPRs,
+// no ds_write; rows above / below the image and chunks beyond Wp read as zero through the buffer range check), the NEXT
+// tile's patch while this one is computed.  An MFMA A fragment (8 consecutive k of one pixel) is 16 bytes at a 4-byte
+// aligned LDS address: four dword reads, no conversion.  sm3_stem_image_prep also replaces the torch.cat of the two views
+// of a branch (it reads them from two pointers), so the step moves fewer bytes than before.
+constexpr int PCH = 33;               // 16-byte chunks per staged row
+constexpr int PROW16 = PCH * 16;      // bytes per staged row (264 values)
+constexpr int PDMA = 11;              // wave-instructions per patch: 11 x 64 lanes >= 21 x 33 = 693 chunks
+constexpr int PATCH16 = PDMA * 1024;  // bytes per patch buffer
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_image_prep_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                              uint4* __restrict__ out, int n_per_view, int H, int W, int Wp8,
+                                                              long chunks) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= chunks) return;
+    const int j = (int)(i % Wp8);
+    const long r = i / Wp8;                 // row (n, c, iy)
+    const long rows_img = 3L * H;
+    const int n = (int)(r / rows_img);
+    const long rr = r - (long)n * rows_img;
+    const float* src = (n < n_per_view ? x0 + (long)n * rows_img * W : x1 + (long)(n - n_per_view) * rows_img * W) + rr * W;
+    float v[8];
+    const int q0 = 8 * j - 4;  // the chunk's values are src[q0 + 1 .. q0 + 8]
+    if ((W & 3) == 0 && q0 >= 0 && q0 + 8 < W && (((uintptr_t)src) & 15) == 0) {
+        // interior chunk of a 16-byte aligned row: two aligned 16-byte loads + one float instead of eight scalar loads at a
+        // 32-byte stride (which ran this pass at half the HBM rate)
+        const float4 a = *reinterpret_cast<const float4*>(src + q0), b = *reinterpret_cast<const float4*>(src + q0 + 4);
+        v[0] = a.y; v[1] = a.z; v[2] = a.w; v[3] = b.x; v[4] = b.y; v[5] = b.z; v[6] = b.w; v[7] = src[q0 + 8];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int q = 8 * j + e - 3;
+            v[e] = (unsigned)q < (unsigned)W ? src[q] : 0.f;
+        }
+    }
+    out[i] = make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
+}
+
+// the PDMA wave-instructions of one patch, dealt round-robin to the 4 waves; lane (row g, chunk j) of instruction k
+__device__ __forceinline__ void patch_dma(__amdgpu_buffer_rsrc_t rs, uint32_t lds_patch, const StemTile& t, int H, int Wp,
+                                          int wave, int lane) {
+    for (int k = wave; k < PDMA; k += 4) {
+        const int idx = k * 64 + lane;
+        const int g = idx / PCH, j = idx - g * PCH;
+        const int kh = g / 3, c = g - 3 * kh;
+        const int iy = 2 * t.oy - 3 + kh, q = 2 * t.x0 + 8 * j;
+        const bool ok = g < NG && (unsigned)iy < (unsigned)H && q < Wp;
+        const uint32_t off = ok ? (uint32_t)((((long)t.n * 3 + c) * H + iy) * Wp + q) * 2u : sm3conv::kOOB;
+        sm3conv::dma16(rs, lds_patch + (uint32_t)k * 1024u, off, 0u);
+    }
+}
+
+constexpr int FWD16_LDS = 2 * PATCH16 + 128 * OUT_PITCH + 4 * 64 * 2 * 4 + 64 * (KPAD + 8) * 2;
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void stem_fwd16_kernel(const char* __restrict__ ximg, uint32_t ximg_bytes,
+                                                          const uint4* __restrict__ w, T* __restrict__ y,
+                                                          float* __restrict__ partials, int H, int Wp, int Ho, int Wo,
+                                                          int xblocks, long tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem16[];
+    char* sPatch = smem16;                                   // [2][PATCH16]
+    char* sOut = smem16 + 2 * PATCH16;                       // [128][OUT_PITCH]
+    float(*sStat)[64][2] = reinterpret_cast<float(*)[64][2]>(sOut + 128 * OUT_PITCH);
+    constexpr int WP = KPAD + 8;
+    uint16_t* sW = reinterpret_cast<uint16_t*>(sOut + 128 * OUT_PITCH + 4 * 64 * 2 * 4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, h = lane >> 5;
+    for (int i = tid; i < 64 * (KPAD / 8); i += 256) {
+        const int co = i / (KPAD / 8), c8 = i - co * (KPAD / 8);
+        *reinterpret_cast<uint4*>(&sW[co * WP + c8 * 8]) = w[i];
+    }
+    const uint16_t* wlane = &sW[col * WP + 8 * h];
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ximg, 0, ximg_bytes, 0x00020000);
+    const uint32_t lds_patch = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)sPatch);
+
+    int buf = 0;
+    if ((long)blockIdx.x < tiles) patch_dma(rs, lds_patch, decode_tile(blockIdx.x, xblocks, Ho), H, Wp, wave, lane);
+    sm3conv::dma_drain();
+    for (long t = blockIdx.x; t < tiles; t += gridDim.x, buf ^= 1) {
+        const StemTile tl = decode_tile(t, xblocks, Ho);
+        const long tn = t + gridDim.x;
+        __syncthreads();       // this tile's patch has landed for everyone (every wave drained its pieces before it got here);
+                               // everyone is done with the previous tile's patch and output tile
+        if (tn < tiles)        // the next tile's patch goes into the other buffer while this one is computed
+            patch_dma(rs, lds_patch + (uint32_t)((buf ^ 1) * PATCH16), decode_tile(tn, xblocks, Ho), H, Wp, wave, lane);
+        f32x16 acc[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+        const int px = 32 * wave + col;
+        const char* prow = sPatch + buf * PATCH16 + 4 * px;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int g = 2 * ks + h;
+            uint4 a = make_uint4(0, 0, 0, 0);
+            if (g < NG) {
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(prow + g * PROW16);  // 8 consecutive k of pixel px
+                a = make_uint4(src[0], src[1], src[2], src[3]);
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                sm3conv::mma_frag<T>(a, *reinterpret_cast<const uint4*>(wlane + nb * 32 * WP + ks * 16), acc[nb]);
+        }
+        // epilogue: the arithmetic of stem_fwd_kernel (same rounding, same partial sums)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const uint16_t b = (uint16_t)pack2<T>(acc[nb][r], 0.f);
+                *reinterpret_cast<uint16_t*>(sOut + row * OUT_PITCH + (nb * 32 + col) * 2) = b;
+                if (tl.x0 + row < Wo) {
+                    const float v = ElemTraits<T>::round(acc[nb][r]);
+                    s1 += v;
+                    s2 += v * v;
+                }
+            }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 32) {
+                sStat[wave][nb * 32 + lane][0] = s1;
+                sStat[wave][nb * 32 + lane][1] = s2;
+            }
+        }
+        // the next patch (issued before the MFMA loop) has had the loop and the staging above to land; waiting HERE, in front
+        // of this tile's global stores, keeps the wait from ever covering a store's round trip
+        sm3conv::dma_drain();
+        __syncthreads();
+        if (partials && tid < 128) {
+            const int c = tid & 63, st = tid >> 6;
+            partials[(t * 2 + st) * 64 + c] = (sStat[0][c][st] + sStat[1][c][st]) + (sStat[2][c][st] + sStat[3][c][st]);
+        }
+        {
+            const int ch = tid & 7, r0 = tid >> 3;
+            const long pix0 = ((long)tl.n * Ho + tl.oy) * Wo + tl.x0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = r0 + 32 * k;
+                if (tl.x0 + row < Wo)
+                    stg16<true>(y + (pix0 + row) * 64 + ch * 8,
+                                *reinterpret_cast<const uint4*>(sOut + row * OUT_PITCH + ch * 16));
+            }
+        }
+    }
+}
+
+struct StemWgrad16Params {
+    StemWgradParams q;      // q.x unused
+    const char* ximg;
+    uint32_t ximg_bytes;
+    int Wp;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 3) void stem_wgrad16_kernel(const StemWgrad16Params pp) {
+    const StemWgradParams& p = pp.q;
+    __shared__ __attribute__((aligned(16))) char sPatch[2 * PATCH16];
+    __shared__ __attribute__((aligned(16))) char sD[128 * 128];  // dxo tile [pixel][64 co], swizzled for tr reads
+    __shared__ __attribute__((aligned(16))) float sCoef[3][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = wave & 1, kb0 = 3 * (wave >> 1);
+
+    if (blockIdx.x == 0 && tid < 64 && p.lsums) {  // parameter gradients of bn1 from the LOCAL sums, once, views in order
+        float db = 0.f, dg = 0.f;
+        for (int v = 0; v < p.views; ++v) {
+            db += (float)p.lsums[v * 128 + tid];
+            dg += (float)p.lsums[v * 128 + 64 + tid];
+        }
+        if (p.dbeta) atomicAdd(&p.dbeta[tid], db);
+        if (p.dgamma) atomicAdd(&p.dgamma[tid], dg);
+    }
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const int ch = tid & 7, r0 = tid >> 3;
+    int cur_view = -1;
+    const int g16 = lane >> 4, ii = lane & 15, qq = ii >> 2, pq = ii & 3, hh = g16 >> 1;
+    const uint32_t ra_off = (uint32_t)(8 * hh + qq) * 128u + ((((uint32_t)(cb * 32 + 16 * (g16 & 1) + 4 * pq)) * 2u) ^ swz128(qq));
+    const int bn = lane & 31, bh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pp.ximg, 0, pp.ximg_bytes, 0x00020000);
+    const uint32_t lds_patch = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)sPatch);
+    // B operand: lane (n = bn, half bh) of k block kb supplies k = 32 kb + bn -> (group g, kw): the 8 pixels of a fragment sit
+    // at every other 16-bit value of the staged row -- dwords (16 s + 8 bh) + (kw >> 1) + i, low or high half by kw's parity
+    uint32_t b_off[3], b_sel[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int k = 32 * (kb0 + j) + bn, g = k >> 3, kw = k & 7;
+        b_off[j] = g < NG ? (uint32_t)(g * PROW16 + 4 * (8 * bh + (kw >> 1))) : 0xffffffffu;
+        b_sel[j] = (kw & 1) ? 0x07060302u : 0x05040100u;
+    }
+
+    auto stage_dxo = [&](const StemTile& tl) {  // dx = A dz - B x + C per channel (the arithmetic of stem_wgrad_kernel)
+        const int view = tl.n / p.n_per_view;
+        if (view != cur_view) {
+            cur_view = view;
+            if (tid < 64) {
+                const int c = tid;
+                const float is = p.invstd[view * 64 + c];
+                const float g = p.gamma ? p.gamma[c] : 1.f;
+                const float k0c = g * is;
+                const float k1c = (float)(p.gsums[view * 128 + c] * p.inv_count);
+                const float qc = k0c * is * (float)(p.gsums[view * 128 + 64 + c] * p.inv_count);
+                sCoef[0][c] = k0c;
+                sCoef[1][c] = qc;
+                sCoef[2][c] = qc * p.mean[view * 64 + c] - k0c * k1c;
+            }
+            __syncthreads();
+        }
+        float cA[8], cB[8], cC[8];
+#pragma unroll
+        for (int e = 0; e < 8; e += 4) {
+            *reinterpret_cast<float4*>(cA + e) = *reinterpret_cast<const float4*>(&sCoef[0][ch * 8 + e]);
+            *reinterpret_cast<float4*>(cB + e) = *reinterpret_cast<const float4*>(&sCoef[1][ch * 8 + e]);
+            *reinterpret_cast<float4*>(cC + e) = *reinterpret_cast<const float4*>(&sCoef[2][ch * 8 + e]);
+        }
+        const long pix0 = ((long)tl.n * p.Ho + tl.oy) * p.Wo + tl.x0;
+#pragma unroll
+        for (int kb = 0; kb < 4; kb += 2) {
+            uint4 gu[2], xu[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int row = r0 + 32 * (kb + k);
+                const bool ok = tl.x0 + row < p.Wo;
+                gu[k] = ok ? ldg16<true>(p.dz + ((pix0 + row) * 64 + ch * 8) * 2) : make_uint4(0, 0, 0, 0);
+                xu[k] = ok ? ldg16<true>(p.xo + ((pix0 + row) * 64 + ch * 8) * 2) : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int row = r0 + 32 * (kb + k);
+                uint4 out = make_uint4(0, 0, 0, 0);
+                if (tl.x0 + row < p.Wo) {
+                    float g[8], xv[8];
+                    unpack16<T>(gu[k], g);
+                    unpack16<T>(xu[k], xv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) g[e] = cA[e] * g[e] - cB[e] * xv[e] + cC[e];
+                    out = pack16<T>(g);
+                }
+                *reinterpret_cast<uint4*>(sD + row * 128 + (((uint32_t)ch * 16u) ^ swz128(row))) = out;
+            }
+        }
+    };
+
+    int buf = 0;
+    if ((long)blockIdx.x < p.tiles) {
+        const StemTile t0 = decode_tile(blockIdx.x, p.xblocks, p.Ho);
+        patch_dma(rs, lds_patch, t0, p.H, pp.Wp, wave, lane);
+        stage_dxo(t0);
+    }
+    sm3conv::dma_drain();
+    for (long t = blockIdx.x; t < p.tiles; t += gridDim.x, buf ^= 1) {
+        const long tn = t + gridDim.x;
+        __syncthreads();  // this tile's patch (every wave drained its pieces) and dxo rows are in LDS for everyone
+        StemTile nx = {0, 0, 0};
+        if (tn < p.tiles) {
+            nx = decode_tile(tn, p.xblocks, p.Ho);
+            patch_dma(rs, lds_patch + (uint32_t)((buf ^ 1) * PATCH16), nx, p.H, pp.Wp, wave, lane);
+        }
+        const char* patch = sPatch + buf * PATCH16;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {  // 16 pixels per step
+            const char* a0 = sD + ra_off + s * 16 * 128;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * 128));
+            const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+            const uint4 fa = make_uint4(l2.x, l2.y, h2.x, h2.y);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                uint4 fb = make_uint4(0, 0, 0, 0);
+                if (b_off[j] != 0xffffffffu) {
+                    const uint32_t* d = reinterpret_cast<const uint32_t*>(patch + b_off[j] + s * 64);  // 16 pixels = 16 dwords
+                    fb = make_uint4(__builtin_amdgcn_perm(d[1], d[0], b_sel[j]), __builtin_amdgcn_perm(d[3], d[2], b_sel[j]),
+                                    __builtin_amdgcn_perm(d[5], d[4], b_sel[j]), __builtin_amdgcn_perm(d[7], d[6], b_sel[j]));
+                }
+                sm3conv::mma_frag<T>(fa, fb, acc[j]);
+            }
+        }
+        __syncthreads();  // everyone is done reading this tile's dxo rows
+        if (tn < p.tiles) stage_dxo(nx);
+        sm3conv::dma_drain();  // the next patch, in flight since before the MFMA loop
     }
 
     const int frow = lane & 31, fh = lane >> 5;
@@ -661,5 +976,93 @@ extern "C" int sm3_stem_wgrad_bn(int dtype, const float* x_nchw, const void* dz,
         hipLaunchKernelGGL(stem_wgrad_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     SM3_CHECK_LAUNCH();
     // the persistent grid and its tile walk are functions of the geometry: the slabs add up to the same bits in every run
+    return dw_slabs ? sm3_slab_reduce(dw_slabs, (int)grid, 64 * 147, dw, 1, stream) : 0;
+}
+
+extern "C" int sm3_stem_image_cols(int W) { return W > 0 ? (W + 6 + 7) / 8 * 8 : SM3_EINVAL; }
+
+extern "C" int sm3_stem_image_prep(int dtype, const float* x_view0, const float* x_view1, void* ximg, int n_per_view,
+                                   int views, int H, int W, void* stream) {
+    if (!x_view0 || !ximg || n_per_view <= 0 || H <= 0 || W <= 0 || views < 1 || views > 2 || (views == 2 && !x_view1))
+        return SM3_EINVAL;
+    if (dtype != SM3_BF16 && dtype != SM3_F16) return SM3_EDTYPE;
+    if ((uintptr_t)ximg & 15) return SM3_EALIGN;
+    const int Wp = sm3_stem_image_cols(W);
+    const long chunks = (long)n_per_view * views * 3 * H * (Wp / 8);
+    if (chunks * 16 >= 0xC0000000L) return SM3_EINVAL;  // 32-bit buffer offsets in the kernels that read it
+    const long blocks = (chunks + 255) / 256;
+    if (dtype == SM3_BF16)
+        hipLaunchKernelGGL(stem_image_prep_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_view0,
+                           x_view1, (uint4*)ximg, n_per_view, H, W, Wp / 8, chunks);
+    else
+        hipLaunchKernelGGL(stem_image_prep_kernel<f16_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_view0,
+                           x_view1, (uint4*)ximg, n_per_view, H, W, Wp / 8, chunks);
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename K>
+static int stem16_allow_lds(K kern, int bytes) {
+    // dynamic LDS above 64 KB needs the function attribute: per (instantiation, device), set once each
+    static std::atomic<int> done[32];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 31) dev = 0;
+    if (!done[dev].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return (int)e;
+        done[dev].store(1, std::memory_order_release);
+    }
+    return 0;
+}
+
+extern "C" int sm3_stem_conv_fwd16(int dtype, const void* ximg, const void* w_stem, void* y, float* stat_partials, int N,
+                                   int H, int W, void* stream) {
+    if (!ximg || !w_stem || !y) return SM3_EINVAL;
+    if (dtype != SM3_BF16 && dtype != SM3_F16) return SM3_EDTYPE;
+    int Ho, Wo, xb;
+    long tiles;
+    if (int rc = stem_geometry(N, H, W, Ho, Wo, xb, tiles)) return rc;
+    const int Wp = sm3_stem_image_cols(W);
+    const long bytes = (long)N * 3 * H * Wp * 2;
+    if (bytes >= 0xC0000000L) return SM3_EINVAL;
+    const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);  // persistent: 2 workgroups per CU (65 KB of LDS each)
+    if (dtype == SM3_BF16) {
+        if (int rc = stem16_allow_lds(stem_fwd16_kernel<bf16_t>, FWD16_LDS)) return rc;
+        hipLaunchKernelGGL(stem_fwd16_kernel<bf16_t>, dim3(grid), dim3(256), FWD16_LDS, (hipStream_t)stream, (const char*)ximg,
+                           (uint32_t)bytes, (const uint4*)w_stem, (bf16_t*)y, stat_partials, H, Wp, Ho, Wo, xb, tiles);
+    } else {
+        if (int rc = stem16_allow_lds(stem_fwd16_kernel<f16_t>, FWD16_LDS)) return rc;
+        hipLaunchKernelGGL(stem_fwd16_kernel<f16_t>, dim3(grid), dim3(256), FWD16_LDS, (hipStream_t)stream, (const char*)ximg,
+                           (uint32_t)bytes, (const uint4*)w_stem, (f16_t*)y, stat_partials, H, Wp, Ho, Wo, xb, tiles);
+    }
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sm3_stem_wgrad_bn16(int dtype, const void* ximg, const void* dz, const void* xo, const float* mean,
+                                   const float* invstd, const float* gamma, const double* global_sums, double count,
+                                   const double* local_sums, float* dgamma, float* dbeta, float* dw, float* dw_slabs,
+                                   int N, int H, int W, int views, void* stream) {
+    if (!ximg || !dz || !xo || !mean || !invstd || !global_sums || !dw || count <= 0 || views < 1 || N % views)
+        return SM3_EINVAL;
+    if (dtype != SM3_BF16 && dtype != SM3_F16) return SM3_EDTYPE;
+    if (dw_slabs && (((uintptr_t)dw_slabs | (uintptr_t)dw) & 15)) return SM3_EALIGN;
+    StemWgrad16Params pp;
+    StemWgradParams& p = pp.q;
+    if (int rc = stem_geometry(N, H, W, p.Ho, p.Wo, p.xblocks, p.tiles)) return rc;
+    pp.Wp = sm3_stem_image_cols(W);
+    const long bytes = (long)N * 3 * H * pp.Wp * 2;
+    if (bytes >= 0xC0000000L) return SM3_EINVAL;
+    pp.ximg = (const char*)ximg; pp.ximg_bytes = (uint32_t)bytes;
+    p.x = nullptr; p.dz = (const char*)dz; p.xo = (const char*)xo;
+    p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.gsums = global_sums; p.lsums = local_sums;
+    p.dgamma = dgamma; p.dbeta = dbeta; p.dw = dw; p.dw_slabs = dw_slabs; p.inv_count = 1.0 / count;
+    p.N = N; p.H = H; p.W = W; p.n_per_view = N / views; p.views = views;
+    const unsigned grid = (unsigned)(p.tiles < SM3_STEM_WGRAD_SLABS ? p.tiles : SM3_STEM_WGRAD_SLABS);
+    if (dtype == SM3_BF16)
+        hipLaunchKernelGGL(stem_wgrad16_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, pp);
+    else
+        hipLaunchKernelGGL(stem_wgrad16_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, pp);
+    SM3_CHECK_LAUNCH();
     return dw_slabs ? sm3_slab_reduce(dw_slabs, (int)grid, 64 * 147, dw, 1, stream) : 0;
 }

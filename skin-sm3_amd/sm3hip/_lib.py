@@ -113,6 +113,10 @@ SIGNATURES = {
     "sm3_stem_weight_prep_if": [_I, _P, _P, _P, _P],
     "sm3_stem_conv_fwd": [_I, _P, _P, _P, _P, _I, _I, _I, _P],
     "sm3_stem_wgrad_bn": [_I, _P, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "sm3_stem_image_cols": [_I],
+    "sm3_stem_image_prep": [_I, _P, _P, _P, _I, _I, _I, _I, _P],
+    "sm3_stem_conv_fwd16": [_I, _P, _P, _P, _P, _I, _I, _I, _P],
+    "sm3_stem_wgrad_bn16": [_I, _P, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "sm3_maxpool3x3s2_fwd": [_I, _P, _P, _P, _I, _I, _I, _I, _P],
     "sm3_maxpool3x3s2_bwd": [_I, _P, _P, _P, _I, _I, _I, _I, _P],
     "sm3_weight_prep_batch": [_I, _P, _I, _P],

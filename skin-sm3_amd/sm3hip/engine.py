@@ -368,6 +368,10 @@ class SM3Engine:
         # fixed-order sum of plain-store slabs (sm3_conv_wgrad_det, sm3_stem_wgrad_bn with slabs) instead of float atomics,
         # so two runs of a training produce the same bits.  SM3_WGRAD_DET=0: the atomic forms (A/B switch).
         self.det_wgrad = _os.environ.get("SM3_WGRAD_DET", "1") != "0"
+        # 16-bit modes: direct stem kernels on images rounded once per step and staged by LDS-DMA (sm3_stem_image_prep,
+        # sm3_stem_conv_fwd16, sm3_stem_wgrad_bn16; bit-identical to the fp32-image kernels).  SM3_STEM16=0: the round-3 kernels.
+        self.stem16 = (self.direct_stem and self.dtype in (SM3_BF16, SM3_F16)
+                       and _os.environ.get("SM3_STEM16", "1") != "0")
 
     # ---- setup ---------------------------------------------------------------------------
     def _all_conv_units(self):
@@ -548,8 +552,8 @@ class SM3Engine:
         with apply=False (the downsample branch) leaves its per-rank statistic sums in the first half of a shared buffer
         and queues its finalize there instead of synchronising; the unit called next with the same list (conv3) puts
         its sums behind them, all-reduces BOTH in one collective and runs the queued finalize before its own."""
-        dev = x.device
-        direct = cu.stem and self.direct_stem  # x is the NCHW fp32 image batch, N / H / W its geometry
+        dev = x.t.device if isinstance(x, ops.StemImage) else x.device
+        direct = cu.stem and self.direct_stem  # x is the NCHW fp32 image batch (or its StemImage), N / H / W its geometry
         if direct:
             d = None
             Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
@@ -575,7 +579,7 @@ class SM3Engine:
                 raise ValueError("two views in one batch need a multiple of 128 rows per view")
             partials = self._work("partials", prow * 2 * C)
             if direct:
-                ops.stem_conv_fwd(self.dtype, x, cu.w_fwd, xo, partials)
+                (ops.stem_conv_fwd16 if isinstance(x, ops.StemImage) else ops.stem_conv_fwd)(self.dtype, x, cu.w_fwd, xo, partials)
             elif bn_in is not None:
                 ops.conv3x3_bnin(d, bn_in[0], bn_in[1], bn_in[2], x, bn_in[3], cu.w_fwd, xo, partials, views=V)
             else:
@@ -645,7 +649,7 @@ class SM3Engine:
             return y_out, Ho, Wo
         else:
             if direct:
-                ops.stem_conv_fwd(self.dtype, x, cu.w_fwd, xo, None)
+                (ops.stem_conv_fwd16 if isinstance(x, ops.StemImage) else ops.stem_conv_fwd)(self.dtype, x, cu.w_fwd, xo, None)
             else:
                 ops.conv_gemm(d, x, cu.w_fwd, xo, None, None)
             ops.bn_eval_scale_shift(gamma, beta, rm, rv, BN_EPS, C, scale, shift)
@@ -1144,8 +1148,13 @@ class SM3Engine:
         """x: NCHW fp32 [N,3,H,W] (as the loader delivers it, tools/backbone_train.py:89-92).
         Writes the pooled features into feat_f32 [N,2048] (fp32) and feat_t (dtype copy, optional).
         views=2: x holds two views back to back (N = 2B), BatchNorm statistics per view."""
-        if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
+        xs = list(x) if isinstance(x, (list, tuple)) else [x]  # the views of the batch, back to back
+        if any(t.dtype != torch.float32 or t.dim() != 4 or t.shape[1] != 3 or t.shape != xs[0].shape for t in xs):
             raise ValueError("encoder input must be NCHW float32 with 3 channels")
+        if len(xs) > 1 and not self.stem16:
+            x = torch.cat(xs, 0)
+        elif len(xs) == 1:
+            x = xs[0]
         self._V = views if train else 1
         try:
             self._encoder_forward(plan, x, train, feat_f32, feat_t, save)
@@ -1153,27 +1162,36 @@ class SM3Engine:
             self._V = 1
 
     def _encoder_forward(self, plan, x, train, feat_f32, feat_t, save):
-        x = x.contiguous()
+        if self.stem16:
+            # 16-bit modes: the images are rounded ONCE (the rounding the stem kernels used to apply per staged tile, forward
+            # and again in the weight gradient) into a row-padded 16-bit copy that both kernels stage by LDS-DMA; the views
+            # of a pair batch are read from their own tensors -- no torch.cat of the fp32 images
+            xs = [t.contiguous() for t in (x if isinstance(x, (list, tuple)) else [x])]
+            x = ops.stem_image_prep(self.dtype, xs)
+            dev0 = xs[0].device
+        else:
+            x = x.contiguous()
+            dev0 = x.device
         N, _, H, W = x.shape
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         recs = [] if save is not None else None
         if self.direct_stem:
             stem_in, sN, sH, sW = x, N, H, W  # the 7x7 convolution reads the NCHW images directly
         else:
-            cols = torch.empty(N * Ho * Wo, STEM_KPAD, dtype=self.tdt, device=x.device)
+            cols = torch.empty(N * Ho * Wo, STEM_KPAD, dtype=self.tdt, device=dev0)
             ops.stem_im2col(self.dtype, x, cols, STEM_KPAD)
             stem_in, sN, sH, sW = cols, N * Ho * Wo, 1, 1
             del cols
         Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
-        p = torch.empty(N * Hp * Wp, 64, dtype=self.tdt, device=x.device)
-        amax = torch.empty(N * Hp * Wp * 64, dtype=torch.uint8, device=x.device) if save is not None else None
+        p = torch.empty(N * Hp * Wp, 64, dtype=self.tdt, device=dev0)
+        amax = torch.empty(N * Hp * Wp * 64, dtype=torch.uint8, device=dev0) if save is not None else None
         lazy = train or save is not None  # not the single-launch conv+evalBN inference path
         if lazy or self.direct_stem:
             # stem BatchNorm + ReLU + max-pool in ONE pass over the pre-BN stem output: the post-ReLU map (the largest
             # activation of the network) and its ReLU mask are never stored; backward recomputes the mask
             V = self._V if train else 1
-            sc = torch.empty(V * 64, dtype=torch.float32, device=x.device)
-            sh = torch.empty(V * 64, dtype=torch.float32, device=x.device)
+            sc = torch.empty(V * 64, dtype=torch.float32, device=dev0)
+            sh = torch.empty(V * 64, dtype=torch.float32, device=dev0)
             xo, _, _ = self.conv_bn(plan.stem, plan.stem_bn, stem_in, sN, sH, sW, True, None, train, recs,
                                     apply=False, scale_shift=(sc, sh))
             if recs is not None:
@@ -1203,12 +1221,12 @@ class SM3Engine:
                 d1 = blk["c1"].fwd_desc(self.dtype, N, h, w)
                 if ops.conv3x3_bnin_ok(blk["c2"].fwd_desc(self.dtype, N, d1.Ho, d1.Wo), Vt):
                     C1 = blk["c1"].Co
-                    sc1 = torch.empty(Vt * C1, dtype=torch.float32, device=x.device)
-                    sh1 = torch.empty(Vt * C1, dtype=torch.float32, device=x.device)
+                    sc1 = torch.empty(Vt * C1, dtype=torch.float32, device=dev0)
+                    sh1 = torch.empty(Vt * C1, dtype=torch.float32, device=dev0)
                     x1, h1, w1 = self.conv_bn(blk["c1"], blk["b1"], cur, N, h, w, True, None, train, br, apply=False,
                                               scale_shift=(sc1, sh1))
                     y1 = torch.empty_like(x1)
-                    mk1 = torch.empty(x1.numel() // (16 // ops._sz(self.dtype)), dtype=torch.uint8, device=x.device)
+                    mk1 = torch.empty(x1.numel() // (16 // ops._sz(self.dtype)), dtype=torch.uint8, device=dev0)
                     br[0].y, br[0].mask = y1, mk1
                     bn_in = (x1, sc1, sh1, mk1)
             if bn_in is None:
@@ -1223,8 +1241,8 @@ class SM3Engine:
             if lin:
                 slabs, cap = self._slab_buf(pp * pp, Vt)
                 ns = ops.conv_wgrad_slabs(self._lin_conv_desc(self.dtype, N, h2, w2, pp, pp), y2, y2, slabs, views=Vt, cap=cap)
-                br[1].gram = torch.empty(Vt * pp * pp, dtype=torch.float32, device=x.device)
-                br[1].colsum = torch.empty(Vt * pp, dtype=torch.float64, device=x.device)
+                br[1].gram = torch.empty(Vt * pp * pp, dtype=torch.float32, device=dev0)
+                br[1].colsum = torch.empty(Vt * pp, dtype=torch.float64, device=dev0)
                 ops.linbn_moments(slabs, ns, pp * pp, br[1].gram, views=Vt, colsum=cs, colsum_rows=crow,
                                   s_out=br[1].colsum, p=pp)
             ra = None
@@ -1370,10 +1388,10 @@ class SM3Engine:
             # BatchNorm-backward apply inside the stem weight gradient's operand load: d(conv1 output) never reaches HBM
             lsums, gsums, count = self._bn_backward_sums(rs, part, prow)
             bn = rs.bu.name
-            ops.stem_wgrad_bn(self.dtype, rs.x_in, dz, rs.xo, rs.mean, rs.invstd, self._p(bn + ".weight"), gsums, count,
-                              lsums, self._g(bn + ".weight"), self._g(bn + ".bias"), self._g(rs.cu.name + ".weight"),
-                              views=rs.V,
-                              slabs=self._work("stem_slabs", ops.STEM_WGRAD_SLABS * 64 * 147) if self.det_wgrad else None)
+            wg = ops.stem_wgrad_bn16 if isinstance(rs.x_in, ops.StemImage) else ops.stem_wgrad_bn
+            wg(self.dtype, rs.x_in, dz, rs.xo, rs.mean, rs.invstd, self._p(bn + ".weight"), gsums, count,
+               lsums, self._g(bn + ".weight"), self._g(bn + ".bias"), self._g(rs.cu.name + ".weight"), views=rs.V,
+               slabs=self._work("stem_slabs", ops.STEM_WGRAD_SLABS * 64 * 147) if self.det_wgrad else None)
         else:
             dxo, _ = self.bn_backward(rs, dz, keep_dz=False, fused_rows=prow)
             self.conv_backward(rs, dxo, need_dx=False)
@@ -1450,7 +1468,7 @@ class SM3Engine:
             if pair:  # both views as one batch of 2B images (BatchNorm statistics still per view)
                 with self.lane(key, streams):
                     tmp = [] if want_grad else None
-                    self.encoder_forward(plan, torch.cat([imgs[0], imgs[1]], 0), train, f32, ft, tmp, views=2)
+                    self.encoder_forward(plan, [imgs[0], imgs[1]], train, f32, ft, tmp, views=2)
                     if want_grad:
                         ctxs = [tmp[0]]
             for v in (() if pair else (0, 1)):

@@ -1104,6 +1104,79 @@ def stem_conv_fwd(dtype, x_nchw, w_stem, y, partials=None):
 STEM_WGRAD_SLABS = 768  # SM3_STEM_WGRAD_SLABS (include/sm3_hip.h)
 
 
+class StemImage:
+    """The images of one encoder pass rounded to the 16-bit type once (sm3_stem_image_prep): t is [N, 3, H, Wp] `dtype` with
+    the 7x7 convolution's left / right zero padding materialised; shape is the NCHW shape of the fp32 images it came from."""
+    __slots__ = ("t", "shape")
+
+    def __init__(self, t, shape):
+        self.t, self.shape = t, tuple(shape)
+
+    def record_stream(self, st):
+        self.t.record_stream(st)
+
+
+def stem_image_cols(W):
+    return (W + 6 + 7) // 8 * 8
+
+
+def stem_image_prep(dtype, views):
+    """views: one or two NCHW fp32 tensors of equal shape -> StemImage of the batch `views[0]` then `views[1]` (no torch.cat)."""
+    x0 = views[0]
+    x1 = views[1] if len(views) > 1 else None
+    _chk(x0, torch.float32, "x0"); _chk(x1, torch.float32, "x1")
+    if x0.dim() != 4 or x0.shape[1] != 3 or (x1 is not None and x1.shape != x0.shape) or len(views) > 2:
+        raise ValueError("stem_image_prep: NCHW fp32 views of equal shape")
+    B, _, H, W = x0.shape
+    V = len(views)
+    out = torch.empty(V * B, 3, H, stem_image_cols(W), dtype=TORCH_DTYPE[dtype], device=x0.device)
+    with _prof("stem_image_prep", 0.0, 4.0 * V * x0.numel() + _sz(dtype) * out.numel()):
+        check(_lib.load().sm3_stem_image_prep(dtype, _ptr(x0), _ptr(x1), _ptr(out), B, V, H, W, _stream()),
+              "sm3_stem_image_prep")
+    return StemImage(out, (V * B, 3, H, W))
+
+
+def stem_conv_fwd16(dtype, img, w_stem, y, partials=None):
+    """sm3_stem_conv_fwd16: the direct stem on a StemImage (LDS-DMA staged 16-bit rows, no conversion in the kernel)."""
+    tdt = TORCH_DTYPE[dtype]
+    _chk(img.t, tdt, "ximg"); _chk(w_stem, tdt, "w_stem"); _chk(y, tdt, "y"); _chk(partials, torch.float32, "partials")
+    N, Cc, H, W = img.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if Cc != 3 or w_stem.numel() != 64 * STEM_KDIRECT or y.numel() != N * Ho * Wo * 64 or \
+            img.t.numel() != N * 3 * H * stem_image_cols(W):
+        raise ValueError("stem_conv_fwd16: size mismatch")
+    if partials is not None and partials.numel() < stem_partial_rows(N, H, W) * 2 * 64:
+        raise ValueError("stem_conv_fwd16: partials too small")
+    M = N * Ho * Wo
+    with _prof("stem_conv_fwd", 2.0 * M * 64 * 147, _sz(dtype) * (img.t.numel() + y.numel())):
+        check(_lib.load().sm3_stem_conv_fwd16(dtype, _ptr(img.t), _ptr(w_stem), _ptr(y), _ptr(partials), N, H, W, _stream()),
+              "sm3_stem_conv_fwd16")
+
+
+def stem_wgrad_bn16(dtype, img, dz, xo, mean, invstd, gamma, gsums, count, lsums, dgamma, dbeta, dw, views=1, slabs=None):
+    """sm3_stem_wgrad_bn16: stem_wgrad_bn on a StemImage."""
+    tdt = TORCH_DTYPE[dtype]
+    _chk(img.t, tdt, "ximg"); _chk(dz, tdt, "dz"); _chk(xo, tdt, "xo"); _chk(dw, torch.float32, "dw")
+    for t in (mean, invstd, gamma, dgamma, dbeta):
+        _chk(t, torch.float32)
+    _chk(gsums, torch.float64); _chk(lsums, torch.float64); _chk(slabs, torch.float32, "slabs")
+    N, Cc, H, W = img.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if Cc != 3 or dz.numel() != N * Ho * Wo * 64 or xo.numel() != dz.numel() or dw.numel() < 64 * 147 or N % views or \
+            img.t.numel() != N * 3 * H * stem_image_cols(W):
+        raise ValueError("stem_wgrad_bn16: size mismatch")
+    if mean.numel() < views * 64 or invstd.numel() < views * 64 or gsums.numel() < views * 128 or \
+            (lsums is not None and lsums.numel() < views * 128):
+        raise ValueError("stem_wgrad_bn16: per-channel vector too small")
+    if slabs is not None and slabs.numel() < STEM_WGRAD_SLABS * 64 * 147:
+        raise ValueError("stem_wgrad_bn16: slab workspace too small")
+    M = N * Ho * Wo
+    with _prof("stem_wgrad_bn", 2.0 * M * 64 * 147, _sz(dtype) * (img.t.numel() + 2 * dz.numel())):
+        check(_lib.load().sm3_stem_wgrad_bn16(dtype, _ptr(img.t), _ptr(dz), _ptr(xo), _ptr(mean), _ptr(invstd), _ptr(gamma),
+                                              _ptr(gsums), float(count), _ptr(lsums), _ptr(dgamma), _ptr(dbeta), _ptr(dw),
+                                              _ptr(slabs), N, H, W, views, _stream()), "sm3_stem_wgrad_bn16")
+
+
 def stem_wgrad_bn(dtype, x_nchw, dz, xo, mean, invstd, gamma, gsums, count, lsums, dgamma, dbeta, dw, views=1, slabs=None):
     """Stem weight gradient with bn1's backward apply fused into the operand load (sm3_stem_wgrad_bn; bf16 / fp16 / exact f32).
     slabs: fp32 workspace of STEM_WGRAD_SLABS * 64 * 147 floats -> fixed-order sum instead of float atomics."""

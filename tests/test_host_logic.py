@@ -106,7 +106,7 @@ def test_engine_dry_run_sequences_and_bucket_schedule(model, linbn):
     assert calls["sm3_bn_finalize"] == (n_from_moments if eng.fused_stats else 230)
     nlin = 64 if linbn else 0  # 16 Bottlenecks x 4 encoder passes: conv3 -> bn3 units whose backward goes by linearity
     nds = 16 if linbn else 0   # ... and the 4 downsample conv -> BatchNorm units of every pass
-    assert calls["sm3_conv_wgrad_det"] == 230 - 4 - nlin - nds and calls["sm3_stem_wgrad_bn"] == 4  # bf16: direct stem (csrc/stem.hip); fixed-order weight gradients (round 6)
+    assert calls["sm3_conv_wgrad_det"] == 230 - 4 - nlin - nds and calls["sm3_stem_wgrad_bn16"] == 4 and calls["sm3_stem_image_prep"] == 4  # bf16: direct stem (csrc/stem.hip); fixed-order weight gradients (round 6)
     # per unit backward: sums + coefficients, then banks / -H / weight-gradient finish as ONE launch (round 5)
     for name in ("sm3_linbn_stats", "sm3_linbn_banks_post"):
         assert calls[name] == nlin + nds, name
@@ -133,7 +133,7 @@ def test_engine_dry_run_sequences_and_bucket_schedule(model, linbn):
     assert calls["sm3_bn_add_bn_act"] == 16 - nds and calls["sm3_bn_act"] + calls["sm3_bn_act_colsum"] == 230 - 16 - 16 - 4 - nfused
     # AdamW bucket by bucket as the gradients become final (single rank): one launch per gradient-ready notification
     assert calls["sm3_ntxent_fused"] == 4 and calls["sm3_adamw"] == len(ranges) > 4
-    assert calls["sm3_stem_conv_fwd"] == 4 and calls["sm3_stem_im2col"] == 0
+    assert calls["sm3_stem_conv_fwd16"] == 4 and calls["sm3_stem_im2col"] == 0
     assert calls["sm3_bn_relu_maxpool_fwd"] == 4 and calls["sm3_maxpool_bn_bwd"] == 4
     assert calls["sm3_maxpool3x3s2_fwd"] == 0 and calls["sm3_maxpool3x3s2_bwd"] == 0
     # bucket coverage

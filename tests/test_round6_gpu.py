@@ -38,6 +38,10 @@ DET_CASES = CONV_CASES + [
     (32, 64, 64, 56, 56, 3, 1, 1),
     (64, 256, 128, 28, 28, 1, 1, 0),
     (32, 256, 256, 14, 14, 3, 1, 1),
+    # layer-3 / layer-4 dense shapes: the 128 x 256 weight-gradient tile (Co x Ci >= 256 x 1024, Ci a multiple of 256)
+    (8, 1024, 256, 14, 14, 1, 1, 0),
+    (8, 256, 1024, 14, 14, 1, 1, 0),
+    (6, 512, 2048, 7, 7, 1, 1, 0),
 ]
 
 
@@ -166,3 +170,62 @@ def test_three_training_steps_are_a_function_of_their_inputs(dt):
     for k in a[5]:
         assert torch.equal(a[5][k], b[5][k]), k
     assert all(l == l for l in a[0]) and a[0][0] != a[0][1]
+
+
+STEM16_CASES = [(4, 64, 64), (2, 224, 224), (3, 96, 80), (2, 70, 54), (2, 448, 448), (1, 37, 301)]
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("case", STEM16_CASES)
+def test_stem_kernels_on_the_16bit_image_equal_the_fp32_image_kernels_bit_for_bit(case, dt):
+    """sm3_stem_image_prep + sm3_stem_conv_fwd16 / sm3_stem_wgrad_bn16 (images rounded once, rows staged by LDS-DMA) against
+    sm3_stem_conv_fwd / sm3_stem_wgrad_bn on the fp32 images (rounded per staged tile): the same round-to-nearest-even of
+    the same values, the same MFMA sequence -- outputs, BatchNorm partial rows and the weight gradient are EQUAL.  Two views
+    come from two tensors (no concatenated copy).  The padded image itself is checked against torch."""
+    ops = _ops()
+    code = ops.dtype_code(dt)
+    B, H, W = case
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    g = torch.Generator(device=DEV).manual_seed(B * 1000 + H + W)
+    views = [torch.randn(B, 3, H, W, device=DEV, generator=g) for _ in range(2)]
+    w_master = (torch.randn(64, 147, device=DEV, generator=g) / 12.0).contiguous()
+    w_stem = torch.empty(64 * ops.STEM_KDIRECT, dtype=dt, device=DEV)
+    ops.stem_weight_prep(code, w_master, w_stem, None)
+    for V in (1, 2):
+        xs = views[:V]
+        N = V * B
+        img = ops.stem_image_prep(code, xs)
+        Wp = ops.stem_image_cols(W)
+        want = torch.zeros(N, 3, H, Wp, dtype=dt, device=DEV)
+        want[..., 3:3 + W] = torch.cat(xs, 0).to(dt)
+        assert torch.equal(img.t, want)
+        xcat = torch.cat(xs, 0).contiguous()
+        prow = ops.stem_partial_rows(N, H, W)
+        y_a, y_b = (torch.empty(N * Ho * Wo, 64, dtype=dt, device=DEV) for _ in range(2))
+        p_a, p_b = (torch.full((prow * 2 * 64,), float("nan"), device=DEV) for _ in range(2))
+        ops.stem_conv_fwd(code, xcat, w_stem, y_a, p_a)
+        ops.stem_conv_fwd16(code, img, w_stem, y_b, p_b)
+        torch.cuda.synchronize()
+        assert torch.equal(y_a, y_b) and torch.equal(p_a, p_b)
+        # weight gradient with bn1's backward apply in the operand load
+        dz = torch.randn(N * Ho * Wo, 64, device=DEV, generator=g).to(dt)
+        mean = torch.randn(V * 64, device=DEV, generator=g) * 0.1
+        invstd = torch.rand(V * 64, device=DEV, generator=g) + 0.5
+        gamma = torch.rand(64, device=DEV, generator=g) + 0.5
+        gsums = torch.randn(V * 128, device=DEV, generator=g, dtype=torch.float64)
+        count = float(B * Ho * Wo)
+        slabs = torch.full((ops.STEM_WGRAD_SLABS * 64 * 147,), float("nan"), device=DEV)
+        outs = []
+        for fn, im in ((ops.stem_wgrad_bn, xcat), (ops.stem_wgrad_bn16, img)):
+            for use_slabs in (True, False):
+                dw = torch.zeros(64 * 147, device=DEV)
+                dg, db = torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
+                fn(code, im, dz, y_a, mean, invstd, gamma, gsums, count, gsums, dg, db, dw, views=V,
+                   slabs=slabs if use_slabs else None)
+                torch.cuda.synchronize()
+                outs.append((dw, dg, db))
+        assert torch.equal(outs[0][0], outs[2][0])                       # fixed-order forms: equal
+        for o in outs[1:]:
+            assert torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
+            sc = float(outs[0][0].abs().max())
+            assert float((o[0] - outs[0][0]).abs().max()) < 2e-5 * max(sc, 1.0)
