@@ -567,7 +567,11 @@ int sm3_mlc_relu_drop_bwd(const float* dhd, const float* h, float p, uint32_t se
                           int N, void* stream);
 /* db[c] += sum_r dy[r][c]: the bias gradient of a Linear */
 int sm3_mlc_colsum(const float* dy, float* db, int64_t rows, int N, void* stream);
-/* loss[0] += mean_h mean_b CE(logits[b, off[h]:off[h+1]] / T, targets[h][b]); dlogits written (mlc_train.py:252-261) */
+/* loss[0] += mean_h mean_b CE(logits[b, off[h]:off[h+1]] / T, targets[h][b]); dlogits written (mlc_train.py:252-261).
+ * ONE workgroup adds the B * H terms in a fixed fp64 order and does a plain (non-atomic) `loss[0] +=`: the caller zeroes
+ * loss[0] before the first term of a step and issues every launch that adds to it on ONE stream (sm3hip/mlc.py does).
+ * Launch time is linear in B * H on one CU (4 096 pairs at config 4's size: ~20 us); a caller with far larger B * H
+ * should split the batch over calls. */
 int sm3_mlc_ce(const float* logits, const int64_t* targets, const int* head_offsets, int H, int B, int Tn, float temperature,
                float* loss, float* dlogits, void* stream);
 /* prototype heads in fp32 with either row layout (bias nullable: mlc_train.py's prototypes have none), and the backward:

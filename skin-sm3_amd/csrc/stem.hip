@@ -386,6 +386,21 @@ __global__ __launch_bounds__(256) void stem_image_prep_kernel(const float* __res
     out[i] = make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
 }
 
+// tile index -> (n, oy, x0) with 32-bit multiply-high divisions (the 64-bit % and / of decode_tile cost ~600 scalar
+// instructions per tile, twice per tile: current + next)
+struct TileDiv {
+    FastDiv xb, ho;
+};
+__device__ __forceinline__ StemTile decode_tile32(uint32_t t, const TileDiv& d) {
+    StemTile s;
+    const uint32_t r = fdiv(t, d.xb), xb = t - r * d.xb.d;
+    const uint32_t n = fdiv(r, d.ho);
+    s.oy = (int)(r - n * d.ho.d);
+    s.n = (int)n;
+    s.x0 = (int)xb * 128;
+    return s;
+}
+
 // the PDMA wave-instructions of one patch, dealt round-robin to the 4 waves; lane (row g, chunk j) of instruction k
 __device__ __forceinline__ void patch_dma(__amdgpu_buffer_rsrc_t rs, uint32_t lds_patch, const StemTile& t, int H, int Wp,
                                           int wave, int lane) {
@@ -406,7 +421,7 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void stem_fwd16_kernel(const char* __restrict__ ximg, uint32_t ximg_bytes,
                                                           const uint4* __restrict__ w, T* __restrict__ y,
                                                           float* __restrict__ partials, int H, int Wp, int Ho, int Wo,
-                                                          int xblocks, long tiles) {
+                                                          const TileDiv td, uint32_t tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem16[];
     char* sPatch = smem16;                                   // [2][PATCH16]
     char* sOut = smem16 + 2 * PATCH16;                       // [128][OUT_PITCH]
@@ -424,15 +439,15 @@ __global__ __launch_bounds__(256, 2) void stem_fwd16_kernel(const char* __restri
     const uint32_t lds_patch = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)sPatch);
 
     int buf = 0;
-    if ((long)blockIdx.x < tiles) patch_dma(rs, lds_patch, decode_tile(blockIdx.x, xblocks, Ho), H, Wp, wave, lane);
+    if (blockIdx.x < tiles) patch_dma(rs, lds_patch, decode_tile32(blockIdx.x, td), H, Wp, wave, lane);
     sm3conv::dma_drain();
-    for (long t = blockIdx.x; t < tiles; t += gridDim.x, buf ^= 1) {
-        const StemTile tl = decode_tile(t, xblocks, Ho);
-        const long tn = t + gridDim.x;
+    for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x, buf ^= 1) {
+        const StemTile tl = decode_tile32(t, td);
+        const uint32_t tn = t + gridDim.x;
         __syncthreads();       // this tile's patch has landed for everyone (every wave drained its pieces before it got here);
                                // everyone is done with the previous tile's patch and output tile
         if (tn < tiles)        // the next tile's patch goes into the other buffer while this one is computed
-            patch_dma(rs, lds_patch + (uint32_t)((buf ^ 1) * PATCH16), decode_tile(tn, xblocks, Ho), H, Wp, wave, lane);
+            patch_dma(rs, lds_patch + (uint32_t)((buf ^ 1) * PATCH16), decode_tile32(tn, td), H, Wp, wave, lane);
         f32x16 acc[2];
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
@@ -480,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd16_kernel(const char* __restri
         __syncthreads();
         if (partials && tid < 128) {
             const int c = tid & 63, st = tid >> 6;
-            partials[(t * 2 + st) * 64 + c] = (sStat[0][c][st] + sStat[1][c][st]) + (sStat[2][c][st] + sStat[3][c][st]);
+            partials[((long)t * 2 + st) * 64 + c] = (sStat[0][c][st] + sStat[1][c][st]) + (sStat[2][c][st] + sStat[3][c][st]);
         }
         {
             const int ch = tid & 7, r0 = tid >> 3;
@@ -501,6 +516,7 @@ struct StemWgrad16Params {
     const char* ximg;
     uint32_t ximg_bytes;
     int Wp;
+    TileDiv td;
 };
 
 template <typename T>
@@ -598,18 +614,19 @@ __global__ __launch_bounds__(256, 3) void stem_wgrad16_kernel(const StemWgrad16P
     };
 
     int buf = 0;
-    if ((long)blockIdx.x < p.tiles) {
-        const StemTile t0 = decode_tile(blockIdx.x, p.xblocks, p.Ho);
+    const uint32_t ntiles = (uint32_t)p.tiles;
+    if (blockIdx.x < ntiles) {
+        const StemTile t0 = decode_tile32(blockIdx.x, pp.td);
         patch_dma(rs, lds_patch, t0, p.H, pp.Wp, wave, lane);
         stage_dxo(t0);
     }
     sm3conv::dma_drain();
-    for (long t = blockIdx.x; t < p.tiles; t += gridDim.x, buf ^= 1) {
-        const long tn = t + gridDim.x;
+    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x, buf ^= 1) {
+        const uint32_t tn = t + gridDim.x;
         __syncthreads();  // this tile's patch (every wave drained its pieces) and dxo rows are in LDS for everyone
         StemTile nx = {0, 0, 0};
-        if (tn < p.tiles) {
-            nx = decode_tile(tn, p.xblocks, p.Ho);
+        if (tn < ntiles) {
+            nx = decode_tile32(tn, pp.td);
             patch_dma(rs, lds_patch + (uint32_t)((buf ^ 1) * PATCH16), nx, p.H, pp.Wp, wave, lane);
         }
         const char* patch = sPatch + buf * PATCH16;
@@ -632,7 +649,7 @@ __global__ __launch_bounds__(256, 3) void stem_wgrad16_kernel(const StemWgrad16P
             }
         }
         __syncthreads();  // everyone is done reading this tile's dxo rows
-        if (tn < p.tiles) stage_dxo(nx);
+        if (tn < ntiles) stage_dxo(nx);
         sm3conv::dma_drain();  // the next patch, in flight since before the MFMA loop
     }
 
@@ -1025,15 +1042,17 @@ extern "C" int sm3_stem_conv_fwd16(int dtype, const void* ximg, const void* w_st
     const int Wp = sm3_stem_image_cols(W);
     const long bytes = (long)N * 3 * H * Wp * 2;
     if (bytes >= 0xC0000000L) return SM3_EINVAL;
+    if (tiles > 0x7fffffffL) return SM3_EINVAL;
+    const TileDiv td{make_fastdiv((uint32_t)xb), make_fastdiv((uint32_t)Ho)};
     const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);  // persistent: 2 workgroups per CU (65 KB of LDS each)
     if (dtype == SM3_BF16) {
         if (int rc = stem16_allow_lds(stem_fwd16_kernel<bf16_t>, FWD16_LDS)) return rc;
         hipLaunchKernelGGL(stem_fwd16_kernel<bf16_t>, dim3(grid), dim3(256), FWD16_LDS, (hipStream_t)stream, (const char*)ximg,
-                           (uint32_t)bytes, (const uint4*)w_stem, (bf16_t*)y, stat_partials, H, Wp, Ho, Wo, xb, tiles);
+                           (uint32_t)bytes, (const uint4*)w_stem, (bf16_t*)y, stat_partials, H, Wp, Ho, Wo, td, (uint32_t)tiles);
     } else {
         if (int rc = stem16_allow_lds(stem_fwd16_kernel<f16_t>, FWD16_LDS)) return rc;
         hipLaunchKernelGGL(stem_fwd16_kernel<f16_t>, dim3(grid), dim3(256), FWD16_LDS, (hipStream_t)stream, (const char*)ximg,
-                           (uint32_t)bytes, (const uint4*)w_stem, (f16_t*)y, stat_partials, H, Wp, Ho, Wo, xb, tiles);
+                           (uint32_t)bytes, (const uint4*)w_stem, (f16_t*)y, stat_partials, H, Wp, Ho, Wo, td, (uint32_t)tiles);
     }
     SM3_CHECK_LAUNCH();
     return 0;
@@ -1053,7 +1072,9 @@ extern "C" int sm3_stem_wgrad_bn16(int dtype, const void* ximg, const void* dz, 
     pp.Wp = sm3_stem_image_cols(W);
     const long bytes = (long)N * 3 * H * pp.Wp * 2;
     if (bytes >= 0xC0000000L) return SM3_EINVAL;
+    if (p.tiles > 0x7fffffffL) return SM3_EINVAL;
     pp.ximg = (const char*)ximg; pp.ximg_bytes = (uint32_t)bytes;
+    pp.td = TileDiv{make_fastdiv((uint32_t)p.xblocks), make_fastdiv((uint32_t)p.Ho)};
     p.x = nullptr; p.dz = (const char*)dz; p.xo = (const char*)xo;
     p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.gsums = global_sums; p.lsums = local_sums;
     p.dgamma = dgamma; p.dbeta = dbeta; p.dw = dw; p.dw_slabs = dw_slabs; p.inv_count = 1.0 / count;

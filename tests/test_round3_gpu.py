@@ -160,6 +160,10 @@ def test_16bit_modes_against_the_oracle_b16_224(dtname):
     # bf16: measured 0.30 (r04), and a mere re-ordering of fp32 sums in the small-grid 3x3 launches moved another B = 16 bf16
     # loss by 0.18 (r05, tests/test_round4_gpu.py) -- torch's own bf16 autocast is 0.2 - 0.85 off at this size
     assert abs(loss - ref_loss) < (0.2 if dtname == "f16" else 1.0)
+    if dtname == "bf16" and abs(loss - ref_loss) >= 0.5:
+        # the bound of rounds 3-4, kept as a printed warning so that margin erosion stays visible (the sharp bf16
+        # anchor is the per-tensor comparison against exact f32 in tests/test_round5_gpu.py)
+        print(f"WARNING: bf16 one-step loss is {abs(loss - ref_loss):.3f} from the fp32 oracle -- beyond the 0.5 of rounds 3-4")
     assert abs(float(g.norm()) - float(gref.norm())) < 0.10 * float(gref.norm())
     assert cos >= (0.65 if dtname == "f16" else 0.15)
     assert cos_proj >= (0.85 if dtname == "f16" else 0.35)
