@@ -25,6 +25,12 @@ for p in (ROOT, os.path.join(ROOT, "skin-sm3_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# Kernel arguments in device memory instead of host memory (a ROCm runtime switch; the HIP runtime reads it when it
+# initialises, so it is set before `import torch`): a kernel that starts no longer fetches its argument block over PCIe.
+# With ~1 160 dependent launches per step that is +2.2 % of the two-lane step and +3.5 % single-lane
+# (profiles/r06_dev_kernarg_ab.txt).  An explicit HIP_FORCE_DEV_KERNARG in the environment wins.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -706,6 +712,11 @@ def main():
                        "extensions": {"metadata_dim": args.metadata_dim, "target_momentum": args.target_momentum},
                        "loss": round(loss_val, 5),
                        "peak_hbm_allocated_gb": peak_gb,
+                       # runtime switches in force (kernel arguments in device memory: set at the top of this file) and the
+                       # arithmetic forms of the step: fixed-order weight gradients, 16-bit image stem
+                       "runtime": {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG"),
+                                   "deterministic_weight_gradients": os.environ.get("SM3_WGRAD_DET", "1") != "0",
+                                   "stem_16bit_image": os.environ.get("SM3_STEM16", "1") != "0" and args.dtype != "f32"},
                        # what ran, measured rather than echoed: ranks counted by an all-reduce of ones, the collective
                        # library's version, how the SyncBN statistics travelled, every rank's own ms/step
                        "witness": witness},

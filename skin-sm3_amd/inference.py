@@ -9,6 +9,9 @@ fine-tuning of tools/mlc_eval.py) the heads run on the train-mode kernels of `sm
 (exact-f32 MFMA GEMMs, attention / LayerNorm / dropout / prototype kernels with autograd).  Checkpoints in the reference's wire format
 (`best_linear.pth` / `best_finetune.pth`, keys with "encoder." stripped, inference.py:123-127) load unchanged.
 """
+import os
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory: see sm3hip/__init__.py
+
 import torch
 import torch.nn as nn
 

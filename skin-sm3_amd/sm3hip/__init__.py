@@ -5,7 +5,14 @@ hard error (sm3hip._lib.SM3LibraryError): there is no CPU fallback in the produc
 """
 import os
 
-import torch
+# Kernel arguments in device memory instead of host memory (a ROCm runtime switch; the HIP runtime reads it when it
+# initialises, so it is set before `import torch`): a kernel that starts no longer fetches its argument block over PCIe.
+# With ~1 160 dependent launches per step that is +2.2 % of the two-lane step and +3.5 % single-lane
+# (profiles/r06_dev_kernarg_ab.txt).  Effective when sm3hip is imported before the
+# process makes its first HIP call (bench.py and the tools set it themselves, first thing).  An explicit HIP_FORCE_DEV_KERNARG in the environment wins.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
+import torch  # noqa: E402
 
 _DEFAULT_DTYPE = {"bf16": torch.bfloat16, "f32": torch.float32, "fp32": torch.float32, "f16": torch.float16,
                   "fp16": torch.float16}[

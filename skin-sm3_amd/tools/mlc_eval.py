@@ -19,6 +19,8 @@ SCRIPT_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT_PATH = os.path.split(SCRIPT_DIR)[0]
 sys.path.insert(0, ROOT_PATH)
 
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory: see sm3hip/__init__.py
+
 import torch  # noqa: E402
 import torch.nn as nn  # noqa: E402
 
