@@ -5,6 +5,7 @@
 set -e
 TAG=$1; OUT=gpurun_out/prof_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
+export HIP_FORCE_DEV_KERNARG=1   # what bench.py sets itself; under rocprofv3 the runtime is up before the script runs
 # 1. HBM traffic of the dominant kernel: separate --pmc passes, nothing else traced
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmcF -o pmc -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmcF.log 2>&1
 echo "fetch pass done"

@@ -4,6 +4,7 @@
 # usage: collect_sq_wait.sh <tag>   (repo root on the GPU box)
 OUT=gpurun_out/sqw_$1; mkdir -p $OUT
 export TMPDIR=/tmp
+export HIP_FORCE_DEV_KERNARG=1   # what bench.py sets itself; under rocprofv3 the runtime is up before the script runs
 rocprofv3 -L > $OUT/counters_list.txt 2>&1 || true
 i=0
 for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" \
