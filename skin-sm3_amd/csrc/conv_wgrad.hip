@@ -397,6 +397,183 @@ __global__ __launch_bounds__(256 * KG, NST == 1 ? 4 : 1) void conv_wgrad_kernel(
             }
 }
 
+// ---- nine-tap owner: the weight gradient of a stride-1 "same" 3x3 convolution (round 6) ----------------------------------
+// The tap-shifted kernel above gives every (Co tile, tap, Ci tile) its own workgroup: dY and X cross L2 -> LDS nine times,
+// 15.6 KB per MFLOP.  Here a workgroup owns a 64 x 64 (co, ci) tile pair and ALL nine taps.  A stage is R whole rows of ONE
+// image (R | H): dY rows [R*W, padded with zero rows to a multiple of 16] and the X "halo image" of the same rows plus one
+// image row above and below plus one pixel either side ((R + 2) * W + 2 rows), each staged ONCE by LDS-DMA; tap (dy, dx) of
+// a 16-pixel K block is a transposing read of the X image at the row shift W + 1 + dy * W + dx -- a per-lane base address
+// per tap, fixed for the whole kernel -- so nine MFMAs share one dY fragment: 3.3 ... 5 KB per MFLOP.  Validity:
+//   * dy: a stage never leaves its image, so the halo rows above row 0 / below row H - 1 are zero-filled by the DMA's range
+//     check (a wave-uniform decision per stage), as are the two corner rows of the image;
+//   * dx: the pixel at column 0 (W - 1) must not see its left (right) neighbour, which in the flattened image is the last
+//     (first) pixel of the adjacent row: because a stage starts at a row start, "column of K row r" = r mod W is the same in
+//     every stage, and two masks per K block (a small LDS table built once) zero those K rows of the dY FRAGMENT (4 v_and
+//     each) -- a masked product is an exact zero, the sums are those of the tap-shifted kernel.
+// Four waves, each a 32 x 32 tile of all nine taps (144 accumulator registers): two workgroups per CU, a 2-stage ring.
+struct Wgrad9Params {
+    const char* x;
+    const char* dy;
+    float* dw;
+    int H, W, Ci, Co, R, RW;          // RW = R * W pixels per stage
+    int kblocks, XR;                  // 16-pixel K blocks per stage (dY rows = 16 * kblocks); X image rows (multiple of 8)
+    int spi;                          // stages per image = H / R
+    int stages_view, stages_per_split, splits_view, splits, gx, tilesCi;
+    int wcol[9];                      // column offset of tap t = 3 * (dy + 1) + (dx + 1) in a dw row (canonical tap order)
+    int w_row_stride;
+    uint32_t x_bytes, dy_bytes;
+    long slab_stride, dw_view_stride;
+    int rmw;
+    int img_view;                     // images per view
+};
+
+template <typename T, int NST, int KB>  // KB: K blocks per stage at compile time (full unroll, immediate offsets); 0 = p.kblocks
+__global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(const Wgrad9Params p) {
+    static_assert(sizeof(T) == 2 && (NST == 1 || NST == 2), "16-bit types, one or two stages");
+    const int kblocks = KB ? KB : p.kblocks;
+    constexpr int ROWB = 128;  // 64 channels x 2 bytes: one LDS row of either operand
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    int bx, slice;  // the block -> (tile, slice) map of conv_wgrad_kernel: a slice's tiles side by side on one XCD
+    if (p.splits >= 8) {
+        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+        bx = q % p.gx;
+        slice = (q / p.gx) * 8 + xcd;
+    } else {
+        bx = blockIdx.x % p.gx;
+        slice = blockIdx.x / p.gx;
+    }
+    if (slice >= p.splits) return;
+    const int tci = bx % p.tilesCi, tco = bx / p.tilesCi;
+    const int co0 = tco * 64, ci0 = tci * 64;
+    const int view = slice / p.splits_view;
+    const int sbeg = (slice - view * p.splits_view) * p.stages_per_split;       // stages of this view
+    const int nst = min(p.stages_per_split, p.stages_view - sbeg);
+    if (nst <= 0) return;
+    const int stage0 = view * p.stages_view + sbeg;  // global stage index = image * spi + row group
+
+    const int A_BYTES = kblocks * 16 * ROWB, STAGE = A_BYTES + p.XR * ROWB;
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+
+    // dx masks of the dY fragment, [K block][lane half h][variant: dx = -1, dx = +1][4 dwords]: dword j of a fragment holds
+    // the K rows 16 * ks + 8 * h + 2 * j (low half) and + 1 (high half)
+    uint32_t* const mtab = reinterpret_cast<uint32_t*>(smem + NST * STAGE);
+    for (int e = tid; e < kblocks * 16; e += 256) {
+        const int j = e & 3, var = (e >> 2) & 1, h = (e >> 3) & 1, ks = e >> 4;
+        const int r0 = ks * 16 + 8 * h + 2 * j;
+        const int c0 = r0 % p.W, c1 = (r0 + 1) % p.W;
+        const int bad = var ? p.W - 1 : 0;
+        mtab[e] = (c0 == bad ? 0u : 0x0000ffffu) | (c1 == bad ? 0u : 0xffff0000u);
+    }
+
+    // DMA lane roles: a wave-instruction stages 8 rows x 128 B; lane -> (row lane >> 3, 16-byte chunk lane & 7)
+    const int rin = lane >> 3;
+    const uint32_t lchunk = ((uint32_t)(lane & 7) * 16u) ^ ((uint32_t)((rin >> 1) & 1) << 6);  // source-side swizzle
+    const uint32_t rowbA = (uint32_t)p.Co * 2u, rowbB = (uint32_t)p.Ci * 2u;
+    const uint32_t laneA = (uint32_t)co0 * 2u + lchunk, laneB = (uint32_t)ci0 * 2u + lchunk;
+    const int nA = kblocks * 2, nB = p.XR >> 3;  // wave-instructions per stage
+
+    auto dma_stage = [&](int buf, int gs) {  // gs: global stage index
+        const int img = gs / p.spi, oy0 = (gs - img * p.spi) * p.R;
+        const int f0 = (img * p.H + oy0) * p.W;  // flattened pixel of the stage's first dY row
+        const uint32_t sA = smem_lds + (uint32_t)(buf * STAGE), sB = sA + (uint32_t)A_BYTES;
+        for (int i = wave; i < nA; i += 4) {
+            const int r = i * 8 + rin;
+            const uint32_t off = r < p.RW ? (uint32_t)(f0 + r) * rowbA + laneA : kOOB;
+            dma16(rdy, sA + (uint32_t)i * 1024u, off, 0u);
+        }
+        // X image row j <-> flattened pixel f0 - W - 1 + j; real pixels j in [jlo, jhi], zeros outside
+        const int jlo = 1 + (oy0 == 0 ? p.W : 0), jhi = (p.R + 2) * p.W - (oy0 + p.R == p.H ? p.W : 0);
+        const int fb = f0 - p.W - 1;
+        for (int i = wave; i < nB; i += 4) {
+            const int j = i * 8 + rin;
+            const uint32_t off = (j >= jlo && j <= jhi) ? (uint32_t)(fb + j) * rowbB + laneB : kOOB;
+            dma16(rx, sB + (uint32_t)i * 1024u, off, 0u);
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // transposing reads (see conv_wgrad_kernel): 16-lane group g reads 4 K rows x 16 channels; lane 4q + pq supplies K row q
+    const int g = lane >> 4, ii = lane & 15, q = ii >> 2, pq = ii & 3, h = g >> 1;
+    const int colsel = 16 * (g & 1) + 4 * pq;
+    const int krow0 = 8 * h + q;
+    const uint32_t ra_off = (uint32_t)krow0 * ROWB + (((uint32_t)(wm * 32 + colsel) * 2u) ^ ((uint32_t)((q >> 1) & 1) << 6));
+    uint32_t rb_off[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int row = krow0 + (t / 3) * p.W + (t % 3);  // shift W + 1 + dy * W + dx; + 16 * ks (+ 4) keeps the swizzle key
+        rb_off[t] = (uint32_t)row * ROWB + (((uint32_t)(wn * 32 + colsel) * 2u) ^ ((uint32_t)((row >> 1) & 1) << 6));
+    }
+    const uint32_t m_off = (uint32_t)(NST * STAGE) + (uint32_t)h * 32u;
+
+    if constexpr (NST == 2) dma_stage(0, stage0);
+    for (int s = 0; s < nst; ++s) {
+        if constexpr (NST == 1) {
+            if (s > 0) __syncthreads();
+            dma_stage(0, stage0 + s);
+            dma_drain();
+            __syncthreads();
+        } else {
+            dma_drain();
+            __syncthreads();  // stage s has landed for everyone (and the mask table, s = 0); everyone is done with s - 1
+            if (s + 1 < nst) dma_stage((s + 1) & 1, stage0 + s + 1);
+        }
+        const char* sA = smem + (NST == 2 ? (s & 1) * STAGE : 0);
+        const char* sB = sA + A_BYTES;
+        auto kblock = [&](int ks) {
+            const char* a0 = sA + ra_off + ks * 16 * ROWB;
+            const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+            const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * ROWB));
+            const uint4 mm = *reinterpret_cast<const uint4*>(smem + m_off + ks * 64);
+            const uint4 mp = *reinterpret_cast<const uint4*>(smem + m_off + ks * 64 + 16);
+            const uint2 l2 = __builtin_bit_cast(uint2, alo), h2 = __builtin_bit_cast(uint2, ahi);
+            uint4 fa[3];
+            fa[1] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+            fa[0] = make_uint4(l2.x & mm.x, l2.y & mm.y, h2.x & mm.z, h2.y & mm.w);
+            fa[2] = make_uint4(l2.x & mp.x, l2.y & mp.y, h2.x & mp.z, h2.y & mp.w);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const char* b0 = sB + rb_off[t] + ks * 16 * ROWB;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b0));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b0 + 4 * ROWB));
+                const uint2 bl = __builtin_bit_cast(uint2, lo), bh = __builtin_bit_cast(uint2, hi);
+                const uint4 fb = make_uint4(bl.x, bl.y, bh.x, bh.y);
+                sm3conv::mma_frag<T>(fa[t % 3], fb, acc[t]);
+            }
+        };
+        if constexpr (KB > 0) {
+#pragma unroll
+            for (int ks = 0; ks < KB; ++ks) kblock(ks);
+        } else {
+#pragma unroll 1
+            for (int ks = 0; ks < kblocks; ++ks) kblock(ks);
+        }
+    }
+
+    const int frow = lane & 31, fh = lane >> 5;
+    float* const dw_out = p.slab_stride ? p.dw + (long)slice * p.slab_stride : p.dw + (long)view * p.dw_view_stride;
+    float* const o0 = dw_out + (long)(co0 + wm * 32 + 4 * fh) * p.w_row_stride + ci0 + wn * 32 + frow;
+    auto emit = [&](auto&& put) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) put(o0 + (long)((r & 3) + 8 * (r >> 2)) * p.w_row_stride + p.wcol[t], acc[t][r]);
+    };
+    if (p.slab_stride) emit([](float* o, float v) { *o = v; });
+    else if (p.rmw) emit([](float* o, float v) { *o += v; });
+    else emit([](float* o, float v) { atomicAdd(o, v); });
+}
+
 // slabs per view of this host thread's most recent launch (sm3_conv_wgrad_slabs returns it right after its own launch;
 // thread_local: launches from another host thread -- a second engine, an evaluation thread -- cannot get in between)
 static thread_local int g_last_slabs = 0;
@@ -516,6 +693,100 @@ int launch_wgrad(WgradParams p, hipStream_t st) {
     return launch_wgrad_kp<T, BMW, BNW, KP, false, 2>(p, st);
 }
 
+// Nine-tap owner launch.  Returns 1 when the launch does not qualify (the caller falls back to the tap-shifted kernel).
+// R = the largest divisor of H whose stage (R rows of an image) fits: <= 13 K blocks and a 2-stage ring within 80 KB (two
+// workgroups per CU); a function of the geometry alone, like the slice partition below (a function of geometry and device).
+template <typename T>
+int launch_wgrad9(const sm3_conv_desc* d, const void* x, const void* dy, float* dw, int views, long dw_view_stride,
+                  int slab_cap, float* dw_direct, hipStream_t st) {
+    if (!env_int("SM3_WGRAD9", 1)) return 1;  // read per launch: the tests A/B the two kernels in one process
+    if (d->ntaps != 9 || d->sy != 1 || d->sx != 1 || d->Hi != d->Ho || d->Wi != d->Wo) return 1;
+    if (d->Co % 64 || d->Ci % 64 || d->N % views) return 1;
+    for (int t = 0; t < 9; ++t)
+        if (d->dy[t] != t / 3 - 1 || d->dx[t] != t % 3 - 1 || d->wtap[t] < 0 || (d->wtap[t] + 1) * d->Ci > d->w_row_stride)
+            return 1;
+    const int H = d->Ho, W = d->Wo;
+    const int force_r = env_int("SM3_WGRAD9_R", 0), force_nst = env_int("SM3_WGRAD9_NST", 0);  // experiments only
+    // (R, ring depth): the candidate with the fewest padded K rows (R * W against its multiple of 16) wins -- measured on the
+    // step's shapes (profiles/r06_wgrad9_ab.txt), padding costs more than the second stage buys --, then two stages over
+    // one, then the larger R; below 85 % useful K rows (7 x 7 maps: 49 of 64) the tap-shifted kernel is faster
+    int R = 0, kblocks = 0, XR = 0, nstg = 0;
+    long best_num = 0, best_den = 1;
+    for (int r = H; r >= 1; --r) {
+        if (H % r || (force_r && r != force_r)) continue;
+        const int kb = (r * W + 15) / 16, xr = (16 * kb + 2 * W + 2 + 7) / 8 * 8;
+        const long stage = (long)(16 * kb + xr) * 128;
+        if (kb > 13) continue;
+        const int n = force_nst ? force_nst : (2 * stage + kb * 64 <= 81920 ? 2 : stage + kb * 64 <= 81920 ? 1 : 0);
+        if (!n || n * stage + kb * 64 > 160 * 1024) continue;
+        const long num = (long)r * W, den = 16L * kb;  // efficiency num / den
+        const bool better = !R || num * best_den > best_num * den || (num * best_den == best_num * den && n > nstg);
+        if (better) { R = r; kblocks = kb; XR = xr; nstg = n; best_num = num; best_den = den; }
+    }
+    if (R && !force_r && best_num * 100 < best_den * 85) return 1;
+    if (!R) return 1;
+    Wgrad9Params p;
+    p.x = (const char*)x; p.dy = (const char*)dy; p.dw = dw;
+    p.H = H; p.W = W; p.Ci = d->Ci; p.Co = d->Co; p.R = R; p.RW = R * W; p.kblocks = kblocks; p.XR = XR;
+    p.spi = H / R;
+    p.img_view = d->N / views;
+    p.stages_view = p.img_view * p.spi;
+    p.tilesCi = d->Ci / 64;
+    p.gx = (d->Co / 64) * p.tilesCi;
+    for (int t = 0; t < 9; ++t) p.wcol[t] = d->wtap[t] * d->Ci;
+    p.w_row_stride = d->w_row_stride;
+    p.x_bytes = (uint32_t)((long)d->N * H * W * d->Ci * 2);
+    p.dy_bytes = (uint32_t)((long)d->N * H * W * d->Co * 2);
+    p.slab_stride = slab_cap > 0 ? (long)d->Co * d->w_row_stride : 0;
+    p.dw_view_stride = dw_view_stride;
+    p.rmw = 0;
+    const int LDS = nstg * (16 * kblocks + XR) * 128 + kblocks * 64;
+    const int kbi = kblocks == 7 ? 1 : kblocks == 13 ? 2 : 0;  // unrolled instantiations: the step's shapes at 224 and 448
+    void (*kern)(const Wgrad9Params) =
+        nstg == 2 ? (kbi == 1 ? conv_wgrad9_kernel<T, 2, 7> : kbi == 2 ? conv_wgrad9_kernel<T, 2, 13> : conv_wgrad9_kernel<T, 2, 0>)
+                  : (kbi == 1 ? conv_wgrad9_kernel<T, 1, 7> : kbi == 2 ? conv_wgrad9_kernel<T, 1, 13> : conv_wgrad9_kernel<T, 1, 0>);
+    static std::atomic<int> attr_dev[6][32];
+    const int dev = current_device(), ki = (nstg - 1) * 3 + kbi;
+    if (!attr_dev[ki][dev].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_dev[ki][dev].store(1, std::memory_order_release);
+    }
+    // one full wave of workgroups, whole slices per XCD (the rule of launch_wgrad_kp), two workgroups per CU by registers
+    const int per_cu = LDS > 81920 ? 1 : 2;
+    const long slots_xcd = (long)cus_per_xcd() * per_cu, gx = p.gx;
+    const long target = env_int("SM3_WGRAD_TARGET_CTAS", 0);
+    long splits;
+    if (target > 0) splits = (target + gx - 1) / gx;
+    else if (gx <= slots_xcd) splits = 8 * (slots_xcd / gx);
+    else splits = 8 * slots_xcd / gx;
+    const bool pair_rule = p.slab_stride && !dw_direct;
+    splits = pair_rule ? (splits + 1) / 2 : (splits + views - 1) / views;
+    if (p.slab_stride && splits > slab_cap) splits = slab_cap;
+    const long max_splits = (p.stages_view + 3) / 4;  // >= 4 stages per slice
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    const long sps = (p.stages_view + splits - 1) / splits;
+    splits = (p.stages_view + sps - 1) / sps;
+    p.stages_per_split = (int)sps;
+    p.splits_view = (int)splits;
+    g_last_slabs = (int)splits;
+    splits *= views;
+    p.splits = (int)splits;
+    if (p.slab_stride && dw_direct && splits == 1) {
+        p.slab_stride = 0;
+        p.rmw = 1;
+        p.dw = dw_direct;
+        g_last_slabs = 0;
+    }
+    const long nblocks = gx * (splits >= 8 ? (splits + 7) / 8 * 8 : splits);
+    if (nblocks > 0x7fffffffL) return SM3_EINVAL;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), LDS, st, p);
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace
 
 static int wgrad_impl(const sm3_conv_desc* d, const void* x, const void* dy, float* dw, const void* dy1, int Co1,
@@ -553,6 +824,12 @@ static int wgrad_impl(const sm3_conv_desc* d, const void* x, const void* dy, flo
     if (xb >= 0xC0000000L || yb >= 0xC0000000L || y1b >= 0xC0000000L) return SM3_EINVAL;  // 32-bit buffer offsets
     p.x_bytes = (uint32_t)xb;
     hipStream_t st = (hipStream_t)stream;
+    if (d->dtype != SM3_F32 && Co1 == 0) {  // stride-1 3x3: the nine-tap owner when the geometry fits it
+        const int rc = d->dtype == SM3_BF16
+                           ? launch_wgrad9<bf16_t>(d, x, dy, dw, views, dw_view_stride, slab_cap, dw_direct, st)
+                           : launch_wgrad9<f16_t>(d, x, dy, dw, views, dw_view_stride, slab_cap, dw_direct, st);
+        if (rc != 1) return rc;
+    }
     const bool nco = d->Co + Co1 <= 64, nci = d->Ci <= 64;
     if (d->dtype == SM3_BF16) {
         if (nco && nci) return launch_wgrad<bf16_t, 64, 64>(p, st);

@@ -229,3 +229,74 @@ def test_stem_kernels_on_the_16bit_image_equal_the_fp32_image_kernels_bit_for_bi
             assert torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
             sc = float(outs[0][0].abs().max())
             assert float((o[0] - outs[0][0]).abs().max()) < 2e-5 * max(sc, 1.0)
+
+
+# ---- nine-tap owner weight gradient (csrc/conv_wgrad.hip: conv_wgrad9_kernel) -------------------------------------------
+WGRAD9_CASES = [
+    # N, Ci, Co, H, W: the step's four 3x3 geometries (R = 1 / 4 / 7 / 7 rows per stage), odd maps (R = 1 on a prime H,
+    # a 6 x 6 map staged whole), a map whose stage only fits a one-stage ring (W = 112), Co != Ci
+    (4, 64, 64, 56, 56), (4, 128, 128, 28, 28), (8, 256, 256, 14, 14), (8, 512, 512, 7, 7),
+    (3, 64, 128, 41, 37), (5, 128, 64, 6, 6), (2, 64, 64, 112, 112), (3, 192, 128, 12, 10), (2, 64, 64, 16, 16),
+]
+
+
+def _wgrad9_inputs(case, dt):
+    N, Ci, Co, H, W = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    dy = torch.randn(N, Co, H, W, generator=g)
+    return x, dy
+
+
+@pytest.mark.parametrize("dt", DTYPES3[1:], ids=IDS3[1:])
+@pytest.mark.parametrize("case", WGRAD9_CASES)
+def test_nine_tap_owner_wgrad_against_fp64_and_the_tap_shifted_kernel(case, dt, monkeypatch):
+    ops = _ops()
+    N, Ci, Co, H, W = case
+    x, dy = _wgrad9_inputs(case, dt)
+    code = ops.dtype_code(dt)
+    ref_dw = torch.nn.grad.conv2d_weight(rnd(x, dt).double(), (Co, Ci, 3, 3), rnd(dy, dt).double(), stride=1, padding=1)
+    xd, dyd = nhwc(x, dt), nhwc(dy, dt)
+    d = ops.fwd_desc(code, N, H, W, Ci, Co, 3, 1, 1)
+    n = Co * 9 * Ci
+    cap = ops.wgrad_det_cap(n)
+    slabs = torch.full((cap * n,), float("nan"), device=dev())
+    sc = ref_dw.abs().max().item()
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SM3_WGRAD9", flag)
+        dwa = torch.zeros(Co, 9 * Ci, device=dev())
+        ops.conv_wgrad(d, xd, dyd, dwa)           # float-atomic form
+        dwd = torch.zeros(Co, 9 * Ci, device=dev())
+        ops.conv_wgrad_det(d, xd, dyd, dwd, slabs, cap)  # slabs + fixed-order sum
+        torch.cuda.synchronize()
+        for o in (dwa, dwd):
+            got = o.cpu().reshape(Co, 3, 3, Ci).permute(0, 3, 1, 2)
+            assert (got.double() - ref_dw).abs().max().item() < tol(dt, sc) * 2
+        res[flag] = (dwa, dwd)
+    # same products, another partition of the pixel axis: fp32 reassociation only
+    for a, b in zip(res["1"], res["0"]):
+        assert (a - b).abs().max().item() < 2e-5 * sc * math.sqrt(N * H * W)
+
+
+@pytest.mark.parametrize("dt", DTYPES3[1:], ids=IDS3[1:])
+@pytest.mark.parametrize("case", [(4, 128, 128, 28, 28), (2, 64, 64, 16, 16), (3, 64, 128, 32, 8)])
+def test_nine_tap_owner_wgrad_bits_equal_the_tap_shifted_kernel_on_one_slice(case, dt, monkeypatch):
+    """With ONE pixel slice and stages that are whole 16-pixel K blocks (R * W a multiple of 16: R = 4 / 8 / 16 by the
+    library's rule here) both kernels feed every accumulator the same 16-pixel groups in the same order; masked and
+    zero-filled products are exact zeros: equal bits."""
+    ops = _ops()
+    N, Ci, Co, H, W = case
+    x, dy = _wgrad9_inputs(case, dt)
+    code = ops.dtype_code(dt)
+    xd, dyd = nhwc(x, dt), nhwc(dy, dt)
+    d = ops.fwd_desc(code, N, H, W, Ci, Co, 3, 1, 1)
+    monkeypatch.setenv("SM3_WGRAD_TARGET_CTAS", "1")
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SM3_WGRAD9", flag)
+        dw = torch.zeros(Co, 9 * Ci, device=dev())
+        ops.conv_wgrad(d, xd, dyd, dw)
+        torch.cuda.synchronize()
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1])
