@@ -402,7 +402,9 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI >= 1 && STAGES == 1) ? 4 : 2) voi
                                     unpack16<T>(*lp, v);
 #pragma unroll
                                     for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
-                                    const bool own = j >= hoff && j < hoff + BM;
+                                    // the activation / mask of a row leave from ONE workgroup: the tile of column block 0 (every
+                                    // column block transforms its own LDS copy; ADVICE r5: 2-4 x the stores otherwise)
+                                    const bool own = n0 == 0 && j >= hoff && j < hoff + BM;
                                     const long goff = (long)q * row_bytes + gch;
                                     if (own) {
                                         unsigned mk = 0;
