@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ x, co
                 mask[r * (C / E) + cv] = (uint8_t)m;
             }
 #pragma unroll
-            for (int e = 0; e < E; ++e) v[e] = fmaxf(v[e], 0.f);
+            for (int e = 0; e < E; ++e) v[e] = relu_f32(v[e]);
         }
         if constexpr (OUT_F32) {
             float* yo = reinterpret_cast<float*>(y) + off;
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             unpack16<T>(xu, xv);
             if (mask) {
 #pragma unroll
-                for (int e = 0; e < E; ++e) g[e] = ((m >> e) & 1u) ? g[e] : 0.f;
+                for (int e = 0; e < E; ++e) g[e] = keep_if_bit(g[e], m, e);
                 if (dz) stg16<NT>(dz + off, pack16<T>(g));
             } else if (y) {
                 float yv[E];

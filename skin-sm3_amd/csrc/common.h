@@ -30,8 +30,11 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
     return __builtin_bit_cast(uint16_t, h);
 }
 
+// both halves in ONE v_cvt_pk_bf16_f32 (a vector conversion: written as two scalar casts + shift/or the compiler emits two
+// conversions and a v_or_sdwa per pair -- three instructions where one does; same round-to-nearest-even per element)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
 
 __device__ __forceinline__ float f16_to_f32(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
@@ -40,7 +43,20 @@ __device__ __forceinline__ uint16_t f32_to_f16(float f) {  // round-to-nearest-e
     return __builtin_bit_cast(uint16_t, h);
 }
 __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
-    return (uint32_t)f32_to_f16(lo) | ((uint32_t)f32_to_f16(hi) << 16);
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, f16x2_t));
+}
+
+// ReLU as ONE v_max_f32: fmaxf(v, 0) costs a canonicalising v_max in front of the v_max wherever the compiler cannot prove
+// its operand quiet (values unpacked from 16-bit words), and it folds v_med3(v, 0, inf) back into the same pair -- so the
+// instruction is written out.  max(0, NaN) = 0, as fmaxf(NaN, 0) is.
+__device__ __forceinline__ float relu_f32(float v) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+// v where bit e of m is set, else +0: v_bfe_i32 (0 / -1) + v_and instead of v_and + v_cmp + v_cndmask
+__device__ __forceinline__ float keep_if_bit(float v, unsigned m, int e) {
+    return __uint_as_float(__float_as_uint(v) & (uint32_t)__builtin_amdgcn_sbfe((int)m, (unsigned)e, 1u));
 }
 
 template <typename T>

@@ -413,7 +413,7 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI >= 1 && STAGES == 1) ? 4 : 2) voi
                                         p.in_mask[goff >> 4] = (uint8_t)mk;
                                     }
 #pragma unroll
-                                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                                    for (int e = 0; e < 8; ++e) v[e] = relu_f32(v[e]);
                                     const uint4 pk = pack16<T>(v);
                                     *lp = pk;
                                     if (own) stg16<true>(p.in_act + goff, pk);
@@ -628,23 +628,31 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI >= 1 && STAGES == 1) ? 4 : 2) voi
         // are tested once, not per accumulator pair -- EPI 2 / 3 launches almost never want the BatchNorm sums of their
         // output and used to pay 2 v_dot2 per pair for them.
         const bool early_relu = epl && p.ep_relu && (EPI == 1 || !p.addend) && !p.ep_mask;
-        auto stage_tile = [&](auto stats_c, auto aff_c) {
-            constexpr bool STATS = decltype(stats_c)::value, AFF = decltype(aff_c)::value;
+        auto stage_tile = [&](auto stats_c, auto aff_c, auto relu_c) {
+            constexpr bool STATS = decltype(stats_c)::value, AFF = decltype(aff_c)::value, RELU = decltype(relu_c)::value;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 float s1 = 0.f, s2 = 0.f;
                 char* colp = sC + (wn * WTN + j * 32 + frow) * 2 + (wm * WTM + 4 * fh) * LEAN_PITCH;
+                const uint32_t colp_lds = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)colp);
                 // BatchNorm affine (+ReLU when nothing is added afterwards) of this lane's column, in the accumulator layout;
                 // per view in the train-mode fused form
-                const float esc = esc_j[j], esh = esh_j[j], elo = (AFF && early_relu) ? 0.f : -INFINITY;
+                const float esc = esc_j[j], esh = esh_j[j];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {  // registers 2q, 2q+1 = rows R, R+1 of this lane's column
                         float v0 = acc[i][j][2 * q], v1 = acc[i][j][2 * q + 1];
-                        if constexpr (AFF) {
-                            v0 = fmaxf(v0 * esc + esh, elo);
-                            v1 = fmaxf(v1 * esc + esh, elo);
+                        if constexpr (AFF) {  // (the ReLU only where nothing is added afterwards: a flavour, not a max with -inf)
+                            // both rows share the column's scale / shift: one v_pk_fma_f32 (the same fma, per element)
+                            f32x2_t vv = {v0, v1};
+                            vv = __builtin_elementwise_fma(vv, f32x2_t{esc, esc}, f32x2_t{esh, esh});
+                            v0 = vv.x;
+                            v1 = vv.y;
+                            if constexpr (RELU) {
+                                v0 = fmaxf(v0, 0.f);
+                                v1 = fmaxf(v1, 0.f);
+                            }
                         }
                         const uint32_t pk = pack2<T>(v0, v1);
                         if constexpr (STATS) {
@@ -652,8 +660,12 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI >= 1 && STAGES == 1) ? 4 : 2) voi
                             s2 = dot2acc<T>(pk, pk, s2);
                         }
                         const int R = i * 32 + (q & 1) * 2 + 8 * (q >> 1);
-                        *reinterpret_cast<uint16_t*>(colp + R * LEAN_PITCH) = (uint16_t)pk;
-                        *reinterpret_cast<uint16_t*>(colp + (R + 1) * LEAN_PITCH) = (uint16_t)(pk >> 16);
+                        // ONE v_cvt_pk per pair: the high half leaves through ds_write_b16_d16_hi (left to itself the compiler
+                        // converts each value on its own to keep both in low halves: 64 conversions per tile instead of 32)
+                        asm volatile("ds_write_b16 %0, %1 offset:%2\n\tds_write_b16_d16_hi %0, %1 offset:%3"
+                                     :
+                                     : "v"(colp_lds), "v"(pk), "n"(R * LEAN_PITCH), "n"((R + 1) * LEAN_PITCH)
+                                     : "memory");
                     }
                 if constexpr (STATS) {
                     s1 += __shfl_xor(s1, 32, 64);
@@ -669,12 +681,15 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI >= 1 && STAGES == 1) ? 4 : 2) voi
         using std::true_type;
         using std::false_type;
         if (p.partials) {
-            if (aff) stage_tile(true_type{}, true_type{});
-            else stage_tile(true_type{}, false_type{});
+            if (aff && early_relu) stage_tile(true_type{}, true_type{}, true_type{});
+            else if (aff) stage_tile(true_type{}, true_type{}, false_type{});
+            else stage_tile(true_type{}, false_type{}, false_type{});
         } else {
-            if (aff) stage_tile(false_type{}, true_type{});
-            else stage_tile(false_type{}, false_type{});
+            if (aff && early_relu) stage_tile(false_type{}, true_type{}, true_type{});
+            else if (aff) stage_tile(false_type{}, true_type{}, false_type{});
+            else stage_tile(false_type{}, false_type{}, false_type{});
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging writes above are issued from asm
         __syncthreads();
         SM3_MARK(3);
         if (p.partials && tid < BN && n0 + tid < p.Co) {
@@ -736,7 +751,11 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI >= 1 && STAGES == 1) ? 4 : 2) voi
                         float a[8];
                         unpack16<T>(pre_add[k], a);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += a[e];
+                        for (int e = 0; e < 8; e += 2) {  // v_pk_add_f32
+                            const f32x2_t t = f32x2_t{v[e], v[e + 1]} + f32x2_t{a[e], a[e + 1]};
+                            v[e] = t.x;
+                            v[e + 1] = t.y;
+                        }
                     }
                     if (late_relu) {
                         if (p.ep_mask) {  // what the backward pass needs of the output: one bit per element
@@ -746,13 +765,13 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI >= 1 && STAGES == 1) ? 4 : 2) voi
                             p.ep_mask[eoff[k] >> 4] = (uint8_t)mbits;
                         }
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                        for (int e = 0; e < 8; ++e) v[e] = relu_f32(v[e]);
                     }
                     if constexpr (EPI == 3) {
                         if (fz) {
                             const unsigned mk = pre_mk[k];
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = ((mk >> e) & 1u) ? v[e] : 0.f;
+                            for (int e = 0; e < 8; ++e) v[e] = keep_if_bit(v[e], mk, e);
                         }
                     }
                     packed = pack16<T>(v);
@@ -980,7 +999,7 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI >= 1 && STAGES == 1) ? 4 : 2) voi
                     p.ep_mask[e_off[k] / EPC] = (uint8_t)m;
                 }
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) v[e] = fmaxf(v[e], 0.f);
+                for (int e = 0; e < EPC; ++e) v[e] = relu_f32(v[e]);
             }
             if (fz) {
                 // BN-backward phase 1 fused here (data-gradient launches): the value just computed is dy of the
@@ -990,7 +1009,7 @@ __global__ __launch_bounds__(WM* WN * 64, (EPI >= 1 && STAGES == 1) ? 4 : 2) voi
                 unpack16<T>(pre_x[k], xv);
                 const unsigned mk = pre_mk[k];
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) v[e] = ((mk >> e) & 1u) ? v[e] : 0.f;
+                for (int e = 0; e < EPC; ++e) v[e] = keep_if_bit(v[e], mk, e);
                 const uint4 packed = pack16<T>(v);
                 float dzr[EPC];
                 unpack16<T>(packed, dzr);  // sums are those of the STORED (rounded) dz, as the standalone kernel's

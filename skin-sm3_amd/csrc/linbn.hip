@@ -259,7 +259,8 @@ __device__ __forceinline__ void banks_row(const T* __restrict__ wd, const float4
         unpack16<T>(pa, fa);
         unpack16<T>(pb, fb);
 #pragma unroll
-        for (int e = 0; e < E; ++e) part -= q[e].w * fb[e] + q[e].z * fa[e];
+        for (int e = 0; e < E; ++e)  // explicit fma: every instantiation of this row (with / without the stored -b wd bank) rounds alike
+            part -= __builtin_fmaf(q[e].w, fb[e], q[e].z * fa[e]);
     }
     part = wave_sum(part);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;

@@ -458,7 +458,8 @@ def conv_wgrad(desc, x, dy, dw):
         check(_lib.load().sm3_conv_wgrad(C.byref(desc), _ptr(x), _ptr(dy), _ptr(dw), _stream()), "sm3_conv_wgrad")
 
 
-WGRAD_SLAB_CAP = 256          # slabs a deterministic weight-gradient launch may use (sm3_conv_wgrad_det)
+WGRAD_SLAB_CAP = 512          # slabs a deterministic weight-gradient launch may use (sm3_conv_wgrad_det); 512: the nine-tap
+                              # owner on 56 x 56 x 64 has ONE tile pair, so its slices are its workgroups (256 -> 512: 189 -> 140 us)
 WGRAD_SLAB_FLOATS = 1 << 26   # ... within a workspace of at most max(this, 8 slabs) floats
 
 
