@@ -71,11 +71,48 @@ __device__ __forceinline__ double half_sum(double v) {  // over the 32 lanes of 
 //   blocks [0, gblocks):  G[v][e] = sum_j slabs[v][j][e]            (the slabs sm3_conv_wgrad_slabs left for y^T y; the
 //                         same sum gives P = dz^T y from its slabs: n elements per view, no column sums)
 //   blocks beyond:        s[v][ci] = sum_r colsum_partials[v][r][ci] (sm3_bn_act_colsum), 32 columns x 8 row lanes per block
+constexpr int kMomentsLaneSlabs = 48;  // from here on the slabs of an element are walked by 8 lanes (linbn_moments_kernel)
 __global__ __launch_bounds__(256) void linbn_moments_kernel(const float* __restrict__ slabs, int nslabs, long pp,
                                                             const float* __restrict__ colsum, int crow,
                                                             float* __restrict__ G, double* __restrict__ s_out, int p,
                                                             int views, int gblocks) {
-    if ((int)blockIdx.x < gblocks) {
+    if ((int)blockIdx.x < gblocks && nslabs >= kMomentsLaneSlabs) {
+        // many slabs (the rule is a function of the slab count, i.e. of the geometry): a workgroup owns 32 float4 columns x 8 slab lanes (the walk of slab_reduce_kernel): lane l adds slabs l, l + 8, ... on
+        // four interleaved accumulators, the eight lane sums are added in lane order through LDS.  (One thread per float4
+        // walking ALL slabs left the 64 x 64 Gram matrices of layer 1 -- 256 slabs, 8 workgroups -- at 24 us per launch.)
+        __shared__ float4 gred[8][32];
+        const int col = threadIdx.x & 31, jl = threadIdx.x >> 5;
+        const long e4 = ((long)blockIdx.x * 32 + col) * 4;
+        const bool in = e4 < (long)views * pp;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+        auto add = [](float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+        if (in) {
+            const int v = (int)(e4 / pp);
+            const float* src = slabs + (long)v * nslabs * pp + (e4 - (long)v * pp);
+            int j = jl;
+            for (; j + 24 < nslabs; j += 32) {
+                const float4 v0 = *reinterpret_cast<const float4*>(src + (long)j * pp);
+                const float4 v1 = *reinterpret_cast<const float4*>(src + (long)(j + 8) * pp);
+                const float4 v2 = *reinterpret_cast<const float4*>(src + (long)(j + 16) * pp);
+                const float4 v3 = *reinterpret_cast<const float4*>(src + (long)(j + 24) * pp);
+                add(a0, v0); add(a1, v1); add(a2, v2); add(a3, v3);
+            }
+            for (; j < nslabs; j += 8) add(a0, *reinterpret_cast<const float4*>(src + (long)j * pp));
+            add(a0, a1);
+            add(a2, a3);
+            add(a0, a2);
+        }
+        gred[jl][col] = a0;
+        __syncthreads();
+        if (jl == 0 && in) {
+            float4 t = gred[0][col];
+#pragma unroll
+            for (int l = 1; l < 8; ++l) add(t, gred[l][col]);
+            *reinterpret_cast<float4*>(G + e4) = t;
+        }
+        return;
+    }
+    if ((int)blockIdx.x < gblocks) {  // few slabs: one thread per float4 walks them all (the lanes above would idle)
         const long e4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;  // four consecutive elements of one view's matrix
         if (e4 >= (long)views * pp) return;
         const int v = (int)(e4 / pp);
@@ -446,7 +483,8 @@ extern "C" int sm3_linbn_moments(const float* slabs, int nslabs, int64_t n, floa
     if (!slabs || !out || nslabs < 1 || n <= 0 || views < 1) return SM3_EINVAL;
     if (colsum_partials && (!s_out || colsum_rows < 1 || p <= 0)) return SM3_EINVAL;
     if (n % 4) return SM3_EALIGN;
-    const int gblocks = (int)(((long)views * n / 4 + 255) / 256), cblocks = colsum_partials ? views * ((p + 31) / 32) : 0;
+    const long per_block = nslabs >= kMomentsLaneSlabs ? 32 : 256;  // float4 columns per workgroup
+    const int gblocks = (int)(((long)views * n / 4 + per_block - 1) / per_block), cblocks = colsum_partials ? views * ((p + 31) / 32) : 0;
     hipLaunchKernelGGL(linbn_moments_kernel, dim3(gblocks + cblocks), dim3(256), 0, (hipStream_t)stream, slabs, nslabs, (long)n,
                        colsum_partials, colsum_rows, out, s_out, p, views, gblocks);
     SM3_CHECK_LAUNCH();
