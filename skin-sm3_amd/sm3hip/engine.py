@@ -335,7 +335,7 @@ class SM3Engine:
         self.view_lanes = _os.environ.get("SM3_VIEW_LANES", "0") == "1"
         self._bn_ev = {}
         self._ordered_bn = False  # set while the two views of a branch run on two lanes
-        self.side_wgrad = _os.environ.get("SM3_SIDE_WGRAD", "0") == "1"  # measured slower (2600 vs 2790 pairs/s): weight-gradient kernels fight the HBM-bound chain for L2/HBM
+        self.side_wgrad = _os.environ.get("SM3_SIDE_WGRAD", "0") == "1"  # round 1: slower (2600 vs 2790 pairs/s); round 6, fixed-order sums on the side stream too: 4 631-4 651 vs 4 601-4 632 (+0.5 %, noise) on the default 4 hardware queues, 4 465 vs 4 590 with GPU_MAX_HW_QUEUES=8 -- stays opt-in
         self._side = {}
         self.two_streams = True
         self._streams, self._streams_dev = None, None
@@ -1069,7 +1069,13 @@ class SM3Engine:
         for t in (dxo, r.x_in):
             t.record_stream(side)  # keep the allocator from recycling them while the side stream still reads
         with torch.cuda.stream(side), ops.stream_scope():
-            ops.conv_wgrad(desc, r.x_in, dxo, gw)
+            if self.det_wgrad and desc.w_row_stride == desc.ntaps * desc.Ci:
+                n = desc.Co * desc.w_row_stride
+                cap = ops.wgrad_det_cap(n)
+                slabs = self._work("wgrad_slabs_side", cap * n)  # the side stream's own slabs (its launches are in order)
+                ops.conv_wgrad_det(desc, r.x_in, dxo, gw, slabs, cap)
+            else:
+                ops.conv_wgrad(desc, r.x_in, dxo, gw)
 
     def _side_stream(self):
         if not self.side_wgrad or self.store.flat_p.device.type != "cuda":
