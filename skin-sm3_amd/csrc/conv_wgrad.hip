@@ -682,7 +682,9 @@ int launch_wgrad(WgradParams p, hipStream_t st) {
     // dense rings (+3 ... +40 % time), 2-stage dense rings at two workgroups per CU with 32- or 64-pixel steps (+8 ... +9 % over
     // the class, profiles/r05_wgrad_dense_variants_ab.txt), two K-groups on the tap-shifted kernel (+4 ... +67 %), the
     // 128-register cap of the tap-shifted kernel (+-0), and a 128 x 256 tile for the layer-3 / layer-4 dense shapes (3-stage
-    // ring x 2 K-groups, 256 registers with 8 spilled: +3 % over the class, profiles/r06_wgrad_wide_tile_ab.txt).
+    // ring x 2 K-groups, 256 registers with 8 spilled: +3 % over the class; its table was lost with that session's container, the code is
+    // in the patch).  Round 6 also measured ONE stage of 128 pixels at two workgroups per CU: faster alone on two layer-4 shapes,
+    // nothing in the step (profiles/r06_wgrad_dense_stage_ab.txt).
     constexpr int KP = sizeof(T) == 2 ? 32 : 16;
     const bool dense = p.ntaps == 1 && p.sy == 1 && p.sx == 1 && p.dyt[0] == 0 && p.dxt[0] == 0 &&
                        p.HoWo == p.Hi * p.Wi;
