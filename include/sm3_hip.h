@@ -470,6 +470,15 @@ int sm3_ntxent_fused(int dtype, const float* z, int R, int D, float temperature,
 int sm3_ntxent_fused_scaled(int dtype, const float* z, int R, int D, float temperature, float weight,
                             const float* dz_scale, float* workspace, float* loss, void* dz, void* stream);
 
+/* n <= 4 NT-Xent terms of EQUAL shape in three launches instead of 3 n (round 6; ABI 8 addition): the four loss terms of a
+ * step -- derm, clinic and the two cross-modal ones (tools/backbone_train.py:99-102,119-121) -- sit on the main stream between
+ * the lanes' forward and backward, where nothing else runs.  z, dz: host arrays of n device pointers; weights: host array of n;
+ * dz_scale: NULL or the device scalar of sm3_ntxent_fused_scaled; workspace: n * round_up(R*D + 3*R, 4) floats, 16-byte aligned.  Every
+ * dz[t] and the loss are bit-identical to n calls of sm3_ntxent_fused(_scaled) in term order.  D % 4 == 0, D <= 128
+ * (SM3_EINVAL otherwise: the caller keeps the per-term calls). */
+int sm3_ntxent_fused_batch(int dtype, int nterms, const float* const* z, int R, int D, float temperature, const float* weights,
+                           const float* dz_scale, float* workspace, float* loss, void* const* dz, void* stream);
+
 /* Global negatives under data parallelism (BASELINE.json north_star: all-gather of the projection embeddings; NOT the
  * reference's behaviour -- its negatives are the local batch, SURVEY.md section 0 -- hence an opt-in mode of the trainer):
  *   zn = normalise(z) (sm3_normalize_rows), all-gathered over RCCL to zg [Rg = world*Rl][D];

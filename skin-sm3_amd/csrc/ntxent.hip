@@ -29,9 +29,30 @@ __global__ __launch_bounds__(256) void ordered_loss_add_kernel(const float* __re
     if (threadIdx.x == 0) *loss += (float)s;
 }
 
+// The NT-Xent terms of a step (derm, clinic, two cross-modal: same R, D, temperature) as ONE launch per phase, blockIdx.y =
+// term (sm3_ntxent_fused_batch, round 6): 12 dependent launches of 64 workgroups on the main stream -- where neither lane has
+// other work -- become 3 of 256.  Per-term operands travel by value.
+struct NtxBatch {
+    const float* z[4];
+    float* ws[4];   // per term: zn [R][D] | inv_norm [R] | lse [R] | row_terms [R]
+    void* dz[4];
+    float weight[4];
+    int n;
+};
+
 // one wave per row: zn = z / max(||z||, 1e-12)
+__device__ __forceinline__ void normalize_rows_body(const float* __restrict__ z, int R, int D, float* __restrict__ zn,
+                                                    float* __restrict__ inv_norm);
 __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ z, int R, int D,
                                                              float* __restrict__ zn, float* __restrict__ inv_norm) {
+    normalize_rows_body(z, R, D, zn, inv_norm);
+}
+__global__ __launch_bounds__(256) void normalize_rows_batch_kernel(const NtxBatch b, int R, int D) {
+    const int t = blockIdx.y;
+    normalize_rows_body(b.z[t], R, D, b.ws[t], b.ws[t] + (size_t)R * D);
+}
+__device__ __forceinline__ void normalize_rows_body(const float* __restrict__ z, int R, int D, float* __restrict__ zn,
+                                                    float* __restrict__ inv_norm) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= R) return;
@@ -359,6 +380,12 @@ namespace {
 constexpr int NTX_TI = 8, NTX_TJ = 64, NTX_CP = NTX_TJ + 4;
 
 template <bool BWD, typename T, int NV>
+__device__ __forceinline__ void ntxent_tile_body(const float* __restrict__ zn, const float* __restrict__ inv_norm,
+                                                 float* __restrict__ lse, int R, int D, float inv_t, float weight,
+                                                 const float* __restrict__ dz_scale, float* __restrict__ row_terms,
+                                                 T* __restrict__ dz);
+
+template <bool BWD, typename T, int NV>
 __global__ __launch_bounds__(256) void ntxent_tile_kernel(const float* __restrict__ zn, const float* __restrict__ inv_norm,
                                                           float* __restrict__ lse, int R, int D, float inv_t, float weight,
                                                           const float* __restrict__ dz_scale, float* __restrict__ row_terms,
@@ -370,6 +397,36 @@ __global__ __launch_bounds__(256) void ntxent_tile_kernel(const float* __restric
             if (threadIdx.x == 0) *loss += (float)s;
         }
     }
+    ntxent_tile_body<BWD, T, NV>(zn, inv_norm, lse, R, D, inv_t, weight, dz_scale, row_terms, dz);
+}
+
+// blockIdx.y = term.  The loss: ONE workgroup adds the terms' sums to *loss one after the other, term 0 first -- the float
+// additions the per-term calls make, in their order (bit-identical to n calls of sm3_ntxent_fused).
+template <bool BWD, typename T, int NV>
+__global__ __launch_bounds__(256) void ntxent_tile_batch_kernel(const NtxBatch b, int R, int D, float inv_t,
+                                                                const float* __restrict__ dz_scale, float* __restrict__ loss) {
+    const int t = blockIdx.y;
+    float* const zn = b.ws[t];
+    float* const inv_norm = zn + (size_t)R * D;
+    float* const lse = inv_norm + R;
+    float* const row_terms = lse + R;
+    if constexpr (BWD) {
+        __shared__ double sh4[4];
+        if (loss && blockIdx.x == 0 && t == 0) {
+            for (int u = 0; u < b.n; ++u) {
+                const double s = block256_ordered_sum(b.ws[u] + (size_t)R * D + 2 * (size_t)R, R, sh4);
+                if (threadIdx.x == 0) *loss += (float)s;
+            }
+        }
+    }
+    ntxent_tile_body<BWD, T, NV>(zn, inv_norm, lse, R, D, inv_t, b.weight[t], dz_scale, row_terms, (T*)b.dz[t]);
+}
+
+template <bool BWD, typename T, int NV>
+__device__ __forceinline__ void ntxent_tile_body(const float* __restrict__ zn, const float* __restrict__ inv_norm,
+                                                 float* __restrict__ lse, int R, int D, float inv_t, float weight,
+                                                 const float* __restrict__ dz_scale, float* __restrict__ row_terms,
+                                                 T* __restrict__ dz) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D4 = D >> 2, DP = D + 4;
     float* zi = sm;                      // [TI][DP]
@@ -570,6 +627,42 @@ static int ntxent_fused_impl(int dtype, const float* z, int R, int D, float temp
                        row_terms, loss, (T*)dz)
     SM3_DISPATCH_DTYPE(dtype, SM3_NTX);
 #undef SM3_NTX
+    SM3_CHECK_LAUNCH();
+    return 0;
+}
+
+// n <= 4 NT-Xent terms of equal shape in three launches (normalise, LSE, backward), blockIdx.y = term; every per-term result and
+// the loss are bit-identical to n calls of sm3_ntxent_fused(_scaled) in term order.  Tiled path only (D % 4 == 0, D <= 128).
+extern "C" int sm3_ntxent_fused_batch(int dtype, int nterms, const float* const* z, int R, int D, float temperature,
+                                      const float* weights, const float* dz_scale, float* workspace, float* loss,
+                                      void* const* dz, void* stream) {
+    if (!z || !weights || !workspace || !dz || nterms < 1 || nterms > 4 || R < 2 || (R & 1) || D <= 0 || temperature <= 0)
+        return SM3_EINVAL;
+    if (!SM3_DTYPE_OK(dtype)) return SM3_EDTYPE;
+    if (D % 4 || D > 128 || ((uintptr_t)workspace & 15)) return SM3_EINVAL;
+    const size_t per = ((size_t)R * D + 3 * (size_t)R + 3) & ~(size_t)3;  // a term's block, padded: every zn stays 16-byte aligned
+    NtxBatch b;
+    b.n = nterms;
+    for (int t = 0; t < 4; ++t) {
+        const int u = t < nterms ? t : 0;
+        if (!z[u] || !dz[u]) return SM3_EINVAL;
+        b.z[t] = z[u];
+        b.ws[t] = workspace + (size_t)u * per;
+        b.dz[t] = dz[u];
+        b.weight[t] = weights[u];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const float inv_t = 1.f / temperature;
+    hipLaunchKernelGGL(normalize_rows_batch_kernel, dim3((R + 3) / 4, nterms), dim3(256), 0, st, b, R, D);
+    SM3_CHECK_LAUNCH();
+    const size_t lds = (size_t)((NTX_TI + NTX_TJ) * (D + 4) + NTX_TI * NTX_CP + NTX_TJ) * 4;
+    const dim3 grid((R + NTX_TI - 1) / NTX_TI, nterms);
+#define SM3_NTX_BATCH(T)                                                                                                 \
+    hipLaunchKernelGGL((ntxent_tile_batch_kernel<false, T, 8>), grid, dim3(256), lds, st, b, R, D, inv_t,                  \
+                       (const float*)nullptr, (float*)nullptr);                                                           \
+    hipLaunchKernelGGL((ntxent_tile_batch_kernel<true, T, 8>), grid, dim3(256), lds, st, b, R, D, inv_t, dz_scale, loss)
+    SM3_DISPATCH_DTYPE(dtype, SM3_NTX_BATCH);
+#undef SM3_NTX_BATCH
     SM3_CHECK_LAUNCH();
     return 0;
 }

@@ -138,6 +138,7 @@ SIGNATURES = {
     "sm3_adamw_dynamic": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P],
     "sm3_loss_scale_update": [_P, _P, _P, _P, _F, _F, _I, _P],
     "sm3_ntxent_fused_scaled": [_I, _P, _I, _I, _F, _F, _P, _P, _P, _P, _P],
+    "sm3_ntxent_fused_batch": [_I, _I, _P, _I, _I, _F, _P, _P, _P, _P, _P, _P],
     "sm3_ema_update": [_P, _P, _L, _F, _P],
     "sm3_check_finite": [_P, _L, _P, _P],
     "sm3_aug_resized_crop": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P],

@@ -1365,6 +1365,38 @@ def ntxent_fused(dtype, z, temperature, weight, workspace, loss, dz, dz_scale=No
                   "sm3_ntxent_fused_scaled")
 
 
+def ntxent_batch_workspace_floats(n, R, D):
+    """Workspace of ntxent_fused_batch: n per-term blocks, each padded to a multiple of 4 floats."""
+    return n * ((ntxent_workspace_floats(R, D) + 3) // 4 * 4)
+
+
+def ntxent_fused_batch(dtype, zs, temperature, weights, workspace, loss, dzs, dz_scale=None):
+    """The NT-Xent terms of a step (equal [R, D] fp32 projections, at most 4) in three launches instead of 3 per term
+    (sm3_ntxent_fused_batch): loss and every dz bit-identical to ntxent_fused called term by term.  Returns False -- nothing
+    launched -- when the shapes do not qualify (the caller then makes the per-term calls)."""
+    n = len(zs)
+    if not (1 <= n <= 4) or len(dzs) != n or len(weights) != n:
+        return False
+    R, D = zs[0].shape
+    if D % 4 or D > 128 or R % 2 or any(tuple(z.shape) != (R, D) for z in zs):
+        return False
+    per = ntxent_batch_workspace_floats(1, R, D)
+    _chk(workspace, torch.float32); _chk(loss, torch.float32); _chk(dz_scale, torch.float32, "dz_scale")
+    for z, dz in zip(zs, dzs):
+        _chk(z, torch.float32); _chk(dz, TORCH_DTYPE[dtype])
+        if dz.numel() != R * D:
+            raise ValueError("ntxent_fused_batch: dz size mismatch")
+    if workspace.numel() < n * per:
+        raise ValueError("ntxent_fused_batch: workspace too small")
+    zp = (C.c_void_p * n)(*[z.data_ptr() for z in zs])
+    dp = (C.c_void_p * n)(*[d.data_ptr() for d in dzs])
+    wp = (C.c_float * n)(*[float(w) for w in weights])
+    with _prof("ntxent_fused", 6.0 * n * R * R * D, 4.0 * n * R * D * 3):
+        check(_lib.load().sm3_ntxent_fused_batch(dtype, n, zp, R, D, temperature, wp, _ptr(dz_scale), _ptr(workspace),
+                                                 _ptr(loss), dp, _stream()), "sm3_ntxent_fused_batch")
+    return True
+
+
 def normalize_rows(z, zn, inv_norm):
     for t in (z, zn, inv_norm):
         _chk(t, torch.float32)

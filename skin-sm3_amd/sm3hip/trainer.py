@@ -259,7 +259,17 @@ class SM3Trainer:
         dz = {}
         T = float(self.model.temperature)
         sc = self._scaler_state(dev, eng.tdt)
-        for name, z in zs.items():
+        batched = False
+        if zt is None and not self.global_negatives and os.environ.get("SM3_NTXENT_BATCH", "1") != "0" and dev.type == "cuda":
+            # the step's terms (equal shapes) in three launches instead of three per term, same bits (sm3_ntxent_fused_batch)
+            names = list(zs)
+            shp = zs[names[0]].shape
+            ws = eng._work("ntxent_ws_batch", ops.ntxent_batch_workspace_floats(len(names), *shp))
+            for name in names:
+                dz[name] = torch.empty(shp[0], shp[1], dtype=eng.tdt, device=dev)
+            batched = ops.ntxent_fused_batch(eng.dtype, [zs[n] for n in names], T, [weights[n] for n in names], ws, loss,
+                                             [dz[n] for n in names], dz_scale=sc["scale"] if sc is not None else None)
+        for name, z in (() if batched else zs.items()):
             R, D = z.shape
             ws = eng._work("ntxent_ws", ops.ntxent_workspace_floats(R, D))
             dz[name] = torch.empty(R, D, dtype=eng.tdt, device=dev)

@@ -300,3 +300,32 @@ def test_nine_tap_owner_wgrad_bits_equal_the_tap_shifted_kernel_on_one_slice(cas
         torch.cuda.synchronize()
         outs.append(dw)
     assert torch.equal(outs[0], outs[1])
+
+
+# ---- the step's NT-Xent terms as one launch per phase (csrc/ntxent.hip: sm3_ntxent_fused_batch) ----------------------------
+@pytest.mark.parametrize("dt", DTYPES3, ids=IDS3)
+@pytest.mark.parametrize("n,R,D,scaled", [(4, 512, 128, False), (4, 64, 128, True), (2, 24, 64, False), (1, 512, 128, True),
+                                          (3, 130, 32, False)])
+def test_batched_ntxent_terms_equal_the_per_term_calls_bit_for_bit(n, R, D, scaled, dt):
+    ops = _ops()
+    code = ops.dtype_code(dt)
+    g = torch.Generator().manual_seed(n * 1000 + R + D)
+    zs = [torch.randn(R, D, generator=g).to(dev()) for _ in range(n)]
+    weights = [1.0, 1.0, 0.5, 0.5][:n]
+    scale = torch.tensor([1024.0], device=dev()) if scaled else None
+    per = ops.ntxent_workspace_floats(R, D)
+    # term by term (what the trainer did until round 6)
+    loss_ref = torch.zeros(1, device=dev())
+    dz_ref = [torch.empty(R, D, dtype=dt, device=dev()) for _ in range(n)]
+    ws1 = torch.empty(per, device=dev())
+    for z, w, d in zip(zs, weights, dz_ref):
+        ops.ntxent_fused(code, z, 0.1, w, ws1, loss_ref, d, dz_scale=scale)
+    # one launch per phase
+    loss = torch.zeros(1, device=dev())
+    dz = [torch.full((R, D), float("nan"), dtype=dt, device=dev()) for _ in range(n)]
+    ws = torch.empty(ops.ntxent_batch_workspace_floats(n, R, D), device=dev())
+    assert ops.ntxent_fused_batch(code, zs, 0.1, weights, ws, loss, dz, dz_scale=scale)
+    torch.cuda.synchronize()
+    assert torch.equal(loss, loss_ref) and float(loss) > 0
+    for a, b in zip(dz, dz_ref):
+        assert torch.equal(a, b)
